@@ -1,0 +1,140 @@
+/* sageicp.h — C ABI of libsageicp_hip.so: the MI355X (gfx950) implementation of SAGE-ICP's
+ * per-scan registration hot path.  Plain pointers and sizes only; no Eigen/Sophus/torch types.
+ *
+ * Every entry point below is what a binding of the reference's C++ interface for this path
+ * would call; the reference interface each one replaces is cited as file:line relative to
+ * NeSC-IV/sage-icp @ 2024_10_08, directory cpp/sage_icp/.  INTEGRATION.md shows the header
+ * shim (sage-icp_amd/shim/sage_icp/core/{VoxelHashMap,Registration}.hpp) that keeps the
+ * reference's C++ signatures on top of this ABI so ros/ros2/OdometryServer.cpp and
+ * pipeline/sageICP.cpp compile unchanged.
+ *
+ * Conventions
+ *   points   double[n][4] row-major = (x, y, z, label); identical to the memory of
+ *            std::vector<Eigen::Vector4d>::data().
+ *   pose     double[7] = (qx, qy, qz, qw, tx, ty, tz); identical to Sophus::SE3d::data().
+ *   return   0 on success, negative on error (never throws); sageicp_last_error() gives text.
+ *   threads  one call at a time per map handle (the reference's single ROS executor thread,
+ *            ros/ros2/OdometryServer.cpp:356).  Different handles may be used concurrently.
+ *   device   the HIP path is the only path: without a gfx950 device every compute entry
+ *            returns SAGEICP_ERR_NO_DEVICE.  There is no CPU fallback in this library.
+ */
+#ifndef SAGEICP_H_
+#define SAGEICP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAGEICP_OK 0
+#define SAGEICP_ERR_INVALID (-1)    /* bad argument */
+#define SAGEICP_ERR_NO_DEVICE (-2)  /* no usable gfx950 device / HIP runtime failure at init */
+#define SAGEICP_ERR_HIP (-3)        /* a HIP call failed */
+#define SAGEICP_ERR_RCCL (-4)       /* RCCL could not be loaded or a collective failed */
+#define SAGEICP_ERR_CAPACITY (-5)   /* > 2^23 voxels or > 255 points per voxel */
+
+typedef struct sageicp_map sageicp_map;       /* opaque: host map + device mirror + scratch */
+typedef struct sageicp_frame sageicp_frame;   /* opaque: a scan resident in HBM */
+typedef struct sageicp_comm sageicp_comm;     /* opaque: RCCL communicator for query sharding */
+
+/* Filled by sageicp_register_frame*.  Times are microseconds. */
+typedef struct sageicp_stats {
+    int32_t iterations;         /* ICP iterations executed (<= 500, Registration.cpp:96) */
+    int32_t converged;          /* 1 if ||log(est)|| < 1e-4 ended the loop (Registration.cpp:137) */
+    uint64_t n_queries;         /* points of the frame (this rank's shard) */
+    uint64_t n_corr_first;      /* accepted correspondences, first iteration (all ranks) */
+    uint64_t n_corr_last;       /* accepted correspondences, last iteration (all ranks) */
+    double last_step_norm;      /* ||log(est)|| of the last iteration */
+    double us_wall;             /* host wall time of the call */
+    double us_upload;           /* frame H2D + lazy map-mirror refresh inside the call */
+    /* device time per kernel summed over the executed iterations (HIP events on the launch
+     * stream); filled only when profiling is enabled with sageicp_set_profiling(). */
+    double us_nn;
+    double us_gn;
+    double us_fin;
+    uint32_t nn_launches;
+    uint32_t reserved;
+    uint32_t n_corr_hist[64];   /* accepted correspondences of the first 64 iterations */
+} sageicp_stats;
+
+/* ---- library ------------------------------------------------------------------------ */
+int sageicp_abi_version(void);
+const char *sageicp_last_error(void);
+int sageicp_device_count(void);               /* number of visible HIP devices (0: none) */
+void sageicp_set_profiling(int enabled);      /* per-kernel HIP-event timing in stats */
+
+/* ---- map: sage_icp::VoxelHashMap (core/VoxelHashMap.hpp:35-107) ------------------------ */
+/* ctor, VoxelHashMap.hpp:79-88.  device: HIP device ordinal that will hold the mirror. */
+sageicp_map *sageicp_map_create(double voxel_size, double max_distance,
+                                int basic_points_per_voxel, int critical_points_per_voxel,
+                                const int *basic_parts_labels, int n_labels, int device);
+void sageicp_map_destroy(sageicp_map *map);
+/* copy construction / copy assignment (ros/ros2/OdometryServer.cpp:104 copy-assigns the pipeline) */
+sageicp_map *sageicp_map_clone(const sageicp_map *map);
+int sageicp_map_clear(sageicp_map *map);                    /* Clear(), VoxelHashMap.hpp:93 */
+int sageicp_map_empty(const sageicp_map *map);              /* Empty(), VoxelHashMap.hpp:94 */
+uint64_t sageicp_map_size(const sageicp_map *map);          /* points held (== Pointcloud().size()) */
+uint64_t sageicp_map_num_voxels(const sageicp_map *map);
+/* AddPoints, VoxelHashMap.cpp:162-174 (sequential semantic retention policy, .hpp:45-70) */
+int sageicp_map_add_points(sageicp_map *map, const double *xyzl, uint64_t n);
+/* RemovePointsFarFromLocation, VoxelHashMap.cpp:176-184 */
+int sageicp_map_remove_far(sageicp_map *map, const double origin[3]);
+/* Update(points, origin), VoxelHashMap.cpp:144-147 */
+int sageicp_map_update(sageicp_map *map, const double *xyzl, uint64_t n, const double origin[3]);
+/* Update(points, pose), VoxelHashMap.cpp:149-160 */
+int sageicp_map_update_pose(sageicp_map *map, const double *xyzl, uint64_t n,
+                            const double pose[7]);
+/* Pointcloud(), VoxelHashMap.cpp:132-142.  Returns the number of points the map holds; writes
+ * at most `cap` of them. */
+uint64_t sageicp_map_pointcloud(const sageicp_map *map, double *out_xyzl, uint64_t cap);
+/* Push pending host-side changes to the HBM mirror now (otherwise done lazily by the next
+ * search).  Lets a caller keep the refresh out of a timed region. */
+int sageicp_map_sync(const sageicp_map *map);
+
+/* ---- search: VoxelHashMap::GetCorrespondences (core/VoxelHashMap.cpp:48-130) ------------ */
+/* src_out / tgt_out: capacity n*4 doubles each; pairs are emitted in query order.
+ * query_idx_out (optional, capacity n): index of the query behind each pair. */
+int sageicp_get_correspondences(const sageicp_map *map, const double *q_xyzl, uint64_t n,
+                                double max_correspondence_distance, double sem_th,
+                                double *src_out, double *tgt_out, uint64_t *n_out,
+                                int64_t *query_idx_out);
+
+/* ---- Gauss-Newton step: AlignClouds (core/Registration.cpp:59-94) ----------------------- */
+/* JTJ_out (36, row-major) and JTr_out (6) are optional.  device: HIP device ordinal. */
+int sageicp_align_clouds(const double *src_xyzl, const double *tgt_xyzl, uint64_t n, double kernel,
+                         double pose_out[7], double *JTJ_out, double *JTr_out, int device);
+
+/* ---- TransformPoints (core/Registration.hpp:32, Registration.cpp:103-111) ---------------- */
+int sageicp_transform_points(const double pose[7], double *xyzl, uint64_t n, int device);
+
+/* ---- RegisterFrame (core/Registration.hpp:34-39, Registration.cpp:113-141) --------------- */
+int sageicp_register_frame(const sageicp_map *map, const double *frame_xyzl, uint64_t n,
+                           const double initial_guess[7], double max_correspondence_distance,
+                           double kernel, double sem_th, double pose_out[7],
+                           sageicp_stats *stats /* optional */);
+
+/* The same call on a scan already resident in HBM (what bench.py times), optionally sharded
+ * over the ranks of `comm` (NULL: single GPU).  Each rank passes ITS contiguous block of the
+ * frame; the map is replicated; the 17 Gauss-Newton sums are all-reduced over RCCL/xGMI every
+ * iteration, so every rank returns the same pose. */
+sageicp_frame *sageicp_frame_upload(const sageicp_map *map, const double *frame_xyzl, uint64_t n);
+void sageicp_frame_destroy(sageicp_frame *frame);
+int sageicp_register_frame_resident(const sageicp_map *map, const sageicp_frame *frame,
+                                    const double initial_guess[7],
+                                    double max_correspondence_distance, double kernel,
+                                    double sem_th, sageicp_comm *comm /* optional */,
+                                    double pose_out[7], sageicp_stats *stats /* optional */);
+
+/* ---- query sharding across GPUs (one process per GPU, RCCL over xGMI) -------------------- */
+#define SAGEICP_UNIQUE_ID_BYTES 128
+int sageicp_comm_unique_id(uint8_t id_out[SAGEICP_UNIQUE_ID_BYTES]);   /* rank 0, then broadcast */
+sageicp_comm *sageicp_comm_create(const uint8_t id[SAGEICP_UNIQUE_ID_BYTES], int rank, int nranks,
+                                  int device);
+void sageicp_comm_destroy(sageicp_comm *comm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAGEICP_H_ */

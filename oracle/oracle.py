@@ -1,0 +1,229 @@
+"""ctypes binding of oracle/libsage_oracle.so — TEST INFRASTRUCTURE ONLY.
+
+May be imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg.  The product (sage-icp_amd/) never imports this module.  Parity is UNPINNED by
+the reference (it holds no tests or vectors for this path); see sage_oracle.cpp.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libsage_oracle.so")
+
+_dp = C.POINTER(C.c_double)
+_u64p = C.POINTER(C.c_uint64)
+_i64p = C.POINTER(C.c_int64)
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int),
+        ("converged", C.c_int),
+        ("n_corr_first", C.c_uint64),
+        ("n_corr_last", C.c_uint64),
+        ("sum_candidates_first", C.c_uint64),
+        ("sum_candidates_total", C.c_uint64),
+        ("sum_corr_total", C.c_uint64),
+        ("last_step_norm", C.c_double),
+        ("seconds_nn", C.c_double),
+        ("seconds_gn", C.c_double),
+        ("seconds_tf", C.c_double),
+    ]
+
+
+def build(force=False):
+    """Compile the oracle with g++ (oracle/Makefile)."""
+    if force or not os.path.exists(_LIB_PATH) or (
+        os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "sage_oracle.cpp"))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libsage_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.sgo_map_create.restype = C.c_void_p
+        L.sgo_map_create.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int,
+                                     C.POINTER(C.c_int), C.c_int]
+        L.sgo_map_destroy.argtypes = [C.c_void_p]
+        L.sgo_map_clear.argtypes = [C.c_void_p]
+        L.sgo_map_empty.argtypes = [C.c_void_p]
+        L.sgo_map_num_voxels.restype = C.c_uint64
+        L.sgo_map_num_voxels.argtypes = [C.c_void_p]
+        L.sgo_map_size.restype = C.c_uint64
+        L.sgo_map_size.argtypes = [C.c_void_p]
+        L.sgo_map_add_points.argtypes = [C.c_void_p, _dp, C.c_uint64]
+        L.sgo_map_remove_far.argtypes = [C.c_void_p, _dp]
+        L.sgo_map_update_pose.argtypes = [C.c_void_p, _dp, C.c_uint64, _dp]
+        L.sgo_map_pointcloud.restype = C.c_uint64
+        L.sgo_map_pointcloud.argtypes = [C.c_void_p, _dp, C.c_uint64]
+        L.sgo_get_correspondences.argtypes = [C.c_void_p, _dp, C.c_uint64, C.c_double, C.c_double,
+                                              _dp, _dp, _u64p, _i64p, _u64p, C.c_int]
+        L.sgo_align_clouds.argtypes = [_dp, _dp, C.c_uint64, C.c_double, _dp, _dp, _dp, C.c_int]
+        L.sgo_transform_points.argtypes = [_dp, _dp, C.c_uint64]
+        L.sgo_register_frame.argtypes = [C.c_void_p, _dp, C.c_uint64, _dp, C.c_double, C.c_double,
+                                         C.c_double, _dp, C.POINTER(Stats), C.c_int]
+        for name, n_in in (("sgo_se3_exp", 1), ("sgo_se3_log", 1), ("sgo_se3_inv", 1),
+                           ("sgo_se3_mul", 2), ("sgo_se3_apply", 2), ("sgo_ldlt_solve6", 2)):
+            getattr(L, name).argtypes = [_dp] * (n_in + 1)
+        L.sgo_num_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+IDENTITY = np.array([0, 0, 0, 1, 0, 0, 0], dtype=np.float64)
+
+
+def se3_exp(x):
+    x, xp = _d(x)
+    o = np.empty(7)
+    lib().sgo_se3_exp(xp, o.ctypes.data_as(_dp))
+    return o
+
+
+def se3_log(T):
+    T, tp = _d(T)
+    o = np.empty(6)
+    lib().sgo_se3_log(tp, o.ctypes.data_as(_dp))
+    return o
+
+
+def se3_inv(T):
+    T, tp = _d(T)
+    o = np.empty(7)
+    lib().sgo_se3_inv(tp, o.ctypes.data_as(_dp))
+    return o
+
+
+def se3_mul(A, B):
+    A, ap = _d(A)
+    B, bp = _d(B)
+    o = np.empty(7)
+    lib().sgo_se3_mul(ap, bp, o.ctypes.data_as(_dp))
+    return o
+
+
+def se3_apply(T, p):
+    T, tp = _d(T)
+    p, pp = _d(p)
+    o = np.empty(3)
+    lib().sgo_se3_apply(tp, pp, o.ctypes.data_as(_dp))
+    return o
+
+
+def ldlt_solve6(A, b):
+    A, ap = _d(A)
+    b, bp = _d(b)
+    o = np.empty(6)
+    lib().sgo_ldlt_solve6(ap, bp, o.ctypes.data_as(_dp))
+    return o
+
+
+def transform_points(T, pts):
+    T, tp = _d(T)
+    out = np.array(pts, dtype=np.float64, order="C", copy=True).reshape(-1, 4)
+    lib().sgo_transform_points(tp, out.ctypes.data_as(_dp), out.shape[0])
+    return out
+
+
+def align_clouds(src, tgt, kernel, nthreads=1):
+    src, sp = _d(src)
+    tgt, gp = _d(tgt)
+    T = np.empty(7)
+    JTJ = np.empty(36)
+    JTr = np.empty(6)
+    lib().sgo_align_clouds(sp, gp, src.reshape(-1, 4).shape[0], kernel, T.ctypes.data_as(_dp),
+                           JTJ.ctypes.data_as(_dp), JTr.ctypes.data_as(_dp), nthreads)
+    return T, JTJ.reshape(6, 6), JTr
+
+
+class Map:
+    """Mirror of sage_icp::VoxelHashMap (core/VoxelHashMap.hpp:35-107) over the oracle."""
+
+    def __init__(self, voxel_size, max_distance, basic=20, critical=20,
+                 basic_labels=(40, 44, 48, 49, 50, 70, 72)):
+        labels = (C.c_int * len(basic_labels))(*basic_labels)
+        self.voxel_size = voxel_size
+        self._h = lib().sgo_map_create(voxel_size, max_distance, basic, critical, labels,
+                                       len(basic_labels))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().sgo_map_destroy(self._h)
+            self._h = None
+
+    def clear(self):
+        lib().sgo_map_clear(self._h)
+
+    def empty(self):
+        return bool(lib().sgo_map_empty(self._h))
+
+    def num_voxels(self):
+        return int(lib().sgo_map_num_voxels(self._h))
+
+    def size(self):
+        return int(lib().sgo_map_size(self._h))
+
+    def add_points(self, pts):
+        pts, pp = _d(pts)
+        lib().sgo_map_add_points(self._h, pp, pts.reshape(-1, 4).shape[0])
+
+    def remove_far(self, origin):
+        o, op = _d(origin)
+        lib().sgo_map_remove_far(self._h, op)
+
+    def update(self, pts, pose):
+        pts, pp = _d(pts)
+        T, tp = _d(pose)
+        lib().sgo_map_update_pose(self._h, pp, pts.reshape(-1, 4).shape[0], tp)
+
+    def pointcloud(self):
+        n = self.size()
+        out = np.empty((n, 4))
+        lib().sgo_map_pointcloud(self._h, out.ctypes.data_as(_dp), n)
+        return out
+
+    def get_correspondences(self, pts, max_dist, th, nthreads=0, with_index=False):
+        pts, pp = _d(pts)
+        n = pts.reshape(-1, 4).shape[0]
+        src = np.empty((n, 4))
+        tgt = np.empty((n, 4))
+        idx = np.empty(n, dtype=np.int64)
+        nout = C.c_uint64(0)
+        cand = C.c_uint64(0)
+        lib().sgo_get_correspondences(self._h, pp, n, max_dist, th, src.ctypes.data_as(_dp),
+                                      tgt.ctypes.data_as(_dp), C.byref(nout),
+                                      idx.ctypes.data_as(_i64p), C.byref(cand), nthreads)
+        k = nout.value
+        self.last_sum_candidates = cand.value
+        if with_index:
+            return src[:k].copy(), tgt[:k].copy(), idx[:k].copy()
+        return src[:k].copy(), tgt[:k].copy()
+
+    def register_frame(self, frame, init, max_dist, kernel, sem_th, nthreads=0):
+        frame, fp = _d(frame)
+        init, ip = _d(init)
+        out = np.empty(7)
+        st = Stats()
+        lib().sgo_register_frame(self._h, fp, frame.reshape(-1, 4).shape[0], ip, max_dist, kernel,
+                                 sem_th, out.ctypes.data_as(_dp), C.byref(st), nthreads)
+        return out, st
+
+
+def num_threads():
+    return int(lib().sgo_num_threads())

@@ -1,0 +1,303 @@
+"""sage_icp_amd — Python binding (ctypes) of libsageicp_hip.so, the MI355X implementation of
+SAGE-ICP's registration hot path, for tests and bench.py.
+
+The product is the C-ABI shared library (include/sageicp.h) and the C++ header shim in
+shim/; this module only mirrors the reference's interface names on top of it:
+
+    VoxelHashMap            sage_icp::VoxelHashMap   (cpp/sage_icp/core/VoxelHashMap.hpp:35-107)
+    register_frame()        sage_icp::RegisterFrame  (cpp/sage_icp/core/Registration.hpp:34-39)
+    transform_points()      sage_icp::TransformPoints(cpp/sage_icp/core/Registration.hpp:32)
+    align_clouds()          AlignClouds              (cpp/sage_icp/core/Registration.cpp:59-94)
+
+There is no CPU fallback: if the library has not been built, importing a compute symbol raises;
+if no HIP device is present every compute call raises SageIcpError(SAGEICP_ERR_NO_DEVICE).
+The directory is named `sage-icp_amd`; import it as `sage_icp_amd` through the loader module
+/sage_icp_amd.py at the repo root.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsageicp_hip.so")
+
+_dp = C.POINTER(C.c_double)
+_u64p = C.POINTER(C.c_uint64)
+_i64p = C.POINTER(C.c_int64)
+_u8p = C.POINTER(C.c_uint8)
+
+ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_RCCL, ERR_CAPACITY = -1, -2, -3, -4, -5
+UNIQUE_ID_BYTES = 128
+
+IDENTITY = np.array([0, 0, 0, 1, 0, 0, 0], dtype=np.float64)
+
+
+class SageIcpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("sageicp error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int32),
+        ("converged", C.c_int32),
+        ("n_queries", C.c_uint64),
+        ("n_corr_first", C.c_uint64),
+        ("n_corr_last", C.c_uint64),
+        ("last_step_norm", C.c_double),
+        ("us_wall", C.c_double),
+        ("us_upload", C.c_double),
+        ("us_nn", C.c_double),
+        ("us_gn", C.c_double),
+        ("us_fin", C.c_double),
+        ("nn_launches", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("n_corr_hist", C.c_uint32 * 64),
+    ]
+
+
+# every symbol include/sageicp.h declares: (name, restype, argtypes)
+_SIGNATURES = [
+    ("sageicp_abi_version", C.c_int, []),
+    ("sageicp_last_error", C.c_char_p, []),
+    ("sageicp_device_count", C.c_int, []),
+    ("sageicp_set_profiling", None, [C.c_int]),
+    ("sageicp_map_create", C.c_void_p,
+     [C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]),
+    ("sageicp_map_destroy", None, [C.c_void_p]),
+    ("sageicp_map_clone", C.c_void_p, [C.c_void_p]),
+    ("sageicp_map_clear", C.c_int, [C.c_void_p]),
+    ("sageicp_map_empty", C.c_int, [C.c_void_p]),
+    ("sageicp_map_size", C.c_uint64, [C.c_void_p]),
+    ("sageicp_map_num_voxels", C.c_uint64, [C.c_void_p]),
+    ("sageicp_map_add_points", C.c_int, [C.c_void_p, _dp, C.c_uint64]),
+    ("sageicp_map_remove_far", C.c_int, [C.c_void_p, _dp]),
+    ("sageicp_map_update", C.c_int, [C.c_void_p, _dp, C.c_uint64, _dp]),
+    ("sageicp_map_update_pose", C.c_int, [C.c_void_p, _dp, C.c_uint64, _dp]),
+    ("sageicp_map_pointcloud", C.c_uint64, [C.c_void_p, _dp, C.c_uint64]),
+    ("sageicp_map_sync", C.c_int, [C.c_void_p]),
+    ("sageicp_get_correspondences", C.c_int,
+     [C.c_void_p, _dp, C.c_uint64, C.c_double, C.c_double, _dp, _dp, _u64p, _i64p]),
+    ("sageicp_align_clouds", C.c_int, [_dp, _dp, C.c_uint64, C.c_double, _dp, _dp, _dp, C.c_int]),
+    ("sageicp_transform_points", C.c_int, [_dp, _dp, C.c_uint64, C.c_int]),
+    ("sageicp_register_frame", C.c_int,
+     [C.c_void_p, _dp, C.c_uint64, _dp, C.c_double, C.c_double, C.c_double, _dp,
+      C.POINTER(Stats)]),
+    ("sageicp_frame_upload", C.c_void_p, [C.c_void_p, _dp, C.c_uint64]),
+    ("sageicp_frame_destroy", None, [C.c_void_p]),
+    ("sageicp_register_frame_resident", C.c_int,
+     [C.c_void_p, C.c_void_p, _dp, C.c_double, C.c_double, C.c_double, C.c_void_p, _dp,
+      C.POINTER(Stats)]),
+    ("sageicp_comm_unique_id", C.c_int, [_u8p]),
+    ("sageicp_comm_create", C.c_void_p, [_u8p, C.c_int, C.c_int, C.c_int]),
+    ("sageicp_comm_destroy", None, [C.c_void_p]),
+]
+
+EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
+
+_lib = None
+
+
+def lib():
+    """Load libsageicp_hip.so.  Raises (loudly) if it has not been built — no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, res, args in _SIGNATURES:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise SageIcpError(rc, (lib().sageicp_last_error() or b"").decode())
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+def device_count():
+    return int(lib().sageicp_device_count())
+
+
+def set_profiling(on):
+    lib().sageicp_set_profiling(1 if on else 0)
+
+
+class Frame:
+    """A scan resident in HBM (sageicp_frame)."""
+
+    def __init__(self, vmap, pts):
+        pts, pp = _d(pts)
+        self.n = pts.reshape(-1, 4).shape[0]
+        self._h = lib().sageicp_frame_upload(vmap._h, pp, self.n)
+        if not self._h:
+            raise SageIcpError(ERR_HIP, (lib().sageicp_last_error() or b"").decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().sageicp_frame_destroy(self._h)
+            self._h = None
+
+
+class Comm:
+    """RCCL communicator for query-sharded registration (one process per GPU)."""
+
+    def __init__(self, unique_id, rank, nranks, device):
+        buf = (C.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        self.rank, self.nranks = rank, nranks
+        self._h = lib().sageicp_comm_create(buf, rank, nranks, device)
+        if not self._h:
+            raise SageIcpError(ERR_RCCL, (lib().sageicp_last_error() or b"").decode())
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * UNIQUE_ID_BYTES)()
+        _check(lib().sageicp_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().sageicp_comm_destroy(self._h)
+            self._h = None
+
+
+class VoxelHashMap:
+    """sage_icp::VoxelHashMap (core/VoxelHashMap.hpp:35-107) over the C ABI."""
+
+    def __init__(self, voxel_size, max_distance, basic_points_per_voxel=20,
+                 critical_points_per_voxel=20, basic_parts_labels=(40, 44, 48, 49, 50, 70, 72),
+                 device=0, _handle=None):
+        self.voxel_size_ = voxel_size
+        self.max_distance_ = max_distance
+        self.basic_points_per_voxel_ = basic_points_per_voxel
+        self.critical_points_per_voxel_ = critical_points_per_voxel
+        self.basic_parts_labels_ = list(basic_parts_labels)
+        self.device = device
+        if _handle is not None:
+            self._h = _handle
+            return
+        labels = (C.c_int * len(self.basic_parts_labels_))(*self.basic_parts_labels_)
+        self._h = lib().sageicp_map_create(voxel_size, max_distance, basic_points_per_voxel,
+                                           critical_points_per_voxel, labels,
+                                           len(self.basic_parts_labels_), device)
+        if not self._h:
+            raise SageIcpError(ERR_INVALID, (lib().sageicp_last_error() or b"").decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().sageicp_map_destroy(self._h)
+            self._h = None
+
+    def clone(self):
+        h = lib().sageicp_map_clone(self._h)
+        return VoxelHashMap(self.voxel_size_, self.max_distance_, self.basic_points_per_voxel_,
+                            self.critical_points_per_voxel_, self.basic_parts_labels_,
+                            self.device, _handle=h)
+
+    # names follow the reference's members
+    def Clear(self):
+        _check(lib().sageicp_map_clear(self._h))
+
+    def Empty(self):
+        return bool(lib().sageicp_map_empty(self._h))
+
+    def size(self):
+        return int(lib().sageicp_map_size(self._h))
+
+    def num_voxels(self):
+        return int(lib().sageicp_map_num_voxels(self._h))
+
+    def AddPoints(self, pts):
+        pts, pp = _d(pts)
+        _check(lib().sageicp_map_add_points(self._h, pp, pts.reshape(-1, 4).shape[0]))
+
+    def RemovePointsFarFromLocation(self, origin):
+        o, op = _d(origin)
+        _check(lib().sageicp_map_remove_far(self._h, op))
+
+    def Update(self, pts, pose_or_origin):
+        pts, pp = _d(pts)
+        x, xp = _d(pose_or_origin)
+        n = pts.reshape(-1, 4).shape[0]
+        if x.size == 7:
+            _check(lib().sageicp_map_update_pose(self._h, pp, n, xp))
+        elif x.size == 3:
+            _check(lib().sageicp_map_update(self._h, pp, n, xp))
+        else:
+            raise ValueError("Update takes a pose[7] or an origin[3]")
+
+    def Pointcloud(self):
+        n = self.size()
+        out = np.empty((n, 4))
+        lib().sageicp_map_pointcloud(self._h, out.ctypes.data_as(_dp), n)
+        return out
+
+    def sync(self):
+        _check(lib().sageicp_map_sync(self._h))
+
+    def GetCorrespondences(self, pts, max_correspondance_distance, th, with_index=False):
+        pts, pp = _d(pts)
+        n = pts.reshape(-1, 4).shape[0]
+        src = np.empty((n, 4))
+        tgt = np.empty((n, 4))
+        idx = np.empty(n, dtype=np.int64)
+        nout = C.c_uint64(0)
+        _check(lib().sageicp_get_correspondences(
+            self._h, pp, n, max_correspondance_distance, th, src.ctypes.data_as(_dp),
+            tgt.ctypes.data_as(_dp), C.byref(nout), idx.ctypes.data_as(_i64p)))
+        k = nout.value
+        if with_index:
+            return src[:k].copy(), tgt[:k].copy(), idx[:k].copy()
+        return src[:k].copy(), tgt[:k].copy()
+
+
+def register_frame(frame, voxel_map, initial_guess, max_correspondence_distance, kernel, sem_th,
+                   comm=None, return_stats=False):
+    """sage_icp::RegisterFrame (core/Registration.cpp:113-141).  `frame` is an (n,4) array or a
+    resident Frame; with `comm` the call is one rank of a query-sharded registration."""
+    init, ip = _d(initial_guess)
+    out = np.empty(7)
+    st = Stats()
+    if isinstance(frame, Frame):
+        _check(lib().sageicp_register_frame_resident(
+            voxel_map._h, frame._h, ip, max_correspondence_distance, kernel, sem_th,
+            comm._h if comm is not None else None, out.ctypes.data_as(_dp), C.byref(st)))
+    else:
+        if comm is not None:
+            raise ValueError("sharded registration needs a resident Frame")
+        pts, pp = _d(frame)
+        _check(lib().sageicp_register_frame(
+            voxel_map._h, pp, pts.reshape(-1, 4).shape[0], ip, max_correspondence_distance,
+            kernel, sem_th, out.ctypes.data_as(_dp), C.byref(st)))
+    return (out, st) if return_stats else out
+
+
+def transform_points(pose, pts, device=0):
+    T, tp = _d(pose)
+    out = np.array(pts, dtype=np.float64, order="C", copy=True).reshape(-1, 4)
+    _check(lib().sageicp_transform_points(tp, out.ctypes.data_as(_dp), out.shape[0], device))
+    return out
+
+
+def align_clouds(src, tgt, kernel, device=0):
+    src, sp = _d(src)
+    tgt, gp = _d(tgt)
+    T = np.empty(7)
+    JTJ = np.empty(36)
+    JTr = np.empty(6)
+    _check(lib().sageicp_align_clouds(sp, gp, src.reshape(-1, 4).shape[0], kernel,
+                                      T.ctypes.data_as(_dp), JTJ.ctypes.data_as(_dp),
+                                      JTr.ctypes.data_as(_dp), device))
+    return T, JTJ.reshape(6, 6), JTr

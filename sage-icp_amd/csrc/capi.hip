@@ -1,0 +1,675 @@
+// C ABI of libsageicp_hip.so (include/sageicp.h): host side of the SAGE-ICP registration hot
+// path on MI355X.  Owns the host-authoritative map, its HBM mirror, the per-map stream and
+// scratch, the ICP launch loop (no host round trip per iteration: kernels early-exit on a
+// device-resident `done` flag and the host polls it once per chunk of iterations) and the
+// optional RCCL exchange of the Gauss-Newton sums for query-sharded multi-GPU runs.
+//
+// Reference call sites this file stands in for (cpp/sage_icp/):
+//   core/Registration.cpp:113-141   RegisterFrame        -> run_icp()
+//   core/VoxelHashMap.cpp:48-130    GetCorrespondences   -> sageicp_get_correspondences()
+//   core/VoxelHashMap.cpp:144-184   Update/AddPoints/... -> HostMap (host_map.hpp)
+// There is no CPU fallback: without a HIP device the compute entries fail with
+// SAGEICP_ERR_NO_DEVICE.
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/sageicp.h"
+#include "host_map.hpp"
+#include "kernels.h"
+#include "se3_math.h"
+#include "sageicp_types.h"
+
+namespace sageicp {
+
+// ---- errors --------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int g_profiling = 0;
+
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess)                                                             \
+            return fail(SAGEICP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+static double now_us() {
+    using namespace std::chrono;
+    return duration<double, std::micro>(steady_clock::now().time_since_epoch()).count();
+}
+
+// ---- per-handle device scratch -----------------------------------------------------------
+constexpr int kChunkMax = 16;
+
+struct Scratch {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    Point4 *d_frame = nullptr; size_t frame_cap = 0;
+    Point4 *d_tgt = nullptr; size_t tgt_cap = 0;
+    int32_t *d_nn = nullptr; size_t nn_cap = 0;
+    double *d_partials = nullptr;
+    IcpState *d_state = nullptr;
+    IcpState *h_state = nullptr;   // pinned
+    std::vector<hipEvent_t> events;  // 4 per iteration of a chunk
+
+    int init(int dev) {
+        if (stream) return SAGEICP_OK;
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+            return fail(SAGEICP_ERR_NO_DEVICE, "no HIP device visible (gfx950 required; no CPU fallback)");
+        if (dev < 0 || dev >= count) return fail(SAGEICP_ERR_INVALID, "device ordinal out of range");
+        device = dev;
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIPCHK(hipMalloc(&d_partials, sizeof(double) * kMaxGnBlocks * kNumSums));
+        HIPCHK(hipMalloc(&d_state, sizeof(IcpState)));
+        HIPCHK(hipHostMalloc(&h_state, sizeof(IcpState), hipHostMallocDefault));
+        return SAGEICP_OK;
+    }
+    int reserve_frame(size_t n) {
+        if (n <= frame_cap) return SAGEICP_OK;
+        if (d_frame) HIPCHK(hipFree(d_frame));
+        d_frame = nullptr; frame_cap = 0;
+        const size_t cap = n + n / 4 + 1024;
+        HIPCHK(hipMalloc(&d_frame, cap * sizeof(Point4)));
+        frame_cap = cap;
+        return SAGEICP_OK;
+    }
+    int reserve_tgt(size_t n) {
+        if (n <= tgt_cap) return SAGEICP_OK;
+        if (d_tgt) HIPCHK(hipFree(d_tgt));
+        d_tgt = nullptr; tgt_cap = 0;
+        const size_t cap = n + n / 4 + 1024;
+        HIPCHK(hipMalloc(&d_tgt, cap * sizeof(Point4)));
+        tgt_cap = cap;
+        return SAGEICP_OK;
+    }
+    int reserve_nn(size_t n) {
+        if (n <= nn_cap) return SAGEICP_OK;
+        if (d_nn) HIPCHK(hipFree(d_nn));
+        d_nn = nullptr; nn_cap = 0;
+        const size_t cap = n + n / 4 + 1024;
+        HIPCHK(hipMalloc(&d_nn, cap * sizeof(int32_t)));
+        nn_cap = cap;
+        return SAGEICP_OK;
+    }
+    int reserve_events() {
+        if (!events.empty()) return SAGEICP_OK;
+        events.resize(4 * kChunkMax);
+        for (auto &e : events) HIPCHK(hipEventCreate(&e));
+        return SAGEICP_OK;
+    }
+    void destroy() {
+        if (!stream) return;
+        (void)hipSetDevice(device);
+        (void)hipStreamSynchronize(stream);
+        for (auto &e : events) (void)hipEventDestroy(e);
+        events.clear();
+        if (d_frame) (void)hipFree(d_frame);
+        if (d_tgt) (void)hipFree(d_tgt);
+        if (d_nn) (void)hipFree(d_nn);
+        if (d_partials) (void)hipFree(d_partials);
+        if (d_state) (void)hipFree(d_state);
+        if (h_state) (void)hipHostFree(h_state);
+        (void)hipStreamDestroy(stream);
+        *this = Scratch();
+    }
+};
+
+}  // namespace sageicp
+
+using namespace sageicp;
+
+// ---- opaque handles -----------------------------------------------------------------------
+struct sageicp_map {
+    HostMap host;
+    int device = 0;
+    // device mirror + scratch: logically a cache of `host`, refreshed lazily by const searches
+    mutable Scratch sc;
+    mutable Slot *d_table = nullptr;
+    mutable size_t d_table_cap = 0;      // slots
+    mutable Point4 *d_pts = nullptr;
+    mutable size_t d_blocks_cap = 0;     // blocks
+    mutable bool mirror_stale_all = true;
+};
+
+struct sageicp_frame {
+    int device = 0;
+    Point4 *d = nullptr;
+    uint64_t n = 0;
+};
+
+struct sageicp_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1, device = 0;
+};
+
+// ---- RCCL, bound at run time (only multi-GPU runs need it) ------------------------------------
+namespace {
+struct Rccl {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                              hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+
+int load_rccl() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.h) return SAGEICP_OK;
+    // Prefer an RCCL the process already holds (torch ships one), then the ROCm install.
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        if (h) break;
+    }
+    for (int i = 0; i < 3 && !h; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(SAGEICP_ERR_RCCL, std::string("cannot load librccl: ") + dlerror());
+    g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce)
+        return fail(SAGEICP_ERR_RCCL, "librccl lacks a required symbol");
+    g_rccl.h = h;
+    return SAGEICP_OK;
+}
+
+// ---- device mirror ------------------------------------------------------------------------
+int sync_mirror(const sageicp_map *m) {
+    int rc = m->sc.init(m->device);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(m->device));
+    const HostMap &h = m->host;
+    hipStream_t s = m->sc.stream;
+    bool any = false;
+    // slot table: whole-table refresh (16 B/slot; a few MB) whenever any slot changed
+    if (h.table.size() != m->d_table_cap) {
+        if (m->d_table) HIPCHK(hipFree(m->d_table));
+        m->d_table = nullptr; m->d_table_cap = 0;
+        HIPCHK(hipMalloc(&m->d_table, h.table.size() * sizeof(Slot)));
+        m->d_table_cap = h.table.size();
+        m->mirror_stale_all = true;
+    }
+    if (h.table_dirty || m->mirror_stale_all) {
+        HIPCHK(hipMemcpyAsync(m->d_table, h.table.data(), h.table.size() * sizeof(Slot),
+                              hipMemcpyHostToDevice, s));
+        any = true;
+    }
+    // point blocks: full refresh after (re)allocation, otherwise coalesced dirty runs
+    const size_t blocks_cap = h.cnt.size();
+    const size_t block_bytes = static_cast<size_t>(h.cap) * sizeof(Point4);
+    bool full = m->mirror_stale_all;
+    if (blocks_cap > m->d_blocks_cap) {
+        if (m->d_pts) HIPCHK(hipFree(m->d_pts));
+        m->d_pts = nullptr; m->d_blocks_cap = 0;
+        HIPCHK(hipMalloc(&m->d_pts, std::max<size_t>(blocks_cap, 1) * block_bytes));
+        m->d_blocks_cap = blocks_cap;
+        full = true;
+    }
+    if (full) {
+        if (h.blocks_hi) {
+            HIPCHK(hipMemcpyAsync(m->d_pts, h.pts.data(), h.blocks_hi * block_bytes,
+                                  hipMemcpyHostToDevice, s));
+            any = true;
+        }
+    } else if (!h.dirty_list.empty()) {
+        std::vector<uint32_t> d(h.dirty_list);
+        std::sort(d.begin(), d.end());
+        size_t i = 0;
+        while (i < d.size()) {
+            size_t j = i;
+            while (j + 1 < d.size() && d[j + 1] <= d[j] + 4) ++j;   // bridge small gaps
+            const size_t b0 = d[i], b1 = d[j] + 1;
+            HIPCHK(hipMemcpyAsync(m->d_pts + b0 * h.cap, h.pts.data() + b0 * h.cap,
+                                  (b1 - b0) * block_bytes, hipMemcpyHostToDevice, s));
+            i = j + 1;
+        }
+        any = true;
+    }
+    if (any) HIPCHK(hipStreamSynchronize(s));
+    const_cast<HostMap &>(h).clear_dirty();
+    m->mirror_stale_all = false;
+    return SAGEICP_OK;
+}
+
+void identity_pose(double T[7]) {
+    T[0] = T[1] = T[2] = 0.0; T[3] = 1.0; T[4] = T[5] = T[6] = 0.0;
+}
+
+void fill_state(IcpState *st, const double init[7]) {
+    std::memset(st, 0, sizeof(IcpState));
+    for (int i = 0; i < 7; ++i) st->T[i] = init[i];
+    quat_to_mat(init, st->R);
+    identity_pose(st->T_icp);
+}
+
+// The ICP loop of Registration.cpp:127-138 as a stream of launches.
+int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const double init[7],
+            double max_dist, double kernel, double sem_th, sageicp_comm *comm, double out[7],
+            sageicp_stats *stats, double us_upload, double t_begin) {
+    Scratch &sc = m->sc;
+    hipStream_t s = sc.stream;
+    if (n > 0x7FFFFFFFull) return fail(SAGEICP_ERR_INVALID, "frame too large");
+    int rc = sc.reserve_nn(n);
+    if (rc) return rc;
+    const bool prof = g_profiling != 0;
+    if (prof && (rc = sc.reserve_events())) return rc;
+
+    fill_state(sc.h_state, init);
+    HIPCHK(hipMemcpyAsync(sc.d_state, sc.h_state, sizeof(IcpState), hipMemcpyHostToDevice, s));
+
+    NnParams np{d_frame, static_cast<int>(n), sc.d_state, m->d_table, m->host.mask, m->d_pts,
+                m->host.cap, m->host.voxel_size, sem_th, max_dist, sc.d_nn};
+    GnParams gp{d_frame, nullptr, static_cast<int>(n), sc.d_state, m->d_pts, sc.d_nn, kernel,
+                sc.d_partials, 1};
+    const int gn_blocks = gn_grid_for(static_cast<int>(n));
+
+    double us_nn = 0, us_gn = 0, us_fin = 0;
+    uint32_t nn_launches = 0;
+    int launched = 0;
+    int chunk = 4;
+    for (;;) {
+        const int todo = std::min(chunk, kMaxIterations - launched);
+        for (int k = 0; k < todo; ++k) {
+            if (prof) HIPCHK(hipEventRecord(sc.events[4 * k + 0], s));
+            launch_nn(np, true, s);
+            if (prof) HIPCHK(hipEventRecord(sc.events[4 * k + 1], s));
+            launch_gn(gp, s);
+            if (prof) HIPCHK(hipEventRecord(sc.events[4 * k + 2], s));
+            if (comm) {
+                launch_fin(sc.d_state, sc.d_partials, gn_blocks, 1, 0, s);
+                ncclResult_t r = g_rccl.AllReduce(sc.d_state->sums, sc.d_state->sums, kNumSums,
+                                                  ncclDouble, ncclSum, comm->comm, s);
+                if (r != ncclSuccess)
+                    return fail(SAGEICP_ERR_RCCL, std::string("ncclAllReduce: ") +
+                                                      (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+                launch_fin(sc.d_state, sc.d_partials, gn_blocks, 2, 0, s);
+            } else {
+                launch_fin(sc.d_state, sc.d_partials, gn_blocks, 0, 0, s);
+            }
+            if (prof) HIPCHK(hipEventRecord(sc.events[4 * k + 3], s));
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(sc.h_state, sc.d_state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        const int iters = sc.h_state->iter;
+        if (prof) {
+            const int executed = std::min(todo, iters - launched);   // the rest were no-ops
+            for (int k = 0; k < executed; ++k) {
+                float a = 0, b = 0, c = 0;
+                (void)hipEventElapsedTime(&a, sc.events[4 * k + 0], sc.events[4 * k + 1]);
+                (void)hipEventElapsedTime(&b, sc.events[4 * k + 1], sc.events[4 * k + 2]);
+                (void)hipEventElapsedTime(&c, sc.events[4 * k + 2], sc.events[4 * k + 3]);
+                us_nn += 1e3 * a; us_gn += 1e3 * b; us_fin += 1e3 * c;
+                ++nn_launches;
+            }
+        }
+        launched += todo;
+        if (sc.h_state->done || launched >= kMaxIterations) break;
+        chunk = std::min(kChunkMax, chunk);
+    }
+    const IcpState &st = *sc.h_state;
+    for (int i = 0; i < 7; ++i) out[i] = st.T[i];
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->iterations = st.iter;
+        stats->converged = st.converged;
+        stats->n_queries = n;
+        stats->n_corr_first = st.iter > 0 ? st.n_corr[0] : 0;
+        stats->n_corr_last = st.iter > 0 ? st.n_corr[std::min(st.iter, kHistory) - 1] : 0;
+        stats->last_step_norm = st.last_step_norm;
+        stats->us_upload = us_upload;
+        stats->us_nn = us_nn; stats->us_gn = us_gn; stats->us_fin = us_fin;
+        stats->nn_launches = nn_launches;
+        for (int i = 0; i < 64 && i < st.iter; ++i) stats->n_corr_hist[i] = st.n_corr[i];
+        stats->us_wall = now_us() - t_begin;
+    }
+    return SAGEICP_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+int sageicp_abi_version(void) { return 1; }
+const char *sageicp_last_error(void) { return g_err.c_str(); }
+int sageicp_device_count(void) {
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+void sageicp_set_profiling(int enabled) { g_profiling = enabled; }
+
+// ---- map ----------------------------------------------------------------------------------
+sageicp_map *sageicp_map_create(double voxel_size, double max_distance, int basic, int critical,
+                                const int *labels, int n_labels, int device) {
+    if (!(voxel_size > 0.0) || basic < 0 || critical < 0 || basic + critical < 1 ||
+        basic + critical > kMaxCap || n_labels < 0 || (n_labels > 0 && !labels)) {
+        fail(SAGEICP_ERR_INVALID, "sageicp_map_create: invalid parameters (need voxel_size > 0, "
+                                  "1 <= basic+critical <= 255)");
+        return nullptr;
+    }
+    sageicp_map *m = new sageicp_map;
+    m->host.configure(voxel_size, max_distance, basic, critical, labels, n_labels);
+    m->device = device;
+    return m;
+}
+
+void sageicp_map_destroy(sageicp_map *m) {
+    if (!m) return;
+    if (m->sc.stream) {
+        (void)hipSetDevice(m->device);
+        (void)hipStreamSynchronize(m->sc.stream);
+        if (m->d_table) (void)hipFree(m->d_table);
+        if (m->d_pts) (void)hipFree(m->d_pts);
+    }
+    m->sc.destroy();
+    delete m;
+}
+
+sageicp_map *sageicp_map_clone(const sageicp_map *src) {
+    if (!src) return nullptr;
+    sageicp_map *m = new sageicp_map;
+    m->host = src->host;
+    m->host.table_dirty = true;
+    m->device = src->device;
+    m->mirror_stale_all = true;   // the clone builds its own mirror on first use
+    return m;
+}
+
+int sageicp_map_clear(sageicp_map *m) {
+    if (!m) return fail(SAGEICP_ERR_INVALID, "null map");
+    m->host.clear();
+    m->mirror_stale_all = true;
+    return SAGEICP_OK;
+}
+int sageicp_map_empty(const sageicp_map *m) { return (!m || m->host.empty()) ? 1 : 0; }
+uint64_t sageicp_map_size(const sageicp_map *m) { return m ? m->host.total_points : 0; }
+uint64_t sageicp_map_num_voxels(const sageicp_map *m) { return m ? m->host.num_voxels : 0; }
+
+int sageicp_map_add_points(sageicp_map *m, const double *xyzl, uint64_t n) {
+    if (!m || (n && !xyzl)) return fail(SAGEICP_ERR_INVALID, "null argument");
+    m->host.add_points(xyzl, n);
+    if (m->host.blocks_hi >= (1u << kMaxBlockBits))
+        return fail(SAGEICP_ERR_CAPACITY, "more than 2^23 voxels");
+    return SAGEICP_OK;
+}
+
+int sageicp_map_remove_far(sageicp_map *m, const double origin[3]) {
+    if (!m || !origin) return fail(SAGEICP_ERR_INVALID, "null argument");
+    m->host.remove_far(origin);
+    return SAGEICP_OK;
+}
+
+int sageicp_map_update(sageicp_map *m, const double *xyzl, uint64_t n, const double origin[3]) {
+    int rc = sageicp_map_add_points(m, xyzl, n);
+    if (rc) return rc;
+    return sageicp_map_remove_far(m, origin);
+}
+
+int sageicp_map_update_pose(sageicp_map *m, const double *xyzl, uint64_t n, const double pose[7]) {
+    if (!m || (n && !xyzl) || !pose) return fail(SAGEICP_ERR_INVALID, "null argument");
+    // Update(points, pose): transform into the map frame, origin = pose.translation()
+    double R[9];
+    quat_to_mat(pose, R);
+    std::vector<double> w(4 * n);
+    for (uint64_t i = 0; i < n; ++i) {
+        mat_apply(R, pose + 4, xyzl + 4 * i, &w[4 * i]);
+        w[4 * i + 3] = xyzl[4 * i + 3];
+    }
+    return sageicp_map_update(m, w.data(), n, pose + 4);
+}
+
+uint64_t sageicp_map_pointcloud(const sageicp_map *m, double *out, uint64_t cap) {
+    if (!m) return 0;
+    return m->host.pointcloud(out, out ? cap : 0);
+}
+
+int sageicp_map_sync(const sageicp_map *m) {
+    if (!m) return fail(SAGEICP_ERR_INVALID, "null map");
+    return sync_mirror(m);
+}
+
+// ---- search ---------------------------------------------------------------------------------
+int sageicp_get_correspondences(const sageicp_map *m, const double *q, uint64_t n, double max_dist,
+                                double sem_th, double *src_out, double *tgt_out, uint64_t *n_out,
+                                int64_t *query_idx_out) {
+    if (!m || !n_out || (n && (!q || !src_out || !tgt_out)))
+        return fail(SAGEICP_ERR_INVALID, "null argument");
+    if (n > 0x7FFFFFFFull) return fail(SAGEICP_ERR_INVALID, "too many queries");
+    *n_out = 0;
+    int rc = sync_mirror(m);
+    if (rc) return rc;
+    if (n == 0 || m->host.empty()) return SAGEICP_OK;
+    Scratch &sc = m->sc;
+    if ((rc = sc.reserve_frame(n))) return rc;
+    if ((rc = sc.reserve_nn(n))) return rc;
+    hipStream_t s = sc.stream;
+    HIPCHK(hipMemcpyAsync(sc.d_frame, q, n * sizeof(Point4), hipMemcpyHostToDevice, s));
+    NnParams np{sc.d_frame, static_cast<int>(n), sc.d_state, m->d_table, m->host.mask, m->d_pts,
+                m->host.cap, m->host.voxel_size, sem_th, max_dist, sc.d_nn};
+    launch_nn(np, false, s);
+    HIPCHK(hipGetLastError());
+    std::vector<int32_t> idx(n);
+    HIPCHK(hipMemcpyAsync(idx.data(), sc.d_nn, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    uint64_t k = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (idx[i] < 0) continue;
+        std::memcpy(src_out + 4 * k, q + 4 * i, 32);
+        std::memcpy(tgt_out + 4 * k, &m->host.pts[idx[i]], 32);
+        if (query_idx_out) query_idx_out[k] = static_cast<int64_t>(i);
+        ++k;
+    }
+    *n_out = k;
+    return SAGEICP_OK;
+}
+
+// ---- AlignClouds ------------------------------------------------------------------------------
+int sageicp_align_clouds(const double *src, const double *tgt, uint64_t n, double kernel,
+                         double pose_out[7], double *JTJ_out, double *JTr_out, int device) {
+    if (!pose_out || (n && (!src || !tgt))) return fail(SAGEICP_ERR_INVALID, "null argument");
+    if (n > 0x7FFFFFFFull) return fail(SAGEICP_ERR_INVALID, "too many pairs");
+    Scratch sc;
+    int rc = sc.init(device);
+    if (rc) return rc;
+    auto body = [&]() -> int {
+        HIPCHK(hipSetDevice(device));
+        int r;
+        if ((r = sc.reserve_frame(n))) return r;
+        if ((r = sc.reserve_tgt(n))) return r;
+        hipStream_t s = sc.stream;
+        if (n) {
+            HIPCHK(hipMemcpyAsync(sc.d_frame, src, n * sizeof(Point4), hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(sc.d_tgt, tgt, n * sizeof(Point4), hipMemcpyHostToDevice, s));
+        }
+        double I[7];
+        identity_pose(I);
+        fill_state(sc.h_state, I);
+        HIPCHK(hipMemcpyAsync(sc.d_state, sc.h_state, sizeof(IcpState), hipMemcpyHostToDevice, s));
+        GnParams gp{sc.d_frame, sc.d_tgt, static_cast<int>(n), sc.d_state, nullptr, nullptr, kernel,
+                    sc.d_partials, 0};
+        const int blocks = launch_gn(gp, s);
+        launch_fin(sc.d_state, sc.d_partials, blocks, 0, 1, s);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(sc.h_state, sc.d_state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        // one step from identity: T_icp == est
+        for (int i = 0; i < 7; ++i) pose_out[i] = sc.h_state->T_icp[i];
+        if (JTJ_out || JTr_out) {
+            double JTJ[36], JTr[6];
+            assemble_normal_equations(sc.h_state->sums, JTJ, JTr);
+            if (JTJ_out) std::memcpy(JTJ_out, JTJ, sizeof(JTJ));
+            if (JTr_out) std::memcpy(JTr_out, JTr, sizeof(JTr));
+        }
+        return SAGEICP_OK;
+    };
+    rc = body();
+    sc.destroy();
+    return rc;
+}
+
+// ---- TransformPoints --------------------------------------------------------------------------
+int sageicp_transform_points(const double pose[7], double *xyzl, uint64_t n, int device) {
+    if (!pose || (n && !xyzl)) return fail(SAGEICP_ERR_INVALID, "null argument");
+    if (n > 0x7FFFFFFFull) return fail(SAGEICP_ERR_INVALID, "too many points");
+    Scratch sc;
+    int rc = sc.init(device);
+    if (rc) return rc;
+    auto body = [&]() -> int {
+        HIPCHK(hipSetDevice(device));
+        int r;
+        if ((r = sc.reserve_frame(n))) return r;
+        hipStream_t s = sc.stream;
+        fill_state(sc.h_state, pose);
+        HIPCHK(hipMemcpyAsync(sc.d_state, sc.h_state, sizeof(IcpState), hipMemcpyHostToDevice, s));
+        if (n) {
+            HIPCHK(hipMemcpyAsync(sc.d_frame, xyzl, n * sizeof(Point4), hipMemcpyHostToDevice, s));
+            launch_tf(sc.d_frame, static_cast<int>(n), sc.d_state, s);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(xyzl, sc.d_frame, n * sizeof(Point4), hipMemcpyDeviceToHost, s));
+        }
+        HIPCHK(hipStreamSynchronize(s));
+        return SAGEICP_OK;
+    };
+    rc = body();
+    sc.destroy();
+    return rc;
+}
+
+// ---- RegisterFrame ----------------------------------------------------------------------------
+int sageicp_register_frame(const sageicp_map *m, const double *frame, uint64_t n,
+                           const double init[7], double max_dist, double kernel, double sem_th,
+                           double pose_out[7], sageicp_stats *stats) {
+    if (!m || !init || !pose_out || (n && !frame)) return fail(SAGEICP_ERR_INVALID, "null argument");
+    const double t0 = now_us();
+    if (m->host.empty()) {   // Registration.cpp:119
+        std::memcpy(pose_out, init, 56);
+        if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->n_queries = n; }
+        return SAGEICP_OK;
+    }
+    int rc = sync_mirror(m);
+    if (rc) return rc;
+    Scratch &sc = m->sc;
+    if ((rc = sc.reserve_frame(n))) return rc;
+    if (n) HIPCHK(hipMemcpyAsync(sc.d_frame, frame, n * sizeof(Point4), hipMemcpyHostToDevice,
+                                 sc.stream));
+    const double us_upload = now_us() - t0;
+    return run_icp(m, sc.d_frame, n, init, max_dist, kernel, sem_th, nullptr, pose_out, stats,
+                   us_upload, t0);
+}
+
+sageicp_frame *sageicp_frame_upload(const sageicp_map *m, const double *frame, uint64_t n) {
+    if (!m || (n && !frame)) { fail(SAGEICP_ERR_INVALID, "null argument"); return nullptr; }
+    if (m->sc.init(m->device)) return nullptr;
+    if (hipSetDevice(m->device) != hipSuccess) { fail(SAGEICP_ERR_HIP, "hipSetDevice"); return nullptr; }
+    sageicp_frame *f = new sageicp_frame;
+    f->device = m->device;
+    f->n = n;
+    if (hipMalloc(&f->d, std::max<uint64_t>(n, 1) * sizeof(Point4)) != hipSuccess) {
+        fail(SAGEICP_ERR_HIP, "hipMalloc(frame)");
+        delete f;
+        return nullptr;
+    }
+    if (n && hipMemcpy(f->d, frame, n * sizeof(Point4), hipMemcpyHostToDevice) != hipSuccess) {
+        fail(SAGEICP_ERR_HIP, "hipMemcpy(frame)");
+        (void)hipFree(f->d);
+        delete f;
+        return nullptr;
+    }
+    return f;
+}
+
+void sageicp_frame_destroy(sageicp_frame *f) {
+    if (!f) return;
+    (void)hipSetDevice(f->device);
+    if (f->d) (void)hipFree(f->d);
+    delete f;
+}
+
+int sageicp_register_frame_resident(const sageicp_map *m, const sageicp_frame *f,
+                                    const double init[7], double max_dist, double kernel,
+                                    double sem_th, sageicp_comm *comm, double pose_out[7],
+                                    sageicp_stats *stats) {
+    if (!m || !f || !init || !pose_out) return fail(SAGEICP_ERR_INVALID, "null argument");
+    if (f->device != m->device) return fail(SAGEICP_ERR_INVALID, "frame and map live on different devices");
+    if (comm && comm->device != m->device) return fail(SAGEICP_ERR_INVALID, "comm and map live on different devices");
+    const double t0 = now_us();
+    if (m->host.empty()) {
+        std::memcpy(pose_out, init, 56);
+        if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->n_queries = f->n; }
+        return SAGEICP_OK;
+    }
+    int rc = sync_mirror(m);
+    if (rc) return rc;
+    const double us_upload = now_us() - t0;
+    return run_icp(m, f->d, f->n, init, max_dist, kernel, sem_th, comm, pose_out, stats, us_upload,
+                   t0);
+}
+
+// ---- RCCL communicator ------------------------------------------------------------------------
+int sageicp_comm_unique_id(uint8_t id_out[SAGEICP_UNIQUE_ID_BYTES]) {
+    if (!id_out) return fail(SAGEICP_ERR_INVALID, "null argument");
+    int rc = load_rccl();
+    if (rc) return rc;
+    static_assert(sizeof(ncclUniqueId) == SAGEICP_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(SAGEICP_ERR_RCCL, "ncclGetUniqueId failed");
+    std::memcpy(id_out, &id, sizeof(id));
+    return SAGEICP_OK;
+}
+
+sageicp_comm *sageicp_comm_create(const uint8_t id_in[SAGEICP_UNIQUE_ID_BYTES], int rank,
+                                  int nranks, int device) {
+    if (!id_in || nranks < 1 || rank < 0 || rank >= nranks) {
+        fail(SAGEICP_ERR_INVALID, "sageicp_comm_create: bad rank/nranks");
+        return nullptr;
+    }
+    if (load_rccl()) return nullptr;
+    if (hipSetDevice(device) != hipSuccess) { fail(SAGEICP_ERR_HIP, "hipSetDevice"); return nullptr; }
+    ncclUniqueId id;
+    std::memcpy(&id, id_in, sizeof(id));
+    sageicp_comm *c = new sageicp_comm;
+    c->rank = rank; c->nranks = nranks; c->device = device;
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
+    if (r != ncclSuccess) {
+        fail(SAGEICP_ERR_RCCL, std::string("ncclCommInitRank: ") +
+                                   (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+void sageicp_comm_destroy(sageicp_comm *c) {
+    if (!c) return;
+    if (c->comm && g_rccl.CommDestroy) {
+        (void)hipSetDevice(c->device);
+        g_rccl.CommDestroy(c->comm);
+    }
+    delete c;
+}
+
+}  // extern "C"

@@ -1,0 +1,252 @@
+// Host-authoritative semantic voxel map: the per-frame map maintenance of
+// sage_icp::VoxelHashMap (reference cpp/sage_icp/core/VoxelHashMap.{hpp,cpp}) re-designed as
+// flat arrays whose memory IS the device layout (open-addressed slot table + fixed-capacity
+// fp64 point blocks), so the device mirror is refreshed by plain dirty-range copies.
+//
+//   AddPoints                    VoxelHashMap.cpp:162-174  (sequential, order dependent)
+//   VoxelBlock::AddPoint policy  VoxelHashMap.hpp:45-70
+//   RemovePointsFarFromLocation  VoxelHashMap.cpp:176-184
+//   Pointcloud                   VoxelHashMap.cpp:132-142
+//   Clear / Empty                VoxelHashMap.hpp:93-94
+//
+// Iteration order (Pointcloud(), far-voxel sweep) is block-pool order, not tsl::robin_map
+// bucket order; the far-voxel sweep removes EVERY voxel whose first point is out of range
+// (the reference erases while iterating its robin_map, which may skip some until a later
+// frame).  The search itself (kernels.hip) never depends on either.
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "sageicp_types.h"
+
+namespace sageicp {
+
+class HostMap {
+public:
+    double voxel_size = 1.0;
+    double max_distance = 100.0;
+    int basic = 20;
+    int critical = 20;
+    std::vector<int> basic_labels;
+    int cap = 40;  // basic + critical
+
+    std::vector<Slot> table;          // power-of-two capacity
+    uint32_t mask = 0;
+    uint32_t num_voxels = 0;
+    std::vector<Point4> pts;          // block b owns pts[b*cap .. b*cap+cap)
+    std::vector<uint8_t> cnt;         // points in block b (0 = block is free)
+    std::vector<int32_t> keys;        // 3 ints per block: its voxel key
+    std::vector<uint32_t> free_blocks;
+    uint32_t blocks_hi = 0;           // high-water mark of allocated block indices
+    uint64_t total_points = 0;
+
+    // dirty tracking for the device mirror
+    bool table_dirty = true;
+    std::vector<uint8_t> block_dirty;
+    std::vector<uint32_t> dirty_list;
+    uint64_t generation = 0;          // bumps on every mutation
+
+    HostMap() { reset_table(1024); }
+
+    void configure(double vs, double md, int b, int c, const int *labels, int nl) {
+        voxel_size = vs;
+        max_distance = md;
+        basic = b;
+        critical = c;
+        cap = b + c;
+        basic_labels.assign(labels, labels + nl);
+    }
+
+    bool empty() const { return num_voxels == 0; }
+
+    void clear() {
+        reset_table(1024);
+        pts.clear();
+        cnt.clear();
+        keys.clear();
+        free_blocks.clear();
+        block_dirty.clear();
+        dirty_list.clear();
+        blocks_hi = 0;
+        total_points = 0;
+        table_dirty = true;
+        ++generation;
+    }
+
+    void add_points(const double *xyzl, uint64_t n) {
+        for (uint64_t i = 0; i < n; ++i) add_point(xyzl + 4 * i);
+        if (n) ++generation;
+    }
+
+    void remove_far(const double origin[3]) {
+        const double max2 = max_distance * max_distance;
+        bool any = false;
+        for (uint32_t b = 0; b < blocks_hi; ++b) {
+            if (cnt[b] == 0) continue;
+            const Point4 &p = pts[static_cast<size_t>(b) * cap];
+            const double dx = p.x - origin[0], dy = p.y - origin[1], dz = p.z - origin[2];
+            if (dx * dx + (dy * dy + dz * dz) > max2) {
+                erase_block(b);
+                any = true;
+            }
+        }
+        if (any) ++generation;
+    }
+
+    uint64_t pointcloud(double *out, uint64_t capacity) const {
+        uint64_t k = 0;
+        for (uint32_t b = 0; b < blocks_hi; ++b) {
+            const Point4 *p = &pts[static_cast<size_t>(b) * cap];
+            for (int j = 0; j < cnt[b]; ++j, ++k)
+                if (k < capacity) std::memcpy(out + 4 * k, &p[j], 32);
+        }
+        return k;
+    }
+
+    void clear_dirty() {
+        for (uint32_t b : dirty_list) block_dirty[b] = 0;
+        dirty_list.clear();
+        table_dirty = false;
+    }
+
+private:
+    void reset_table(uint32_t capacity) {
+        table.assign(capacity, Slot{0, 0, 0, kEmptySlot});
+        mask = capacity - 1;
+        num_voxels = 0;
+    }
+
+    // returns slot index holding the key, or the empty slot where it would be inserted
+    uint32_t probe(int32_t x, int32_t y, int32_t z) const {
+        uint32_t s = voxel_hash(x, y, z) & mask;
+        for (;;) {
+            const Slot &e = table[s];
+            if (e.blk == kEmptySlot) return s;
+            if (e.x == x && e.y == y && e.z == z) return s;
+            s = (s + 1) & mask;
+        }
+    }
+
+    void grow_table() {
+        std::vector<Slot> old;
+        old.swap(table);
+        const uint32_t capacity = static_cast<uint32_t>(old.size()) * 2;
+        table.assign(capacity, Slot{0, 0, 0, kEmptySlot});
+        mask = capacity - 1;
+        for (const Slot &e : old) {
+            if (e.blk == kEmptySlot) continue;
+            table[probe(e.x, e.y, e.z)] = e;
+        }
+        table_dirty = true;
+    }
+
+    void mark_dirty(uint32_t b) {
+        if (!block_dirty[b]) {
+            block_dirty[b] = 1;
+            dirty_list.push_back(b);
+        }
+    }
+
+    uint32_t alloc_block() {
+        uint32_t b;
+        if (!free_blocks.empty()) {
+            b = free_blocks.back();
+            free_blocks.pop_back();
+        } else {
+            b = blocks_hi++;
+            if (blocks_hi > cnt.size()) {
+                const size_t nb = std::max<size_t>(1024, cnt.size() * 2);
+                cnt.resize(nb, 0);
+                block_dirty.resize(nb, 0);
+                keys.resize(nb * 3, 0);
+                pts.resize(nb * cap, Point4{0, 0, 0, 0});
+            }
+        }
+        return b;
+    }
+
+    void add_point(const double *p) {
+        // (v3point / voxel_size_).cast<int>(): fp64 divide, truncation toward zero
+        const int32_t vx = static_cast<int32_t>(p[0] / voxel_size);
+        const int32_t vy = static_cast<int32_t>(p[1] / voxel_size);
+        const int32_t vz = static_cast<int32_t>(p[2] / voxel_size);
+        uint32_t s = probe(vx, vy, vz);
+        const Point4 np{p[0], p[1], p[2], p[3]};
+        if (table[s].blk == kEmptySlot) {
+            // new voxel: its first point is taken unconditionally (VoxelHashMap.cpp:171)
+            if ((static_cast<uint64_t>(num_voxels) + 1) * 4 > table.size()) {
+                grow_table();
+                s = probe(vx, vy, vz);
+            }
+            const uint32_t b = alloc_block();
+            pts[static_cast<size_t>(b) * cap] = np;
+            cnt[b] = 1;
+            keys[3 * b] = vx; keys[3 * b + 1] = vy; keys[3 * b + 2] = vz;
+            table[s] = Slot{vx, vy, vz, (b << 8) | 1u};
+            ++num_voxels;
+            ++total_points;
+            table_dirty = true;
+            mark_dirty(b);
+            return;
+        }
+        const uint32_t b = table[s].blk >> 8;
+        Point4 *blk = &pts[static_cast<size_t>(b) * cap];
+        int c = cnt[b];
+        auto append = [&]() {
+            blk[c] = np;
+            cnt[b] = static_cast<uint8_t>(c + 1);
+            table[s].blk = (b << 8) | static_cast<uint32_t>(c + 1);
+            ++total_points;
+            table_dirty = true;
+            mark_dirty(b);
+        };
+        auto replace_first_unlabelled = [&]() {
+            for (int j = 0; j < c; ++j)
+                if (static_cast<int>(blk[j].l) == 0) {
+                    blk[j] = np;
+                    mark_dirty(b);
+                    break;
+                }
+        };
+        if (c < basic) {
+            append();
+            return;
+        }
+        const int label = static_cast<int>(p[3]);
+        if (label == 0) return;
+        if (std::find(basic_labels.begin(), basic_labels.end(), label) != basic_labels.end()) {
+            replace_first_unlabelled();
+        } else if (c < basic + critical) {
+            append();
+        } else {
+            replace_first_unlabelled();
+        }
+    }
+
+    void erase_block(uint32_t b) {
+        uint32_t i = probe(keys[3 * b], keys[3 * b + 1], keys[3 * b + 2]);
+        // backward-shift deletion keeps linear-probe chains free of tombstones
+        uint32_t j = i;
+        for (;;) {
+            j = (j + 1) & mask;
+            const Slot &e = table[j];
+            if (e.blk == kEmptySlot) break;
+            const uint32_t k = voxel_hash(e.x, e.y, e.z) & mask;
+            const bool stays = (i <= j) ? (i < k && k <= j) : (i < k || k <= j);
+            if (stays) continue;
+            table[i] = e;
+            i = j;
+        }
+        table[i] = Slot{0, 0, 0, kEmptySlot};
+        total_points -= cnt[b];
+        cnt[b] = 0;
+        free_blocks.push_back(b);
+        --num_voxels;
+        table_dirty = true;
+    }
+};
+
+}  // namespace sageicp

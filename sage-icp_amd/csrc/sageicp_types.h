@@ -1,0 +1,77 @@
+// Internal layout shared by the host map, the device mirror and the HIP kernels.
+// gfx950 only.  Not part of the C ABI (see include/sageicp.h for that).
+#pragma once
+
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SAGE_HD __host__ __device__
+#else
+#define SAGE_HD
+#endif
+
+namespace sageicp {
+
+// One open-addressed hash slot, 16 B.  `blk` packs (block_index << 8) | point_count so a probe
+// returns the candidate count without a second load; kEmptySlot marks a free slot.  Linear
+// probing, power-of-two capacity, load factor <= 0.25 (misses dominate the 27-voxel probe).
+struct alignas(16) Slot {
+    int32_t x, y, z;
+    uint32_t blk;
+};
+constexpr uint32_t kEmptySlot = 0xFFFFFFFFu;
+constexpr int kMaxBlockBits = 23;   // block_index < 2^23
+constexpr int kMaxCap = 255;        // basic + critical points per voxel
+
+// Any hash works (the reference's 20-bit hash, VoxelHashMap.hpp:72-77, only shapes bucket
+// order, never results).  This one mixes all 96 key bits so linear-probe runs stay short.
+SAGE_HD inline uint32_t voxel_hash(int32_t x, int32_t y, int32_t z) {
+    uint32_t h = static_cast<uint32_t>(x) * 0x9E3779B1u;
+    h ^= static_cast<uint32_t>(y) * 0x85EBCA77u + (h << 6) + (h >> 2);
+    h ^= static_cast<uint32_t>(z) * 0xC2B2AE3Du + (h << 6) + (h >> 2);
+    h ^= h >> 16;
+    h *= 0x7FEB352Du;
+    h ^= h >> 15;
+    h *= 0x846CA68Bu;
+    h ^= h >> 16;
+    return h;
+}
+
+// A map point: exactly Eigen::Vector4d's memory (x, y, z, label), 32 B, fp64 so that the
+// device search reproduces the reference's fp64 comparisons index-for-index.
+struct alignas(32) Point4 {
+    double x, y, z, l;
+};
+
+constexpr int kMaxIterations = 500;        // Registration.cpp:96
+constexpr double kEstimationThreshold = 1e-4;  // Registration.cpp:97
+constexpr int kNumSums = 20;               // 16 closed-form GN sums + count + 3 pad
+constexpr int kHistory = 512;
+
+// Device-resident loop state, written by k_fin, read by every kernel of the next iteration.
+struct IcpState {
+    double T[7];        // cumulative pose applied to the pristine frame: T_icp * initial_guess
+    double R[9];        // rotation matrix of T (row-major), refreshed with T
+    double T_icp[7];    // product of the per-iteration estimates (Registration.cpp:135)
+    double last_step_norm;
+    int32_t iter;       // iterations completed
+    int32_t done;       // 1: converged or hit kMaxIterations -> later launches are no-ops
+    int32_t converged;
+    int32_t pad;
+    double sums[kNumSums];          // last reduced GN sums (diagnostics / multi-GPU exchange)
+    uint32_t n_corr[kHistory];      // accepted correspondences per iteration (all ranks)
+};
+
+// Index into the 16 closed-form sums of AlignClouds (Registration.cpp:59-94):
+//   JTJ = [[Sw I, -hat(Sws)], [hat(Sws), Sw(|s|^2 I - s s^T)]],  JTr = [Swr ; Sw(s x r)]
+enum Sum : int {
+    kW = 0,
+    kWsx, kWsy, kWsz,
+    kWxx, kWxy, kWxz, kWyy, kWyz, kWzz,
+    kWrx, kWry, kWrz,
+    kWcx, kWcy, kWcz,   // w * (s x r)
+    kCount,
+};
+
+}  // namespace sageicp
