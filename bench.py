@@ -1,0 +1,236 @@
+#!/usr/bin/env python
+"""bench.py — ICP frames/sec of the MI355X registration hot path (BASELINE.json metric).
+
+A "step" is one sage_icp::RegisterFrame() call run to convergence (the span the reference times,
+pipeline/sageICP.cpp:79-88) on one synthetic labelled scan, with the scan and the replicated map
+already resident in HBM when the timed region starts.
+
+  N = 1   workload c2: 120,000-pt scan vs 1,000,000-pt semantic voxel map, identity initial guess,
+          reference start-up parameters (sigma = 2.0 -> max_corr 6.0, kernel 2/3, sem_th 0.4).
+  N > 1   the SAME frame, query-sharded in contiguous blocks over the N ranks (one process per
+          GPU), map replicated, the 17 Gauss-Newton sums all-reduced over RCCL/xGMI each
+          iteration -> strong scaling.  (--workload c4 runs the 500k-vs-10M multi-GPU config.)
+
+Prints ONE JSON line on rank 0 (see the task contract), including
+  roofline      NN kernel: algorithmic bytes (456 B/query + 16 B/candidate, SURVEY.md §8d, with
+                the candidate count taken exactly from the kernel) / HIP-event launch duration
+  cpu_baseline  the CPU oracle (a structure-faithful port of the reference path, OpenMP over all
+                host cores) timed on a bounded sample of the same frame, rank 0 at N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c4"])
+    ap.add_argument("--params", default="cold", choices=["cold", "steady"])
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0,
+                    help="CPU time budget of the cpu_baseline sample")
+    ap.add_argument("--no-profile-events", action="store_true",
+                    help="do not record per-kernel HIP events in the timed region")
+    return ap.parse_args()
+
+
+def shard_bounds(n, rank, world):
+    """contiguous blocks of ceil(n / world) queries (keeps query order across ranks)"""
+    per = -(-n // world)
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
+                             "--nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+
+    import numpy as np
+    import torch   # device sync + torch.distributed rendezvous only; the hot path is the C ABI
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", world_size=world, rank=rank,
+                                device_id=torch.device("cuda", local_rank))
+
+    import sage_icp_amd as sage
+    from sage_icp_amd import synthetic as syn
+
+    if sage.device_count() <= local_rank:
+        raise SystemExit("HIP device %d not visible to libsageicp_hip.so" % local_rank)
+
+    wl = syn.WORKLOADS[args.workload]
+    prm = syn.PARAMS[args.params]
+    t_gen = time.time()
+    w = syn.make_workload(args.workload,
+                          lambda: sage.VoxelHashMap(wl["voxel"], 100.0, device=local_rank),
+                          scale=args.scale)
+    vmap, scan = w["map"], w["scan"]
+    vmap.sync()                                    # map mirror resident before the timed region
+    lo, hi = shard_bounds(len(scan), rank, world)
+    frame = sage.Frame(vmap, scan[lo:hi])          # this rank's block of the scan, resident in HBM
+    t_gen = time.time() - t_gen
+
+    comm = None
+    if world > 1:
+        ids = [sage.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        comm = sage.Comm(ids[0], rank, world, local_rank)
+
+    def step():
+        return sage.register_frame(frame, vmap, sage.IDENTITY, prm["max_dist"], prm["kernel"],
+                                   prm["sem_th"], comm=comm, return_stats=True)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sage.set_profiling(not args.no_profile_events)
+    fence()
+    t0 = time.perf_counter()
+    stats = []
+    pose = None
+    for _ in range(args.steps):
+        pose, st = step()
+        stats.append((st.iterations, st.us_nn, st.nn_launches, st.sum_candidates, st.us_gn,
+                      st.us_fin, st.n_corr_first, st.n_corr_last, st.converged))
+    fence()
+    elapsed = time.perf_counter() - t0
+    sage.set_profiling(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    iters = stats[-1][0]
+    n_local = hi - lo
+    us_nn = sum(s[1] for s in stats)
+    launches = sum(s[2] for s in stats)
+    cands = sum(s[3] for s in stats)
+    roofline = None
+    if launches:
+        bytes_nn = 456.0 * n_local * launches + 16.0 * cands     # B_nn summed over the launches
+        avg_us = us_nn / launches
+        achieved = bytes_nn / (us_nn * 1e-6) / 1e9                # GB/s
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "nn_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "k_nn", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": traffic,
+                    "algorithmic_bytes_per_launch": round(bytes_nn / launches),
+                    "avg_launch_us": round(avg_us, 2), "launches": launches,
+                    "queries_per_launch": n_local,
+                    "candidates_per_query": round(cands / launches / max(n_local, 1), 1),
+                    "k_gn_avg_us": round(sum(s[4] for s in stats) / launches, 2),
+                    "k_fin_avg_us": round(sum(s[5] for s in stats) / launches, 2)}
+
+    fps = args.steps / elapsed
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        import oracle                              # the checker / CPU port, timed as a baseline
+        om = oracle.Map(wl["voxel"], 100.0)
+        om.add_points(w["stream"])
+        threads = oracle.num_threads()
+        t = time.perf_counter()
+        om.register_frame(scan, oracle.IDENTITY, prm["max_dist"], prm["kernel"], prm["sem_th"],
+                          max_iter=2)
+        per_iter = (time.perf_counter() - t) / 2
+        cap = int(max(3, min(iters, args.cpu_seconds / max(per_iter, 1e-9))))
+        t = time.perf_counter()
+        _, ost = om.register_frame(scan, oracle.IDENTITY, prm["max_dist"], prm["kernel"],
+                                   prm["sem_th"], max_iter=cap)
+        dt = time.perf_counter() - t
+        per_iter = dt / ost.iterations
+        cpu_fps = 1.0 / (per_iter * iters)
+        cpu = {"value": round(cpu_fps, 5), "unit": "frames/s", "cores": threads, "kind": "port",
+               "sample": "first %d of %d ICP iterations of the same %s frame (%d queries), "
+                         "%.1f s of CPU work on %d OpenMP threads; per-iteration cost is constant, "
+                         "scaled to the %d iterations the frame takes"
+                         % (ost.iterations, iters, args.workload, len(scan), dt, threads, iters),
+               "seconds_per_iteration": round(per_iter, 5),
+               "speedup_gpu_over_cpu": round(fps / cpu_fps, 1)}
+
+    err = None
+    try:
+        Tg = w["T_gt"]
+        R1, R2 = syn.quat_to_mat(pose[:4]), syn.quat_to_mat(Tg[:4])
+        ang = float(np.arccos(np.clip((np.trace(R1.T @ R2) - 1) / 2, -1, 1)))
+        err = {"translation_m": round(float(np.linalg.norm(pose[4:] - Tg[4:])), 5),
+               "rotation_rad": round(ang, 6)}
+    except Exception:
+        pass
+
+    out = {
+        "metric": "ICP frames/sec (120k-pt scan vs 1M-pt map)" if args.workload == "c2"
+                  else "ICP frames/sec (%s)" % args.workload,
+        "value": round(fps, 3),
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "%s-%s: %d-pt labelled scan vs %d-pt semantic voxel map (voxel %.1f m, "
+                               "20+20 pts/voxel), max_corr %.2f kernel %.4f sem_th %.2f, identity "
+                               "guess, full ICP loop to convergence"
+                               % (args.workload, args.params, len(scan), vmap.size(), wl["voxel"],
+                                  prm["max_dist"], prm["kernel"], prm["sem_th"]),
+                   "parallelism": "query-sharded x%d, map replicated, RCCL all-reduce of 17 fp64 sums"
+                                  % world if world > 1 else "single GPU",
+                   "scan_points": len(scan), "map_points": vmap.size(),
+                   "map_voxels": vmap.num_voxels(), "iterations_per_frame": iters,
+                   "correspondences_first_last": [stats[-1][6], stats[-1][7]],
+                   "converged": bool(stats[-1][8]),
+                   "pose_error_vs_planted": err, "setup_seconds": round(t_gen, 1)},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

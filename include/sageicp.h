@@ -56,6 +56,8 @@ typedef struct sageicp_stats {
     double us_fin;
     uint32_t nn_launches;
     uint32_t reserved;
+    uint64_t sum_candidates;    /* sum over iterations and queries of C_q: map points stored in the
+                                 * <=27 existing neighbour voxels of each query (this rank) */
     uint32_t n_corr_hist[64];   /* accepted correspondences of the first 64 iterations */
 } sageicp_stats;
 

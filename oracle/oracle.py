@@ -73,6 +73,9 @@ def lib():
         L.sgo_transform_points.argtypes = [_dp, _dp, C.c_uint64]
         L.sgo_register_frame.argtypes = [C.c_void_p, _dp, C.c_uint64, _dp, C.c_double, C.c_double,
                                          C.c_double, _dp, C.POINTER(Stats), C.c_int]
+        L.sgo_register_frame_capped.argtypes = [C.c_void_p, _dp, C.c_uint64, _dp, C.c_double,
+                                                C.c_double, C.c_double, _dp, C.POINTER(Stats),
+                                                C.c_int, C.c_int]
         for name, n_in in (("sgo_se3_exp", 1), ("sgo_se3_log", 1), ("sgo_se3_inv", 1),
                            ("sgo_se3_mul", 2), ("sgo_se3_apply", 2), ("sgo_ldlt_solve6", 2)):
             getattr(L, name).argtypes = [_dp] * (n_in + 1)
@@ -215,13 +218,14 @@ class Map:
             return src[:k].copy(), tgt[:k].copy(), idx[:k].copy()
         return src[:k].copy(), tgt[:k].copy()
 
-    def register_frame(self, frame, init, max_dist, kernel, sem_th, nthreads=0):
+    def register_frame(self, frame, init, max_dist, kernel, sem_th, nthreads=0, max_iter=500):
         frame, fp = _d(frame)
         init, ip = _d(init)
         out = np.empty(7)
         st = Stats()
-        lib().sgo_register_frame(self._h, fp, frame.reshape(-1, 4).shape[0], ip, max_dist, kernel,
-                                 sem_th, out.ctypes.data_as(_dp), C.byref(st), nthreads)
+        lib().sgo_register_frame_capped(self._h, fp, frame.reshape(-1, 4).shape[0], ip, max_dist,
+                                        kernel, sem_th, out.ctypes.data_as(_dp), C.byref(st),
+                                        nthreads, max_iter)
         return out, st
 
 

@@ -607,10 +607,11 @@ static double now_s() {
 #endif
 }
 
-// Registration.cpp:113-141
-int sgo_register_frame(const void *h, const double *frame, uint64_t n, const double init[7],
-                       double max_dist, double kernel, double sem_th, double T_out[7],
-                       sgo_stats *st, int nthreads) {
+// Registration.cpp:113-141.  max_iter < 500 bounds the loop for the timed CPU-baseline sample
+// (bench.py); the parity oracle always runs with the reference's 500.
+int sgo_register_frame_capped(const void *h, const double *frame, uint64_t n, const double init[7],
+                              double max_dist, double kernel, double sem_th, double T_out[7],
+                              sgo_stats *st, int nthreads, int max_iter) {
     const Map &m = *static_cast<const Map *>(h);
     sgo_stats local;
     std::memset(&local, 0, sizeof(local));
@@ -623,7 +624,7 @@ int sgo_register_frame(const void *h, const double *frame, uint64_t n, const dou
     sgo_transform_points(init, source.data(), n);
     double T_icp[7] = {0, 0, 0, 1, 0, 0, 0};
     std::vector<double> src(4 * n), tgt(4 * n);
-    constexpr int kMaxIter = 500;        // Registration.cpp:96
+    const int kMaxIter = (max_iter > 0 && max_iter < 500) ? max_iter : 500;  // Registration.cpp:96
     constexpr double kEstThresh = 1e-4;  // Registration.cpp:97
     for (int j = 0; j < kMaxIter; ++j) {
         uint64_t nc = 0, cand = 0;
@@ -658,6 +659,13 @@ int sgo_register_frame(const void *h, const double *frame, uint64_t n, const dou
     se3_mul(T_icp, init, T_out);
     if (st) *st = local;
     return 0;
+}
+
+int sgo_register_frame(const void *h, const double *frame, uint64_t n, const double init[7],
+                       double max_dist, double kernel, double sem_th, double T_out[7],
+                       sgo_stats *st, int nthreads) {
+    return sgo_register_frame_capped(h, frame, n, init, max_dist, kernel, sem_th, T_out, st,
+                                     nthreads, 500);
 }
 
 int sgo_num_threads(void) { return resolve_threads(0); }

@@ -279,7 +279,8 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     HIPCHK(hipMemcpyAsync(sc.d_state, sc.h_state, sizeof(IcpState), hipMemcpyHostToDevice, s));
 
     NnParams np{d_frame, static_cast<int>(n), sc.d_state, m->d_table, m->host.mask, m->d_pts,
-                m->host.cap, m->host.voxel_size, sem_th, max_dist, sc.d_nn};
+                m->host.cap, m->host.voxel_size, sem_th, max_dist, sc.d_nn,
+                &sc.d_state->sum_candidates};
     GnParams gp{d_frame, nullptr, static_cast<int>(n), sc.d_state, m->d_pts, sc.d_nn, kernel,
                 sc.d_partials, 1};
     const int gn_blocks = gn_grid_for(static_cast<int>(n));
@@ -326,7 +327,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         }
         launched += todo;
         if (sc.h_state->done || launched >= kMaxIterations) break;
-        chunk = std::min(kChunkMax, chunk);
+        chunk = std::min(kChunkMax, chunk * 2);   // 4, 8, 16, 16, ... : few syncs, bounded no-op tail
     }
     const IcpState &st = *sc.h_state;
     for (int i = 0; i < 7; ++i) out[i] = st.T[i];
@@ -341,6 +342,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         stats->us_upload = us_upload;
         stats->us_nn = us_nn; stats->us_gn = us_gn; stats->us_fin = us_fin;
         stats->nn_launches = nn_launches;
+        stats->sum_candidates = st.sum_candidates;
         for (int i = 0; i < 64 && i < st.iter; ++i) stats->n_corr_hist[i] = st.n_corr[i];
         stats->us_wall = now_us() - t_begin;
     }
@@ -468,7 +470,7 @@ int sageicp_get_correspondences(const sageicp_map *m, const double *q, uint64_t 
     hipStream_t s = sc.stream;
     HIPCHK(hipMemcpyAsync(sc.d_frame, q, n * sizeof(Point4), hipMemcpyHostToDevice, s));
     NnParams np{sc.d_frame, static_cast<int>(n), sc.d_state, m->d_table, m->host.mask, m->d_pts,
-                m->host.cap, m->host.voxel_size, sem_th, max_dist, sc.d_nn};
+                m->host.cap, m->host.voxel_size, sem_th, max_dist, sc.d_nn, nullptr};
     launch_nn(np, false, s);
     HIPCHK(hipGetLastError());
     std::vector<int32_t> idx(n);

@@ -19,6 +19,7 @@ struct NnParams {
     double sem_th;
     double max_dist;
     int32_t *nn_idx;          // out: block*cap+slot of the accepted neighbour, -1 if none
+    unsigned long long *cand_counter;  // optional: += sum_q C_q (candidates visible to q)
 };
 
 struct GnParams {

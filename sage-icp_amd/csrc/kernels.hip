@@ -61,6 +61,8 @@ __global__ __launch_bounds__(256) void k_nn(NnParams P) {
     // neighbour offset of this lane: x outer, y, z inner (VoxelHashMap.cpp:57-63)
     const int ox = lane / 9 - 1, oy = (lane / 3) % 3 - 1, oz = lane % 3 - 1;
 
+    unsigned wave_candidates = 0;   // wave-uniform: sum of C_q over this wave's queries
+
     for (int q = q0; q < q1; ++q) {
         const Point4 fq = P.frame[q];
         double px, py, pz;
@@ -107,6 +109,7 @@ __global__ __launch_bounds__(256) void k_nn(NnParams P) {
             const uint32_t vb = rl_u32(blk, v);
             const uint32_t count = vb & 255u;
             const uint32_t base = (vb >> 8) * static_cast<uint32_t>(P.cap);
+            wave_candidates += count;
             for (uint32_t s0 = 0; s0 < count; s0 += 64) {
                 const uint32_t slot = s0 + lane;
                 if (slot < count) {
@@ -143,6 +146,8 @@ __global__ __launch_bounds__(256) void k_nn(NnParams P) {
             P.nn_idx[q] = (sqrt(best_raw) < P.max_dist) ? best_idx : -1;
         }
     }
+    if (P.cand_counter && lane == 0 && wave_candidates)
+        atomicAdd(P.cand_counter, static_cast<unsigned long long>(wave_candidates));
 }
 
 // ------------------------------------------------------------------------------------ k_gn
