@@ -51,7 +51,8 @@ typedef struct sageicp_stats {
     double us_upload;           /* frame H2D + lazy map-mirror refresh inside the call */
     /* device time per kernel summed over the executed iterations (HIP events on the launch
      * stream); filled only when profiling is enabled with sageicp_set_profiling(). */
-    double us_nn;
+    double us_group;            /* k_group: pose apply + home voxel + grouping */
+    double us_nn;               /* k_nn: the correspondence search */
     double us_gn;
     double us_fin;
     uint32_t nn_launches;

@@ -49,6 +49,7 @@ class Stats(C.Structure):
         ("last_step_norm", C.c_double),
         ("us_wall", C.c_double),
         ("us_upload", C.c_double),
+        ("us_group", C.c_double),
         ("us_nn", C.c_double),
         ("us_gn", C.c_double),
         ("us_fin", C.c_double),

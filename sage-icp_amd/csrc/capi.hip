@@ -60,10 +60,15 @@ struct Scratch {
     Point4 *d_frame = nullptr; size_t frame_cap = 0;
     Point4 *d_tgt = nullptr; size_t tgt_cap = 0;
     int32_t *d_nn = nullptr; size_t nn_cap = 0;
+    // Morton re-ordering of the frame (sort.hip)
+    Point4 *d_sorted = nullptr; uint32_t *d_keys = nullptr; uint32_t *d_vals = nullptr;
+    void *d_sort_temp = nullptr; size_t sort_cap = 0; size_t sort_temp_bytes_ = 0;
+    // per-iteration work buffers: transformed queries and the group list (k_group)
+    Point4 *d_src = nullptr; int4 *d_groups = nullptr;
     double *d_partials = nullptr;
     IcpState *d_state = nullptr;
     IcpState *h_state = nullptr;   // pinned
-    std::vector<hipEvent_t> events;  // 4 per iteration of a chunk
+    std::vector<hipEvent_t> events;  // 5 per iteration of a chunk
 
     int init(int dev) {
         if (stream) return SAGEICP_OK;
@@ -106,9 +111,30 @@ struct Scratch {
         nn_cap = cap;
         return SAGEICP_OK;
     }
+    int reserve_sort(size_t n) {
+        if (n <= sort_cap) return SAGEICP_OK;
+        if (d_sorted) HIPCHK(hipFree(d_sorted));
+        if (d_keys) HIPCHK(hipFree(d_keys));
+        if (d_vals) HIPCHK(hipFree(d_vals));
+        if (d_sort_temp) HIPCHK(hipFree(d_sort_temp));
+        if (d_src) HIPCHK(hipFree(d_src));
+        if (d_groups) HIPCHK(hipFree(d_groups));
+        d_sorted = nullptr; d_keys = d_vals = nullptr; d_sort_temp = nullptr; sort_cap = 0;
+        d_src = nullptr; d_groups = nullptr;
+        const size_t cap = n + n / 4 + 1024;
+        HIPCHK(hipMalloc(&d_sorted, cap * sizeof(Point4)));
+        HIPCHK(hipMalloc(&d_src, cap * sizeof(Point4)));
+        HIPCHK(hipMalloc(&d_groups, 8 * static_cast<size_t>(group_list_stride(cap)) * sizeof(int4)));
+        HIPCHK(hipMalloc(&d_keys, 2 * cap * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&d_vals, 2 * cap * sizeof(uint32_t)));
+        sort_temp_bytes_ = sort_temp_bytes(static_cast<int>(cap));
+        HIPCHK(hipMalloc(&d_sort_temp, sort_temp_bytes_));
+        sort_cap = cap;
+        return SAGEICP_OK;
+    }
     int reserve_events() {
         if (!events.empty()) return SAGEICP_OK;
-        events.resize(4 * kChunkMax);
+        events.resize(5 * kChunkMax);
         for (auto &e : events) HIPCHK(hipEventCreate(&e));
         return SAGEICP_OK;
     }
@@ -121,6 +147,12 @@ struct Scratch {
         if (d_frame) (void)hipFree(d_frame);
         if (d_tgt) (void)hipFree(d_tgt);
         if (d_nn) (void)hipFree(d_nn);
+        if (d_sorted) (void)hipFree(d_sorted);
+        if (d_keys) (void)hipFree(d_keys);
+        if (d_vals) (void)hipFree(d_vals);
+        if (d_sort_temp) (void)hipFree(d_sort_temp);
+        if (d_src) (void)hipFree(d_src);
+        if (d_groups) (void)hipFree(d_groups);
         if (d_partials) (void)hipFree(d_partials);
         if (d_state) (void)hipFree(d_state);
         if (h_state) (void)hipHostFree(h_state);
@@ -269,7 +301,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
             sageicp_stats *stats, double us_upload, double t_begin) {
     Scratch &sc = m->sc;
     hipStream_t s = sc.stream;
-    if (n > 0x7FFFFFFFull) return fail(SAGEICP_ERR_INVALID, "frame too large");
+    if (n > kMaxQueries) return fail(SAGEICP_ERR_INVALID, "frame too large (2^26 points max)");
     int rc = sc.reserve_nn(n);
     if (rc) return rc;
     const bool prof = g_profiling != 0;
@@ -278,25 +310,38 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     fill_state(sc.h_state, init);
     HIPCHK(hipMemcpyAsync(sc.d_state, sc.h_state, sizeof(IcpState), hipMemcpyHostToDevice, s));
 
-    NnParams np{d_frame, static_cast<int>(n), sc.d_state, m->d_table, m->host.mask, m->d_pts,
-                m->host.cap, m->host.voxel_size, sem_th, max_dist, sc.d_nn,
-                &sc.d_state->sum_candidates};
-    GnParams gp{d_frame, nullptr, static_cast<int>(n), sc.d_state, m->d_pts, sc.d_nn, kernel,
-                sc.d_partials, 1};
+    // spatial re-ordering of the frame, once per call; the loop runs on the sorted copy
+    if ((rc = sc.reserve_sort(n))) return rc;
+    if (n > 0) {
+        HIPCHK(sort_frame(d_frame, sc.d_sorted, static_cast<int>(n), sc.d_state, true,
+                          m->host.voxel_size, sc.d_keys, sc.d_vals, sc.d_sort_temp,
+                          sc.sort_temp_bytes_, s));
+        d_frame = sc.d_sorted;
+    }
+
+    GroupParams grp{d_frame, static_cast<int>(n), sc.d_state, m->host.voxel_size, sc.d_src,
+                    sc.d_groups, sc.d_state->ngroups, group_list_stride(n)};
+    NnParams np{sc.d_src, static_cast<int>(n), sc.d_state, 1, sc.d_groups, sc.d_state->ngroups,
+                group_list_stride(n), m->d_table, m->host.mask, m->d_pts, m->host.cap, nn_cand_stride(m->host.cap),
+                sem_th, max_dist, sc.d_nn, &sc.d_state->sum_candidates};
+    GnParams gp{sc.d_src, nullptr, static_cast<int>(n), sc.d_state, 1, m->d_pts, sc.d_nn, kernel,
+                sc.d_partials};
     const int gn_blocks = gn_grid_for(static_cast<int>(n));
 
-    double us_nn = 0, us_gn = 0, us_fin = 0;
+    double us_group = 0, us_nn = 0, us_gn = 0, us_fin = 0;
     uint32_t nn_launches = 0;
     int launched = 0;
     int chunk = 4;
     for (;;) {
         const int todo = std::min(chunk, kMaxIterations - launched);
         for (int k = 0; k < todo; ++k) {
-            if (prof) HIPCHK(hipEventRecord(sc.events[4 * k + 0], s));
-            launch_nn(np, true, s);
-            if (prof) HIPCHK(hipEventRecord(sc.events[4 * k + 1], s));
+            if (prof) HIPCHK(hipEventRecord(sc.events[5 * k + 0], s));
+            launch_group(grp, true, s);
+            if (prof) HIPCHK(hipEventRecord(sc.events[5 * k + 1], s));
+            launch_nn(np, s);
+            if (prof) HIPCHK(hipEventRecord(sc.events[5 * k + 2], s));
             launch_gn(gp, s);
-            if (prof) HIPCHK(hipEventRecord(sc.events[4 * k + 2], s));
+            if (prof) HIPCHK(hipEventRecord(sc.events[5 * k + 3], s));
             if (comm) {
                 launch_fin(sc.d_state, sc.d_partials, gn_blocks, 1, 0, s);
                 ncclResult_t r = g_rccl.AllReduce(sc.d_state->sums, sc.d_state->sums, kNumSums,
@@ -308,7 +353,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
             } else {
                 launch_fin(sc.d_state, sc.d_partials, gn_blocks, 0, 0, s);
             }
-            if (prof) HIPCHK(hipEventRecord(sc.events[4 * k + 3], s));
+            if (prof) HIPCHK(hipEventRecord(sc.events[5 * k + 4], s));
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(sc.h_state, sc.d_state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
@@ -317,11 +362,12 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         if (prof) {
             const int executed = std::min(todo, iters - launched);   // the rest were no-ops
             for (int k = 0; k < executed; ++k) {
-                float a = 0, b = 0, c = 0;
-                (void)hipEventElapsedTime(&a, sc.events[4 * k + 0], sc.events[4 * k + 1]);
-                (void)hipEventElapsedTime(&b, sc.events[4 * k + 1], sc.events[4 * k + 2]);
-                (void)hipEventElapsedTime(&c, sc.events[4 * k + 2], sc.events[4 * k + 3]);
-                us_nn += 1e3 * a; us_gn += 1e3 * b; us_fin += 1e3 * c;
+                float g = 0, a = 0, b = 0, c = 0;
+                (void)hipEventElapsedTime(&g, sc.events[5 * k + 0], sc.events[5 * k + 1]);
+                (void)hipEventElapsedTime(&a, sc.events[5 * k + 1], sc.events[5 * k + 2]);
+                (void)hipEventElapsedTime(&b, sc.events[5 * k + 2], sc.events[5 * k + 3]);
+                (void)hipEventElapsedTime(&c, sc.events[5 * k + 3], sc.events[5 * k + 4]);
+                us_group += 1e3 * g; us_nn += 1e3 * a; us_gn += 1e3 * b; us_fin += 1e3 * c;
                 ++nn_launches;
             }
         }
@@ -340,6 +386,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         stats->n_corr_last = st.iter > 0 ? st.n_corr[std::min(st.iter, kHistory) - 1] : 0;
         stats->last_step_norm = st.last_step_norm;
         stats->us_upload = us_upload;
+        stats->us_group = us_group;
         stats->us_nn = us_nn; stats->us_gn = us_gn; stats->us_fin = us_fin;
         stats->nn_launches = nn_launches;
         stats->sum_candidates = st.sum_candidates;
@@ -459,7 +506,7 @@ int sageicp_get_correspondences(const sageicp_map *m, const double *q, uint64_t 
                                 int64_t *query_idx_out) {
     if (!m || !n_out || (n && (!q || !src_out || !tgt_out)))
         return fail(SAGEICP_ERR_INVALID, "null argument");
-    if (n > 0x7FFFFFFFull) return fail(SAGEICP_ERR_INVALID, "too many queries");
+    if (n > kMaxQueries) return fail(SAGEICP_ERR_INVALID, "too many queries (2^26 max)");
     *n_out = 0;
     int rc = sync_mirror(m);
     if (rc) return rc;
@@ -467,20 +514,39 @@ int sageicp_get_correspondences(const sageicp_map *m, const double *q, uint64_t 
     Scratch &sc = m->sc;
     if ((rc = sc.reserve_frame(n))) return rc;
     if ((rc = sc.reserve_nn(n))) return rc;
+    if ((rc = sc.reserve_sort(n))) return rc;
     hipStream_t s = sc.stream;
     HIPCHK(hipMemcpyAsync(sc.d_frame, q, n * sizeof(Point4), hipMemcpyHostToDevice, s));
-    NnParams np{sc.d_frame, static_cast<int>(n), sc.d_state, m->d_table, m->host.mask, m->d_pts,
-                m->host.cap, m->host.voxel_size, sem_th, max_dist, sc.d_nn, nullptr};
-    launch_nn(np, false, s);
+    double I[7];
+    identity_pose(I);
+    fill_state(sc.h_state, I);
+    HIPCHK(hipMemcpyAsync(sc.d_state, sc.h_state, sizeof(IcpState), hipMemcpyHostToDevice, s));
+    // same pipeline as the ICP loop, pose = identity: sort, group, search; results are mapped
+    // back to the caller's query order through the sort permutation
+    HIPCHK(sort_frame(sc.d_frame, sc.d_sorted, static_cast<int>(n), sc.d_state, false,
+                      m->host.voxel_size, sc.d_keys, sc.d_vals, sc.d_sort_temp, sc.sort_temp_bytes_,
+                      s));
+    GroupParams grp{sc.d_sorted, static_cast<int>(n), sc.d_state, m->host.voxel_size, sc.d_src,
+                    sc.d_groups, sc.d_state->ngroups, group_list_stride(n)};
+    launch_group(grp, false, s);
+    NnParams np{sc.d_src, static_cast<int>(n), sc.d_state, 0, sc.d_groups, sc.d_state->ngroups,
+                group_list_stride(n), m->d_table, m->host.mask, m->d_pts, m->host.cap, nn_cand_stride(m->host.cap),
+                sem_th, max_dist, sc.d_nn, nullptr};
+    launch_nn(np, s);
     HIPCHK(hipGetLastError());
     std::vector<int32_t> idx(n);
+    std::vector<uint32_t> perm(n);
     HIPCHK(hipMemcpyAsync(idx.data(), sc.d_nn, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(perm.data(), sc.d_vals + n, n * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                          s));
     HIPCHK(hipStreamSynchronize(s));
+    std::vector<int32_t> by_query(n);
+    for (uint64_t i = 0; i < n; ++i) by_query[perm[i]] = idx[i];
     uint64_t k = 0;
-    for (uint64_t i = 0; i < n; ++i) {
-        if (idx[i] < 0) continue;
+    for (uint64_t i = 0; i < n; ++i) {     // pairs in query order (VoxelHashMap.cpp:119-127)
+        if (by_query[i] < 0) continue;
         std::memcpy(src_out + 4 * k, q + 4 * i, 32);
-        std::memcpy(tgt_out + 4 * k, &m->host.pts[idx[i]], 32);
+        std::memcpy(tgt_out + 4 * k, &m->host.pts[by_query[i]], 32);
         if (query_idx_out) query_idx_out[k] = static_cast<int64_t>(i);
         ++k;
     }
@@ -510,8 +576,8 @@ int sageicp_align_clouds(const double *src, const double *tgt, uint64_t n, doubl
         identity_pose(I);
         fill_state(sc.h_state, I);
         HIPCHK(hipMemcpyAsync(sc.d_state, sc.h_state, sizeof(IcpState), hipMemcpyHostToDevice, s));
-        GnParams gp{sc.d_frame, sc.d_tgt, static_cast<int>(n), sc.d_state, nullptr, nullptr, kernel,
-                    sc.d_partials, 0};
+        GnParams gp{sc.d_frame, sc.d_tgt, static_cast<int>(n), sc.d_state, 0, nullptr, nullptr,
+                    kernel, sc.d_partials};
         const int blocks = launch_gn(gp, s);
         launch_fin(sc.d_state, sc.d_partials, blocks, 0, 1, s);
         HIPCHK(hipGetLastError());

@@ -1,4 +1,4 @@
-// Launch interface between capi.hip (host side) and kernels.hip (device side).
+// Launch interface between capi.hip (host side) and kernels.hip / sort.hip (device side).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -7,15 +7,30 @@
 
 namespace sageicp {
 
+struct GroupParams {
+    const Point4 *frame;      // pristine (sorted) frame, or already-transformed queries
+    int n;
+    const IcpState *st;       // pose to apply (apply_pose) and the done flag
+    double voxel_size;
+    Point4 *src;              // out: transformed queries (x, y, z, label)
+    int4 *groups;             // out: 8 lists of {start | len << 26, kx, ky, kz} records
+    unsigned *ngroups;        // out: 8 list lengths (appended atomically; zeroed by k_fin / upload)
+    unsigned list_stride;     // records reserved per list (group_list_stride(n))
+};
+
 struct NnParams {
-    const Point4 *frame;      // pristine frame (or already-transformed queries when !apply_pose)
+    const Point4 *src;        // transformed queries
     int n;
     const IcpState *st;
+    int check_done;           // 1 inside the ICP loop: later launches of a finished loop are no-ops
+    const int4 *groups;
+    const unsigned *ngroups;
+    unsigned list_stride;
     const Slot *table;
     uint32_t mask;
     const Point4 *pts;
     int cap;
-    double voxel_size;
+    unsigned cand_stride;     // LDS words per wave (nn_cand_stride(cap))
     double sem_th;
     double max_dist;
     int32_t *nn_idx;          // out: block*cap+slot of the accepted neighbour, -1 if none
@@ -23,24 +38,34 @@ struct NnParams {
 };
 
 struct GnParams {
-    const Point4 *frame;
+    const Point4 *src;        // transformed queries (or the explicit sources of align_clouds)
     const Point4 *tgt_pairs;  // explicit targets (align_clouds entry) or nullptr
     int n;
     const IcpState *st;
+    int check_done;
     const Point4 *pts;
     const int32_t *nn_idx;
     double kernel;
     double *partials;         // [gridDim.x][kNumSums]
-    int apply_pose;
 };
 
 constexpr int kMaxGnBlocks = 512;
+constexpr uint64_t kMaxQueries = (1ull << 26) - 1;   // group record packs start into 26 bits
 
-void launch_nn(const NnParams &p, bool apply_pose, hipStream_t s);
+void launch_group(const GroupParams &p, bool apply_pose, hipStream_t s);
+void launch_nn(const NnParams &p, hipStream_t s);
 int launch_gn(const GnParams &p, hipStream_t s);   // returns the number of partials written
 void launch_fin(IcpState *st, const double *partials, int nparts, int mode, int standalone,
                 hipStream_t s);
 void launch_tf(Point4 *pts, int n, const IcpState *st, hipStream_t s);
 int gn_grid_for(int n);
+unsigned nn_cand_stride(int cap);
+inline unsigned group_list_stride(uint64_t n) { return static_cast<unsigned>((n + 7) / 8 + 64); }
+
+// sort.hip: re-ordering of a frame along the Morton curve of its map-frame voxels
+size_t sort_temp_bytes(int n);
+hipError_t sort_frame(const Point4 *d_in, Point4 *d_out, int n, const IcpState *st, bool apply_pose,
+                      double voxel_size, uint32_t *keys, uint32_t *vals, void *temp,
+                      size_t temp_bytes, hipStream_t s);
 
 }  // namespace sageicp

@@ -1,22 +1,30 @@
 // Hand-written HIP kernels for gfx950 (CDNA4, wave64) — SAGE-ICP registration hot path.
 //
-//   k_nn   semantic nearest-neighbour search over the 27-voxel neighbourhood of a GPU-resident
-//          open-addressed voxel hash.   Replaces VoxelHashMap::GetCorrespondences' per-point
-//          lambda (reference core/VoxelHashMap.cpp:51-96) and its acceptance test (:109-115),
-//          with TransformPoints (core/Registration.cpp:103-111,133) fused in: the cumulative
-//          pose is applied to the pristine frame instead of re-writing `source` every iteration.
-//   k_gn   robust-weighted point-to-point Gauss-Newton accumulation (Registration.cpp:62-90) as
-//          16 closed-form fp64 sums + count, wave-shuffle -> LDS -> one partial per workgroup.
-//   k_fin  fixed-order reduction of the workgroup partials, 6x6 LDL^T solve, SE3 exp, pose
-//          composition and the convergence test (Registration.cpp:92-93,135-137), all on device so
-//          the host never round-trips inside the ICP loop.
-//   k_tf   TransformPoints for the stand-alone API entry (Registration.cpp:103-111).
+//   k_group  per query: apply the cumulative pose to the pristine frame (TransformPoints,
+//            reference core/Registration.cpp:103-111,133, fused: `source` is never rewritten in
+//            place), compute its home voxel with the reference's exact fp64 divide + truncation
+//            (core/VoxelHashMap.cpp:52-54) and cut the spatially sorted frame into GROUPS: runs
+//            of consecutive queries that share a home voxel (<= 32 long).  All queries of a
+//            group see the same 27-voxel candidate list.
+//   k_nn     one wavefront per group: lanes 0..26 probe the 27 neighbour voxels of the GPU-
+//            resident open-addressed hash in parallel, the occupied voxels' points are
+//            enumerated once in reference order (x outer, y, z inner, then insertion order) into
+//            an LDS candidate list, and the (query x candidate) pairs are spread over the 64
+//            lanes — W = 64 / pow2(group size) lanes per query, each lane striding the list —
+//            followed by a W-lane argmin.  Replaces VoxelHashMap::GetCorrespondences' per-point
+//            lambda (core/VoxelHashMap.cpp:51-96) and its acceptance test (:109-115).
+//   k_gn     robust-weighted point-to-point Gauss-Newton accumulation (Registration.cpp:62-90) as
+//            16 closed-form fp64 sums + count, wave-shuffle -> LDS -> one partial per workgroup.
+//   k_fin    fixed-order reduction of the workgroup partials, 6x6 LDL^T solve, SE3 exp, pose
+//            composition and the convergence test (Registration.cpp:92-93,135-137), all on device
+//            so the host never round-trips inside the ICP loop.
+//   k_tf     TransformPoints for the stand-alone API entry (Registration.cpp:103-111).
 //
 // Roofline: HBM-bound integer/byte + fp64 compare work (~0.1 flop/B) — no MFMA (a 6x6 outer
-// product sum is not a dense contraction).  One wavefront owns one query: lanes 0..26 probe the
-// 27 neighbour voxels in parallel (one 16-B slot load per probe step), then the wave walks the
-// occupied voxels in reference order (x outer, y, z inner), 64 lanes loading one voxel block's
-// points as one contiguous, coalesced run of 32-B records.
+// product sum is not a dense contraction).  What matters here is coalescing (a voxel block is
+// one contiguous run of 32-B records; identical addresses across the lanes of a group collapse
+// into one request), LDS staging of the candidate enumeration, enough loads in flight per wave
+// (the pair loop is unrolled 4x) and wave-uniform control flow.
 //
 // Built with -ffp-contract=off: distances are the plain IEEE sequence
 // dx*dx + (dy*dy + dz*dz) the CPU evaluates, so the argmin is index-exact against the oracle.
@@ -35,115 +43,177 @@ __device__ __forceinline__ uint32_t rl_u32(uint32_t v, int lane) {
     return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), lane));
 }
 
-// ------------------------------------------------------------------------------------ k_nn
+// ---------------------------------------------------------------------------------- k_group
+// One lane per query.  Group heads: a query whose home voxel differs from its predecessor's,
+// or whose index is a multiple of 32 (so a group never exceeds 32 queries nor crosses a wave).
 template <bool APPLY_POSE>
-__global__ __launch_bounds__(256) void k_nn(NnParams P) {
+__global__ __launch_bounds__(256) void k_group(GroupParams P) {
     if (APPLY_POSE && P.st->done) return;
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = q < P.n;
+
+    int kx = 0, ky = 0, kz = 0;
+    if (valid) {
+        const Point4 f = P.frame[q];
+        Point4 s;
+        if (APPLY_POSE) {
+            const double *R = P.st->R;
+            const double *T = P.st->T;
+            s.x = R[0] * f.x + R[1] * f.y + R[2] * f.z + T[4];
+            s.y = R[3] * f.x + R[4] * f.y + R[5] * f.z + T[5];
+            s.z = R[6] * f.x + R[7] * f.y + R[8] * f.z + T[6];
+        } else {
+            s.x = f.x; s.y = f.y; s.z = f.z;
+        }
+        s.l = f.l;
+        P.src[q] = s;
+        // static_cast<int>(p / voxel_size): exact fp64 divide, truncation toward zero
+        kx = static_cast<int>(s.x / P.voxel_size);
+        ky = static_cast<int>(s.y / P.voxel_size);
+        kz = static_cast<int>(s.z / P.voxel_size);
+    }
+    const int pkx = __shfl_up(kx, 1, 64), pky = __shfl_up(ky, 1, 64), pkz = __shfl_up(kz, 1, 64);
+    const bool head = valid && ((lane & 31) == 0 || kx != pkx || ky != pky || kz != pkz);
+    const unsigned long long heads = __ballot(head);
+    if (heads == 0) return;
+    const unsigned long long live = __ballot(valid);
+
+    // Eight group lists, one per eighth of the sorted frame: k_nn's workgroup b (dispatched to XCD
+    // b % 8) serves list b % 8, so each XCD's private L2 only ever sees one compact region of
+    // the map.  Within a list the append order is arbitrary (it only decides which wave serves
+    // which group, never a result).
+    const unsigned wave_q0 = blockIdx.x * 256u + (threadIdx.x & ~63u);
+    const unsigned list = static_cast<unsigned>((static_cast<unsigned long long>(wave_q0) * 8ull) /
+                                                static_cast<unsigned long long>(P.n));
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(P.ngroups + list, static_cast<unsigned>(__popcll(heads)));
+    base = rl_u32(base, 0) + list * P.list_stride;
+    if (head) {
+        // length: distance to the next head, the end of this 32-query chunk or the end of the frame
+        const unsigned long long above = (lane == 63) ? 0ull : (heads >> (lane + 1)) << (lane + 1);
+        int end = above ? __builtin_ctzll(above) : 64;
+        end = min(end, (lane | 31) + 1);
+        end = min(end, 64 - __builtin_clzll(live));
+        const unsigned rank = __popcll(heads & ((1ull << lane) - 1ull));
+        int4 rec;
+        rec.x = q | ((end - lane) << 26);      // start (26 bits) | length (1..32)
+        rec.y = kx; rec.z = ky; rec.w = kz;
+        P.groups[base + rank] = rec;
+    }
+}
+
+// ------------------------------------------------------------------------------------- k_nn
+__global__ __launch_bounds__(256) void k_nn(NnParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    if (P.check_done && P.st->done) return;
 
     const int lane = threadIdx.x & 63;
-    // Workgroup b runs on XCD b % 8 (observed dispatch order; used for L2 affinity only):
-    // give each XCD one contiguous eighth of the (spatially coherent) query range.
-    const unsigned G = gridDim.x;  // multiple of 8
-    const unsigned L = (blockIdx.x & 7u) * (G >> 3) + (blockIdx.x >> 3);
-    const unsigned wave = __builtin_amdgcn_readfirstlane(L * 4u + (threadIdx.x >> 6));
-    const unsigned total_waves = G * 4u;
-    const int chunk = (P.n + static_cast<int>(total_waves) - 1) / static_cast<int>(total_waves);
-    const int q0 = static_cast<int>(wave) * chunk;
-    const int q1 = min(q0 + chunk, P.n);
+    const int wv = threadIdx.x >> 6;
+    uint32_t *cand = smem + wv * P.cand_stride;      // this wave's candidate list (absolute indices)
 
-    double R[9], t[3];
-    if (APPLY_POSE) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) R[i] = P.st->R[i];
-        t[0] = P.st->T[4]; t[1] = P.st->T[5]; t[2] = P.st->T[6];
-    }
-
+    // workgroup b is dispatched to XCD b % 8 (observed; speed only): it serves group list b % 8
+    const unsigned list = blockIdx.x & 7u;
+    const unsigned ngroups = P.ngroups[list];
+    const int4 *groups = P.groups + list * P.list_stride;
+    const unsigned waves_per_list = (gridDim.x >> 3) * 4u;
     // neighbour offset of this lane: x outer, y, z inner (VoxelHashMap.cpp:57-63)
     const int ox = lane / 9 - 1, oy = (lane / 3) % 3 - 1, oz = lane % 3 - 1;
+    unsigned wave_candidates = 0;   // wave-uniform: sum over this wave's queries of C_q
 
-    unsigned wave_candidates = 0;   // wave-uniform: sum of C_q over this wave's queries
+    for (unsigned g = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * 4u + wv); g < ngroups;
+         g += waves_per_list) {
+        const int4 rec = groups[g];                 // wave-uniform 16-B record
+        const int start = rec.x & 0x03FFFFFF;
+        const int len = static_cast<unsigned>(rec.x) >> 26;
 
-    for (int q = q0; q < q1; ++q) {
-        const Point4 fq = P.frame[q];
-        double px, py, pz;
-        if (APPLY_POSE) {
-            px = R[0] * fq.x + R[1] * fq.y + R[2] * fq.z + t[0];
-            py = R[3] * fq.x + R[4] * fq.y + R[5] * fq.z + t[1];
-            pz = R[6] * fq.x + R[7] * fq.y + R[8] * fq.z + t[2];
-        } else {
-            px = fq.x; py = fq.y; pz = fq.z;
-        }
-        const double pl = fq.l;
-        const int pli = static_cast<int>(pl);
-
-        // static_cast<int>(p / voxel_size): exact fp64 divide, trunc toward zero.  One divide
-        // sequence serves the three axes (lane 0/1/2), results broadcast by readlane.
-        const double c = (lane == 0) ? px : ((lane == 1) ? py : pz);
-        const int kc = static_cast<int>(c / P.voxel_size);
-        const int kx = __builtin_amdgcn_readlane(kc, 0);
-        const int ky = __builtin_amdgcn_readlane(kc, 1);
-        const int kz = __builtin_amdgcn_readlane(kc, 2);
-
-        // 27 parallel hash probes
+        // ---- 27 parallel hash probes, one 16-B slot load per probe step
         uint32_t blk = kEmptySlot;
         if (lane < 27) {
-            const int vx = kx + ox, vy = ky + oy, vz = kz + oz;
+            const int vx = rec.y + ox, vy = rec.z + oy, vz = rec.w + oz;
             uint32_t s = voxel_hash(vx, vy, vz) & P.mask;
             for (;;) {
-                const Slot e = P.table[s];
-                if (e.blk == kEmptySlot) break;
-                if (e.x == vx && e.y == vy && e.z == vz) { blk = e.blk; break; }
+                const int4 e = reinterpret_cast<const int4 *>(P.table)[s];
+                if (static_cast<uint32_t>(e.w) == kEmptySlot) break;
+                if (e.x == vx && e.y == vy && e.z == vz) { blk = static_cast<uint32_t>(e.w); break; }
                 s = (s + 1) & P.mask;
             }
         }
         unsigned long long occupied = __ballot(blk != kEmptySlot);
 
-        double best = DBL_MAX;      // scaled squared distance (closest_distance2)
-        double best_raw = 0.0;      // unscaled squared distance of that candidate
-        int best_idx = -1;
-        unsigned best_key = 0xFFFFFFFFu;  // (voxel order << 8) | slot : first-minimum tie-break
-
-        while (occupied) {  // wave-uniform walk in reference enumeration order
+        // ---- enumerate the candidates once, in reference order, into LDS
+        unsigned C = 0;
+        while (occupied) {
             const int v = __builtin_ctzll(occupied);
             occupied &= occupied - 1;
             const uint32_t vb = rl_u32(blk, v);
             const uint32_t count = vb & 255u;
             const uint32_t base = (vb >> 8) * static_cast<uint32_t>(P.cap);
-            wave_candidates += count;
-            for (uint32_t s0 = 0; s0 < count; s0 += 64) {
-                const uint32_t slot = s0 + lane;
-                if (slot < count) {
-                    const Point4 nb = P.pts[base + slot];
-                    const double dx = nb.x - px, dy = nb.y - py, dz = nb.z - pz;
-                    const double raw = dx * dx + (dy * dy + dz * dz);
-                    double d = raw;
-                    // same label, or either side unlabelled (VoxelHashMap.cpp:87-88)
-                    if (static_cast<int>(nb.l) == pli || static_cast<int>(nb.l * pl) == 0)
-                        d = d * P.sem_th;
-                    if (d < best) {  // strict <: first minimum wins within the lane
-                        best = d;
-                        best_raw = raw;
-                        best_idx = static_cast<int>(base + slot);
-                        best_key = (static_cast<unsigned>(v) << 8) | slot;
-                    }
-                }
+            for (uint32_t s0 = 0; s0 < count; s0 += 64)
+                if (s0 + lane < count) cand[C + s0 + lane] = base + s0 + lane;
+            C += count;
+        }
+        wave_candidates += C * static_cast<unsigned>(len);
+
+        // ---- (query x candidate) pairs over the lanes: W lanes per query
+        const int lgq = (len <= 1) ? 0 : (32 - __builtin_clz(static_cast<unsigned>(len - 1)));
+        const int lw = 6 - lgq;                     // log2(W)
+        const int W = 1 << lw;
+        const int qi = lane >> lw;                  // query of this lane within the group
+        const int ci = lane & (W - 1);
+        const bool active = qi < len;
+        Point4 p;
+        p.x = p.y = p.z = p.l = 0.0;
+        if (active) p = P.src[start + qi];
+        const int pli = static_cast<int>(p.l);
+
+        double best = DBL_MAX;        // scaled squared distance (closest_distance2)
+        unsigned best_f = 0xFFFFFFFFu;  // flat candidate index == enumeration order: tie-break
+
+        auto eval = [&](unsigned f, const Point4 &nb) {
+            const double dx = nb.x - p.x, dy = nb.y - p.y, dz = nb.z - p.z;
+            double d = dx * dx + (dy * dy + dz * dz);
+            // same label, or either side unlabelled (VoxelHashMap.cpp:87-88)
+            if (static_cast<int>(nb.l) == pli || static_cast<int>(nb.l * p.l) == 0) d = d * P.sem_th;
+            if (d < best) { best = d; best_f = f; }   // strict <: first minimum wins
+        };
+
+        if (active) {
+            const unsigned step = W;
+            for (unsigned f = ci; f < C; f += 4 * step) {     // 4 candidates in flight per lane
+                const unsigned f1 = f + step, f2 = f + 2 * step, f3 = f + 3 * step;
+                const bool v1 = f1 < C, v2 = f2 < C, v3 = f3 < C;
+                const uint32_t i0 = cand[f];
+                const uint32_t i1 = v1 ? cand[f1] : i0;
+                const uint32_t i2 = v2 ? cand[f2] : i0;
+                const uint32_t i3 = v3 ? cand[f3] : i0;
+                const Point4 n0 = P.pts[i0], n1 = P.pts[i1], n2 = P.pts[i2], n3 = P.pts[i3];
+                eval(f, n0);
+                if (v1) eval(f1, n1);
+                if (v2) eval(f2, n2);
+                if (v3) eval(f3, n3);
             }
         }
 
-        // cross-lane argmin, lexicographic on (distance, enumeration key)
+        // ---- argmin over the W lanes of each query: lexicographic (distance, enumeration index)
         double wbest = best;
-        unsigned wkey = best_key;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
+        unsigned wkey = best_f;
+        for (int off = W >> 1; off > 0; off >>= 1) {
             const double ob = __shfl_xor(wbest, off, 64);
             const unsigned ok = __shfl_xor(wkey, off, 64);
             if (ob < wbest || (ob == wbest && ok < wkey)) { wbest = ob; wkey = ok; }
         }
-        if (wkey == 0xFFFFFFFFu) {
-            if (lane == 0) P.nn_idx[q] = -1;   // no candidate at all -> rejected
-        } else if (best_key == wkey) {
-            // acceptance on the UNscaled Euclidean distance (VoxelHashMap.cpp:111)
-            P.nn_idx[q] = (sqrt(best_raw) < P.max_dist) ? best_idx : -1;
+        if (active) {
+            if (wkey == 0xFFFFFFFFu) {
+                if (ci == 0) P.nn_idx[start + qi] = -1;      // no candidate at all -> rejected
+            } else if (best_f == wkey) {
+                // acceptance on the UNscaled Euclidean distance (VoxelHashMap.cpp:111)
+                const uint32_t idx = cand[wkey];
+                const Point4 nb = P.pts[idx];
+                const double dx = nb.x - p.x, dy = nb.y - p.y, dz = nb.z - p.z;
+                const double raw = dx * dx + (dy * dy + dz * dz);
+                P.nn_idx[start + qi] = (sqrt(raw) < P.max_dist) ? static_cast<int>(idx) : -1;
+            }
         }
     }
     if (P.cand_counter && lane == 0 && wave_candidates)
@@ -152,19 +222,13 @@ __global__ __launch_bounds__(256) void k_nn(NnParams P) {
 
 // ------------------------------------------------------------------------------------ k_gn
 __global__ __launch_bounds__(256) void k_gn(GnParams P) {
-    if (P.apply_pose && P.st->done) return;
+    if (P.check_done && P.st->done) return;
     __shared__ double lds[4][kNumSums];
 
     double acc[kCount + 1];
 #pragma unroll
     for (int i = 0; i <= kCount; ++i) acc[i] = 0.0;
 
-    double R[9], t[3];
-    if (P.apply_pose) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) R[i] = P.st->R[i];
-        t[0] = P.st->T[4]; t[1] = P.st->T[5]; t[2] = P.st->T[6];
-    }
     const double k = P.kernel;
     const double k2 = k * k;
 
@@ -177,15 +241,8 @@ __global__ __launch_bounds__(256) void k_gn(GnParams P) {
             if (idx < 0) continue;
             g = P.pts[idx];
         }
-        const Point4 fq = P.frame[q];
-        double sx, sy, sz;
-        if (P.apply_pose) {
-            sx = R[0] * fq.x + R[1] * fq.y + R[2] * fq.z + t[0];
-            sy = R[3] * fq.x + R[4] * fq.y + R[5] * fq.z + t[1];
-            sz = R[6] * fq.x + R[7] * fq.y + R[8] * fq.z + t[2];
-        } else {
-            sx = fq.x; sy = fq.y; sz = fq.z;
-        }
+        const Point4 s = P.src[q];
+        const double sx = s.x, sy = s.y, sz = s.z;
         const double rx = sx - g.x, ry = sy - g.y, rz = sz - g.z;
         const double r2 = rx * rx + (ry * ry + rz * rz);
         const double den = k + r2;
@@ -233,8 +290,18 @@ __global__ __launch_bounds__(256) void k_fin(IcpState *st, const double *partial
     if (mode != 2) {
         const int comp = threadIdx.x & 31, sl = threadIdx.x >> 5;
         double v = 0.0;
-        if (comp < kNumSums)
-            for (int b = sl; b < nparts; b += 8) v += partials[b * kNumSums + comp];
+        if (comp < kNumSums) {
+            // fixed summation order; loads are independent, 8 in flight per thread
+            int b = sl;
+            for (; b + 56 < nparts; b += 64) {
+                double t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = partials[(b + 8 * u) * kNumSums + comp];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v += t[u];
+            }
+            for (; b < nparts; b += 8) v += partials[b * kNumSums + comp];
+        }
         slice[sl][comp] = v;
         __syncthreads();
         if (threadIdx.x < kNumSums) {
@@ -254,26 +321,40 @@ __global__ __launch_bounds__(256) void k_fin(IcpState *st, const double *partial
     if (threadIdx.x != 0) return;
     double JTJ[36], JTr[6], neg[6], x[6], est[7];
     assemble_normal_equations(S, JTJ, JTr);
+#pragma unroll
     for (int i = 0; i < 6; ++i) neg[i] = -JTr[i];
     ldlt_solve6(JTJ, neg, x);
     se3_exp(x, est);
 
     double Tn[7];
     se3_mul(est, st->T, Tn);
+#pragma unroll
     for (int i = 0; i < 7; ++i) st->T[i] = Tn[i];
     quat_to_mat(Tn, st->R);
     se3_mul(est, st->T_icp, Tn);
+#pragma unroll
     for (int i = 0; i < 7; ++i) st->T_icp[i] = Tn[i];
 
-    double lg[6];
-    se3_log(est, lg);
+    // ||log(exp(x))|| == ||x|| (principal branch, |omega| < pi, which a Gauss-Newton step of a
+    // converging registration always satisfies): the reference's estimation.log().norm()
+    // (Registration.cpp:137) without the atan2/sincos round trip on one serial lane.
     double nrm = 0.0;
-    for (int i = 0; i < 6; ++i) nrm += lg[i] * lg[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) nrm += x[i] * x[i];
     nrm = sqrt(nrm);
+    if (!(x[3] * x[3] + x[4] * x[4] + x[5] * x[5] < 9.0)) {   // |omega| >= 3: take the exact path
+        double lg[6];
+        se3_log(est, lg);
+        nrm = 0.0;
+        for (int i = 0; i < 6; ++i) nrm += lg[i] * lg[i];
+        nrm = sqrt(nrm);
+    }
     st->last_step_norm = nrm;
     const int it = st->iter;
     if (it < kHistory) st->n_corr[it] = static_cast<uint32_t>(S[kCount]);
     st->iter = it + 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st->ngroups[i] = 0;   // k_group of the next iteration appends from zero
     if (nrm < kEstimationThreshold) {
         st->converged = 1;
         st->done = 1;
@@ -297,10 +378,10 @@ __global__ __launch_bounds__(256) void k_tf(Point4 *pts, int n, const IcpState *
 
 // ------------------------------------------------------------------------------------ launchers
 int nn_grid_for(int n) {
-    // one wave per query chunk; 2048 workgroups x 4 waves = every wave slot of the chip
-    // (256 CUs x 32 waves) once; smaller inputs shrink the grid in multiples of 8 (XCD remap).
-    long waves = n;
-    long blocks = (waves + 3) / 4;
+    // persistent waves striding over the groups; 2048 workgroups x 4 waves = every wave slot of
+    // the chip (256 CUs x 32 waves).  There are at least n/32 groups and at most n.  A multiple
+    // of 8 so that every XCD list gets the same number of waves.
+    long blocks = (static_cast<long>(n) + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     blocks = ((blocks + 7) / 8) * 8;
     return static_cast<int>(blocks);
@@ -313,13 +394,25 @@ int gn_grid_for(int n) {
     return static_cast<int>(blocks);
 }
 
-void launch_nn(const NnParams &p, bool apply_pose, hipStream_t s) {
+unsigned nn_cand_stride(int cap) {
+    // LDS words per wave: 27 voxels x cap candidates, rounded to a multiple of 4 words
+    return (27u * static_cast<unsigned>(cap) + 3u) & ~3u;
+}
+
+void launch_group(const GroupParams &p, bool apply_pose, hipStream_t s) {
+    if (p.n <= 0) return;
+    const int grid = (p.n + 255) / 256;
+    if (apply_pose)
+        hipLaunchKernelGGL(k_group<true>, dim3(grid), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL(k_group<false>, dim3(grid), dim3(256), 0, s, p);
+}
+
+void launch_nn(const NnParams &p, hipStream_t s) {
     if (p.n <= 0) return;
     const int grid = nn_grid_for(p.n);
-    if (apply_pose)
-        hipLaunchKernelGGL(k_nn<true>, dim3(grid), dim3(256), 0, s, p);
-    else
-        hipLaunchKernelGGL(k_nn<false>, dim3(grid), dim3(256), 0, s, p);
+    const size_t lds = 4u * p.cand_stride * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_nn, dim3(grid), dim3(256), lds, s, p);
 }
 
 int launch_gn(const GnParams &p, hipStream_t s) {

@@ -123,48 +123,103 @@ SAGE_HD inline void se3_log(const double T[7], double a[6]) {
 // pseudo-inverted (x = 0 for A = 0), matching Eigen::LDLT::solve's behaviour on the
 // rank-deficient systems ICP can produce (no correspondences, planar scenes).
 // A is row-major, only the lower triangle is read.
+//
+// Every loop has a compile-time trip count and every array index is a compile-time constant
+// after unrolling (the run-time pivot index is matched by an if-cascade), so on the device the
+// 6x6 lives in registers: a dynamically indexed A[][] goes to scratch memory and made the
+// one-lane solve in k_fin several times slower.
+SAGE_HD inline void ldlt_sym_swap(double (&A)[6][6], const int k, const int p) {
+    // symmetric interchange of rows/columns k < p on the lower triangle
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+        if (j < k) { const double s = A[k][j]; A[k][j] = A[p][j]; A[p][j] = s; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        if (i > p) { const double s = A[i][k]; A[i][k] = A[i][p]; A[i][p] = s; }
+    { const double s = A[k][k]; A[k][k] = A[p][p]; A[p][p] = s; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        if (i > k && i < p) { const double s = A[i][k]; A[i][k] = A[p][i]; A[p][i] = s; }
+}
+
 SAGE_HD inline void ldlt_solve6(const double *Ain, const double *b, double *x) {
     double A[6][6];
+#pragma unroll
     for (int i = 0; i < 6; ++i)
+#pragma unroll
         for (int j = 0; j < 6; ++j) A[i][j] = Ain[i * 6 + j];
-    int tr[6];
+    int tr[6] = {0, 1, 2, 3, 4, 5};
     bool zero = false;
-    for (int k = 0; k < 6 && !zero; ++k) {
-        int piv = k;
-        double big = fabs(A[k][k]);
-        for (int i = k + 1; i < 6; ++i) {
-            const double v = fabs(A[i][i]);
-            if (v > big) { big = v; piv = i; }
-        }
-        tr[k] = piv;
-        if (piv != k) {
-            for (int j = 0; j < k; ++j) { const double s = A[k][j]; A[k][j] = A[piv][j]; A[piv][j] = s; }
-            for (int i = piv + 1; i < 6; ++i) { const double s = A[i][k]; A[i][k] = A[i][piv]; A[i][piv] = s; }
-            { const double s = A[k][k]; A[k][k] = A[piv][piv]; A[piv][piv] = s; }
-            for (int i = k + 1; i < piv; ++i) { const double s = A[i][k]; A[i][k] = A[piv][i]; A[piv][i] = s; }
-        }
-        double tmp[6];
-        for (int j = 0; j < k; ++j) tmp[j] = A[j][j] * A[k][j];
-        for (int j = 0; j < k; ++j) A[k][k] -= A[k][j] * tmp[j];
-        for (int i = k + 1; i < 6; ++i)
-            for (int j = 0; j < k; ++j) A[i][k] -= A[i][j] * tmp[j];
-        const double akk = A[k][k];
-        if (fabs(akk) > 0.0) {
-            for (int i = k + 1; i < 6; ++i) A[i][k] /= akk;
-        } else if (k == 0) {
-            for (int j = 0; j < 6; ++j) { tr[j] = j; A[j][j] = 0.0; }
-            zero = true;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        if (!zero) {
+            int piv = k;
+            double big = fabs(A[k][k]);
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                if (i > k) {
+                    const double v = fabs(A[i][i]);
+                    if (v > big) { big = v; piv = i; }
+                }
+            tr[k] = piv;
+#pragma unroll
+            for (int p = 0; p < 6; ++p)
+                if (p > k && piv == p) ldlt_sym_swap(A, k, p);
+            double tmp[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (j < k) tmp[j] = A[j][j] * A[k][j];
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (j < k) A[k][k] -= A[k][j] * tmp[j];
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                if (i > k) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j)
+                        if (j < k) A[i][k] -= A[i][j] * tmp[j];
+                }
+            const double akk = A[k][k];
+            if (fabs(akk) > 0.0) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                    if (i > k) A[i][k] /= akk;
+            } else if (k == 0) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) { tr[j] = j; A[j][j] = 0.0; }
+                zero = true;
+            }
         }
     }
     double y[6];
+#pragma unroll
     for (int i = 0; i < 6; ++i) y[i] = b[i];
-    for (int k = 0; k < 6; ++k) { const double s = y[k]; y[k] = y[tr[k]]; y[tr[k]] = s; }
-    for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < i; ++j) y[i] -= A[i][j] * y[j];
-    for (int i = 0; i < 6; ++i) y[i] = (fabs(A[i][i]) > 2.2250738585072014e-308) ? y[i] / A[i][i] : 0.0;
-    for (int i = 5; i >= 0; --i)
-        for (int j = i + 1; j < 6; ++j) y[i] -= A[j][i] * y[j];
-    for (int k = 5; k >= 0; --k) { const double s = y[k]; y[k] = y[tr[k]]; y[tr[k]] = s; }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {          // y = P b
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+            if (p > k && tr[k] == p) { const double s = y[k]; y[k] = y[p]; y[p] = s; }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)            // L^-1
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            if (j < i) y[i] -= A[i][j] * y[j];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)            // D^+
+        y[i] = (fabs(A[i][i]) > 2.2250738585072014e-308) ? y[i] / A[i][i] : 0.0;
+#pragma unroll
+    for (int i = 5; i >= 0; --i)           // L^-T
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            if (j > i) y[i] -= A[j][i] * y[j];
+#pragma unroll
+    for (int k = 5; k >= 0; --k) {         // P^T
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+            if (p > k && tr[k] == p) { const double s = y[k]; y[k] = y[p]; y[p] = s; }
+    }
+#pragma unroll
     for (int i = 0; i < 6; ++i) x[i] = y[i];
 }
 

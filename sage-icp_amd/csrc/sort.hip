@@ -1,0 +1,84 @@
+// Per-frame spatial ordering of the scan (gfx950).  The reference hands RegisterFrame a scan in
+// hash-map iteration order (core/Preprocessing.cpp:75-82), i.e. spatially random.  Here the
+// frame is re-ordered once per call along the Morton curve of the map-frame voxels its points
+// fall into under the initial guess, so that queries sharing a home voxel are consecutive
+// (k_group cuts the frame into such runs and k_nn serves a whole run with one candidate list)
+// and neighbouring runs touch neighbouring voxel blocks (L1/L2 hits).  The pose moves by less
+// than a voxel during the ICP loop, so the order stays good for every iteration.
+// A stable sort keeps the result — and therefore the fp64 summation order of k_gn —
+// bit-reproducible from run to run.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "kernels.h"
+
+namespace sageicp {
+
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {
+    v &= 1023u;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+template <bool APPLY_POSE>
+__global__ __launch_bounds__(256) void k_morton_keys(const Point4 *pts, int n, const IcpState *st,
+                                                     double voxel_size, uint32_t *keys,
+                                                     uint32_t *vals) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const Point4 f = pts[i];
+    double x = f.x, y = f.y, z = f.z;
+    if (APPLY_POSE) {
+        const double *R = st->R;
+        const double *T = st->T;
+        x = R[0] * f.x + R[1] * f.y + R[2] * f.z + T[4];
+        y = R[3] * f.x + R[4] * f.y + R[5] * f.z + T[5];
+        z = R[6] * f.x + R[7] * f.y + R[8] * f.z + T[6];
+    }
+    // the same expression k_group evaluates, so at the initial pose equal keys <=> same home voxel
+    // (10 bits per axis: voxels 1024 apart alias, which only costs a group split)
+    const int cx = static_cast<int>(x / voxel_size) + 512;
+    const int cy = static_cast<int>(y / voxel_size) + 512;
+    const int cz = static_cast<int>(z / voxel_size) + 512;
+    keys[i] = spread10(static_cast<uint32_t>(cx)) | (spread10(static_cast<uint32_t>(cy)) << 1) |
+              (spread10(static_cast<uint32_t>(cz)) << 2);
+    vals[i] = static_cast<uint32_t>(i);
+}
+
+__global__ __launch_bounds__(256) void k_gather(const Point4 *in, const uint32_t *perm, int n,
+                                                Point4 *out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    out[i] = in[perm[i]];
+}
+
+size_t sort_temp_bytes(int n) {
+    size_t bytes = 0;
+    uint32_t *k = nullptr;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k, k, k, k, n, 0, 30);
+    return bytes;
+}
+
+// keys/vals: 2*n uint32 each (in | out halves).  perm_out = vals + n afterwards.
+hipError_t sort_frame(const Point4 *d_in, Point4 *d_out, int n, const IcpState *st, bool apply_pose,
+                      double voxel_size, uint32_t *keys, uint32_t *vals, void *temp,
+                      size_t temp_bytes, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const int grid = (n + 255) / 256;
+    if (apply_pose)
+        hipLaunchKernelGGL(k_morton_keys<true>, dim3(grid), dim3(256), 0, s, d_in, n, st, voxel_size,
+                           keys, vals);
+    else
+        hipLaunchKernelGGL(k_morton_keys<false>, dim3(grid), dim3(256), 0, s, d_in, n, st,
+                           voxel_size, keys, vals);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys + n, vals,
+                                                      vals + n, n, 0, 30, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), 0, s, d_in, vals + n, n, d_out);
+    return hipGetLastError();
+}
+
+}  // namespace sageicp

@@ -131,6 +131,20 @@ def test_queries_exactly_on_voxel_faces(gpu_sage, oracle):
     assert np.array_equal(idx, oidx) and np.array_equal(tgt, otgt)
 
 
+@pytest.mark.parametrize("n_q,box", [(5000, 1.6), (700, 4.0), (64, 0.4), (33, 0.9)])
+def test_dense_queries_share_voxels(gpu_sage, oracle, n_q, box):
+    """many queries per home voxel: exercises every (queries x candidates) lane split of k_nn"""
+    rng = np.random.default_rng(14)
+    mp, _ = random_scene(14, n_map=30000, span=5.0)
+    q = rng.uniform(-box, box, size=(n_q, 4))
+    q[:, 3] = rng.choice([0, 40, 50, 70, 71, 80], size=n_q)
+    a, b = both_maps(gpu_sage, oracle, mp, vs=1.0)
+    _, tgt, idx = a.GetCorrespondences(q, 2.0, 0.4, with_index=True)
+    _, otgt, oidx = b.get_correspondences(q, 2.0, 0.4, with_index=True)
+    assert len(oidx) > 0.5 * n_q
+    assert np.array_equal(idx, oidx) and np.array_equal(tgt, otgt)
+
+
 def test_mirror_refresh_after_updates(gpu_sage, oracle):
     """dirty-block / table refresh: search between successive map mutations stays exact"""
     rng = np.random.default_rng(13)
