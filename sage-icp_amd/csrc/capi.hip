@@ -16,7 +16,9 @@
 #include <rccl/rccl.h>
 
 #include <chrono>
+#include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -33,6 +35,23 @@ namespace sageicp {
 // ---- errors --------------------------------------------------------------------------
 static thread_local std::string g_err;
 static int g_profiling = 0;
+
+// tuning knobs (defaults chosen by measurement on MI355X; the environment overrides are for
+// experiments only)
+static int env_int(const char *name, int dflt) {
+    const char *v = std::getenv(name);
+    return v ? std::atoi(v) : dflt;
+}
+static int group_cap() {
+    static int c = [] {
+        int v = env_int("SAGEICP_GROUP_MAX", 32);
+        int p = 1;
+        while (p * 2 <= v && p < 32) p *= 2;
+        return p;
+    }();
+    return c;
+}
+
 
 static int fail(int code, const std::string &msg) {
     g_err = msg;
@@ -64,8 +83,10 @@ struct Scratch {
     Point4 *d_sorted = nullptr; uint32_t *d_keys = nullptr; uint32_t *d_vals = nullptr;
     void *d_sort_temp = nullptr; size_t sort_cap = 0; size_t sort_temp_bytes_ = 0;
     // per-iteration work buffers: transformed queries and the group list (k_group)
-    Point4 *d_src = nullptr; int4 *d_groups = nullptr;
+    Point4 *d_src = nullptr; int4 *d_groups = nullptr; uint2 *d_blks = nullptr;
     double *d_partials = nullptr;
+    unsigned long long *d_cand = nullptr;      // per-wave candidate counters of k_nn
+    unsigned long long *h_cand = nullptr;      // pinned
     IcpState *d_state = nullptr;
     IcpState *h_state = nullptr;   // pinned
     std::vector<hipEvent_t> events;  // 5 per iteration of a chunk
@@ -81,6 +102,8 @@ struct Scratch {
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIPCHK(hipMalloc(&d_partials, sizeof(double) * kMaxGnBlocks * kNumSums));
         HIPCHK(hipMalloc(&d_state, sizeof(IcpState)));
+        HIPCHK(hipMalloc(&d_cand, sizeof(unsigned long long) * kNnMaxWaves));
+        HIPCHK(hipHostMalloc(&h_cand, sizeof(unsigned long long) * kNnMaxWaves, hipHostMallocDefault));
         HIPCHK(hipHostMalloc(&h_state, sizeof(IcpState), hipHostMallocDefault));
         return SAGEICP_OK;
     }
@@ -119,12 +142,15 @@ struct Scratch {
         if (d_sort_temp) HIPCHK(hipFree(d_sort_temp));
         if (d_src) HIPCHK(hipFree(d_src));
         if (d_groups) HIPCHK(hipFree(d_groups));
+        if (d_blks) HIPCHK(hipFree(d_blks));
+        d_blks = nullptr;
         d_sorted = nullptr; d_keys = d_vals = nullptr; d_sort_temp = nullptr; sort_cap = 0;
         d_src = nullptr; d_groups = nullptr;
         const size_t cap = n + n / 4 + 1024;
         HIPCHK(hipMalloc(&d_sorted, cap * sizeof(Point4)));
         HIPCHK(hipMalloc(&d_src, cap * sizeof(Point4)));
         HIPCHK(hipMalloc(&d_groups, 8 * static_cast<size_t>(group_list_stride(cap)) * sizeof(int4)));
+        HIPCHK(hipMalloc(&d_blks, 8 * static_cast<size_t>(group_list_stride(cap)) * 32 * sizeof(uint2)));
         HIPCHK(hipMalloc(&d_keys, 2 * cap * sizeof(uint32_t)));
         HIPCHK(hipMalloc(&d_vals, 2 * cap * sizeof(uint32_t)));
         sort_temp_bytes_ = sort_temp_bytes(static_cast<int>(cap));
@@ -153,8 +179,11 @@ struct Scratch {
         if (d_sort_temp) (void)hipFree(d_sort_temp);
         if (d_src) (void)hipFree(d_src);
         if (d_groups) (void)hipFree(d_groups);
+        if (d_blks) (void)hipFree(d_blks);
         if (d_partials) (void)hipFree(d_partials);
         if (d_state) (void)hipFree(d_state);
+        if (d_cand) (void)hipFree(d_cand);
+        if (h_cand) (void)hipHostFree(h_cand);
         if (h_state) (void)hipHostFree(h_state);
         (void)hipStreamDestroy(stream);
         *this = Scratch();
@@ -320,12 +349,15 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     }
 
     GroupParams grp{d_frame, static_cast<int>(n), sc.d_state, m->host.voxel_size, sc.d_src,
-                    sc.d_groups, sc.d_state->ngroups, group_list_stride(n)};
+                    sc.d_groups, sc.d_state->ngroups, group_list_stride(n), group_cap() - 1};
+    ProbeParams pp{sc.d_state, 1, sc.d_groups, sc.d_state->ngroups, group_list_stride(n), m->d_table,
+                   m->host.mask, m->host.cap, sc.d_blks};
     NnParams np{sc.d_src, static_cast<int>(n), sc.d_state, 1, sc.d_groups, sc.d_state->ngroups,
-                group_list_stride(n), m->d_table, m->host.mask, m->d_pts, m->host.cap, nn_cand_stride(m->host.cap),
-                sem_th, max_dist, sc.d_nn, &sc.d_state->sum_candidates};
+                group_list_stride(n), sc.d_blks, m->d_pts, m->host.cap,
+                nn_cand_stride(m->host.cap), sem_th, sc.d_nn, sc.d_cand};
+    HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * kNnMaxWaves, s));
     GnParams gp{sc.d_src, nullptr, static_cast<int>(n), sc.d_state, 1, m->d_pts, sc.d_nn, kernel,
-                sc.d_partials};
+                max_dist, sc.d_partials};
     const int gn_blocks = gn_grid_for(static_cast<int>(n));
 
     double us_group = 0, us_nn = 0, us_gn = 0, us_fin = 0;
@@ -337,6 +369,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         for (int k = 0; k < todo; ++k) {
             if (prof) HIPCHK(hipEventRecord(sc.events[5 * k + 0], s));
             launch_group(grp, true, s);
+            launch_probe(pp, static_cast<int>(n), s);
             if (prof) HIPCHK(hipEventRecord(sc.events[5 * k + 1], s));
             launch_nn(np, s);
             if (prof) HIPCHK(hipEventRecord(sc.events[5 * k + 2], s));
@@ -377,6 +410,13 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     }
     const IcpState &st = *sc.h_state;
     for (int i = 0; i < 7; ++i) out[i] = st.T[i];
+    unsigned long long sum_candidates = 0;
+    if (stats) {
+        HIPCHK(hipMemcpyAsync(sc.h_cand, sc.d_cand, sizeof(unsigned long long) * kNnMaxWaves,
+                              hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        for (int i = 0; i < kNnMaxWaves; ++i) sum_candidates += sc.h_cand[i];
+    }
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         stats->iterations = st.iter;
@@ -389,7 +429,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         stats->us_group = us_group;
         stats->us_nn = us_nn; stats->us_gn = us_gn; stats->us_fin = us_fin;
         stats->nn_launches = nn_launches;
-        stats->sum_candidates = st.sum_candidates;
+        stats->sum_candidates = sum_candidates;
         for (int i = 0; i < 64 && i < st.iter; ++i) stats->n_corr_hist[i] = st.n_corr[i];
         stats->us_wall = now_us() - t_begin;
     }
@@ -527,11 +567,14 @@ int sageicp_get_correspondences(const sageicp_map *m, const double *q, uint64_t 
                       m->host.voxel_size, sc.d_keys, sc.d_vals, sc.d_sort_temp, sc.sort_temp_bytes_,
                       s));
     GroupParams grp{sc.d_sorted, static_cast<int>(n), sc.d_state, m->host.voxel_size, sc.d_src,
-                    sc.d_groups, sc.d_state->ngroups, group_list_stride(n)};
+                    sc.d_groups, sc.d_state->ngroups, group_list_stride(n), group_cap() - 1};
     launch_group(grp, false, s);
+    ProbeParams pp{sc.d_state, 0, sc.d_groups, sc.d_state->ngroups, group_list_stride(n), m->d_table,
+                   m->host.mask, m->host.cap, sc.d_blks};
+    launch_probe(pp, static_cast<int>(n), s);
     NnParams np{sc.d_src, static_cast<int>(n), sc.d_state, 0, sc.d_groups, sc.d_state->ngroups,
-                group_list_stride(n), m->d_table, m->host.mask, m->d_pts, m->host.cap, nn_cand_stride(m->host.cap),
-                sem_th, max_dist, sc.d_nn, nullptr};
+                group_list_stride(n), sc.d_blks, m->d_pts, m->host.cap,
+                nn_cand_stride(m->host.cap), sem_th, sc.d_nn, nullptr};
     launch_nn(np, s);
     HIPCHK(hipGetLastError());
     std::vector<int32_t> idx(n);
@@ -545,8 +588,12 @@ int sageicp_get_correspondences(const sageicp_map *m, const double *q, uint64_t 
     uint64_t k = 0;
     for (uint64_t i = 0; i < n; ++i) {     // pairs in query order (VoxelHashMap.cpp:119-127)
         if (by_query[i] < 0) continue;
+        // acceptance on the unscaled distance: (nn - point).norm() < max (VoxelHashMap.cpp:111)
+        const Point4 &t = m->host.pts[by_query[i]];
+        const double dx = t.x - q[4 * i], dy = t.y - q[4 * i + 1], dz = t.z - q[4 * i + 2];
+        if (!(std::sqrt(dx * dx + (dy * dy + dz * dz)) < max_dist)) continue;
         std::memcpy(src_out + 4 * k, q + 4 * i, 32);
-        std::memcpy(tgt_out + 4 * k, &m->host.pts[by_query[i]], 32);
+        std::memcpy(tgt_out + 4 * k, &t, 32);
         if (query_idx_out) query_idx_out[k] = static_cast<int64_t>(i);
         ++k;
     }
@@ -577,7 +624,7 @@ int sageicp_align_clouds(const double *src, const double *tgt, uint64_t n, doubl
         fill_state(sc.h_state, I);
         HIPCHK(hipMemcpyAsync(sc.d_state, sc.h_state, sizeof(IcpState), hipMemcpyHostToDevice, s));
         GnParams gp{sc.d_frame, sc.d_tgt, static_cast<int>(n), sc.d_state, 0, nullptr, nullptr,
-                    kernel, sc.d_partials};
+                    kernel, 0.0, sc.d_partials};
         const int blocks = launch_gn(gp, s);
         launch_fin(sc.d_state, sc.d_partials, blocks, 0, 1, s);
         HIPCHK(hipGetLastError());

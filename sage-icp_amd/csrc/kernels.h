@@ -16,6 +16,19 @@ struct GroupParams {
     int4 *groups;             // out: 8 lists of {start | len << 26, kx, ky, kz} records
     unsigned *ngroups;        // out: 8 list lengths (appended atomically; zeroed by k_fin / upload)
     unsigned list_stride;     // records reserved per list (group_list_stride(n))
+    int group_mask;           // group cap - 1 (cap is a power of two <= 32)
+};
+
+struct ProbeParams {
+    const IcpState *st;
+    int check_done;
+    const int4 *groups;
+    const unsigned *ngroups;
+    unsigned list_stride;
+    const Slot *table;
+    uint32_t mask;
+    int cap;
+    uint2 *blks;              // out: [8 * list_stride][32] {candidate offset, first point} per voxel
 };
 
 struct NnParams {
@@ -26,15 +39,14 @@ struct NnParams {
     const int4 *groups;
     const unsigned *ngroups;
     unsigned list_stride;
-    const Slot *table;
-    uint32_t mask;
+    const uint2 *blks;        // {candidate offset, first point} tables of k_probe
     const Point4 *pts;
     int cap;
     unsigned cand_stride;     // LDS words per wave (nn_cand_stride(cap))
     double sem_th;
-    double max_dist;
-    int32_t *nn_idx;          // out: block*cap+slot of the accepted neighbour, -1 if none
-    unsigned long long *cand_counter;  // optional: += sum_q C_q (candidates visible to q)
+    int32_t *nn_idx;          // out: block*cap+slot of the semantic nearest neighbour, -1 if the
+                              //      27-voxel neighbourhood is empty (acceptance is applied later)
+    unsigned long long *cand_counter;  // optional: [kNnMaxWaves] per-wave running sums of C_q
 };
 
 struct GnParams {
@@ -46,13 +58,16 @@ struct GnParams {
     const Point4 *pts;
     const int32_t *nn_idx;
     double kernel;
+    double max_dist;          // acceptance threshold on the unscaled distance
     double *partials;         // [gridDim.x][kNumSums]
 };
 
 constexpr int kMaxGnBlocks = 512;
+constexpr int kNnMaxWaves = 2048 * 4;   // k_nn grid is at most 2048 workgroups of 4 waves
 constexpr uint64_t kMaxQueries = (1ull << 26) - 1;   // group record packs start into 26 bits
 
 void launch_group(const GroupParams &p, bool apply_pose, hipStream_t s);
+void launch_probe(const ProbeParams &p, int n, hipStream_t s);
 void launch_nn(const NnParams &p, hipStream_t s);
 int launch_gn(const GnParams &p, hipStream_t s);   // returns the number of partials written
 void launch_fin(IcpState *st, const double *partials, int nparts, int mode, int standalone,

@@ -45,7 +45,8 @@ __device__ __forceinline__ uint32_t rl_u32(uint32_t v, int lane) {
 
 // ---------------------------------------------------------------------------------- k_group
 // One lane per query.  Group heads: a query whose home voxel differs from its predecessor's,
-// or whose index is a multiple of 32 (so a group never exceeds 32 queries nor crosses a wave).
+// or whose index is a multiple of the group cap (a power of two <= 32, so a group never crosses
+// a wave).
 template <bool APPLY_POSE>
 __global__ __launch_bounds__(256) void k_group(GroupParams P) {
     if (APPLY_POSE && P.st->done) return;
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void k_group(GroupParams P) {
         kz = static_cast<int>(s.z / P.voxel_size);
     }
     const int pkx = __shfl_up(kx, 1, 64), pky = __shfl_up(ky, 1, 64), pkz = __shfl_up(kz, 1, 64);
-    const bool head = valid && ((lane & 31) == 0 || kx != pkx || ky != pky || kz != pkz);
+    const bool head = valid && ((lane & P.group_mask) == 0 || kx != pkx || ky != pky || kz != pkz);
     const unsigned long long heads = __ballot(head);
     if (heads == 0) return;
     const unsigned long long live = __ballot(valid);
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void k_group(GroupParams P) {
         // length: distance to the next head, the end of this 32-query chunk or the end of the frame
         const unsigned long long above = (lane == 63) ? 0ull : (heads >> (lane + 1)) << (lane + 1);
         int end = above ? __builtin_ctzll(above) : 64;
-        end = min(end, (lane | 31) + 1);
+        end = min(end, (lane | P.group_mask) + 1);
         end = min(end, 64 - __builtin_clzll(live));
         const unsigned rank = __popcll(heads & ((1ull << lane) - 1ull));
         int4 rec;
@@ -103,121 +104,250 @@ __global__ __launch_bounds__(256) void k_group(GroupParams P) {
     }
 }
 
+// ---------------------------------------------------------------------------------- k_probe
+// One lane per (group, neighbour voxel): 32 lanes per group slot, 27 of them probing the GPU-
+// resident open-addressed hash (linear probing, 16-B slots, load factor <= 0.25).  Doing the
+// probes here — 1.4 M independent look-ups, no serial chain — instead of at the head of k_nn's
+// per-group dependency chain takes one to three memory round trips off every k_nn wave.
+// blks[slot][v] = {exclusive candidate offset, index of the voxel block's first point} of
+// neighbour v (x outer, y, z inner).
+__global__ __launch_bounds__(256) void k_probe(ProbeParams P) {
+    if (P.check_done && P.st->done) return;
+    const unsigned slot = blockIdx.x * 8u + (threadIdx.x >> 5);      // group slot over all 8 lists
+    const unsigned v = threadIdx.x & 31u;
+    const unsigned list = slot / P.list_stride;
+    if (list >= 8u || slot - list * P.list_stride >= P.ngroups[list]) return;
+    uint32_t blk = kEmptySlot;
+    if (v < 27u) {
+        const int4 rec = P.groups[slot];
+        const int vx = rec.y + static_cast<int>(v / 9u) - 1;
+        const int vy = rec.z + static_cast<int>((v / 3u) % 3u) - 1;
+        const int vz = rec.w + static_cast<int>(v % 3u) - 1;
+        uint32_t s = voxel_hash(vx, vy, vz) & P.mask;
+        for (;;) {
+            int4 e = reinterpret_cast<const int4 *>(P.table)[s];
+            asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(e.z), "+v"(e.w));   // one 16-B load
+            if (static_cast<uint32_t>(e.w) == kEmptySlot) break;
+            if (e.x == vx && e.y == vy && e.z == vz) { blk = static_cast<uint32_t>(e.w); break; }
+            s = (s + 1) & P.mask;
+        }
+    }
+    // exclusive prefix of the candidate counts over the group's 32 lanes (reference enumeration
+    // order); entry 27 carries the total C and 28..31 a sentinel, so k_nn can locate the voxel
+    // of any flat candidate index with a fixed 5-step binary search over 32 entries.
+    const uint32_t cnt = (blk == kEmptySlot) ? 0u : (blk & 255u);
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d, 32);
+        if (v >= static_cast<unsigned>(d)) incl += t;
+    }
+    uint32_t off = incl - cnt;
+    if (v > 27u) off = 0xFFFFFFFFu;
+    uint2 rec2;
+    rec2.x = off;
+    rec2.y = (blk == kEmptySlot) ? 0u : (blk >> 8) * static_cast<uint32_t>(P.cap);   // first point
+    P.blks[slot * 32u + v] = rec2;
+}
+
 // ------------------------------------------------------------------------------------- k_nn
+// Cross-lane helpers.  DPP moves run on the VALU (no LDS traffic, no scalar instructions); the
+// patterns used are involutions (quad swaps, half-row and row mirrors), so each step is an
+// exchange and every lane of a segment ends with the segment's result.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+    return static_cast<unsigned>(
+        __builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), CTRL, 0xF, 0xF, false));
+}
+constexpr int kDppXor1 = 0xB1;          // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;          // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;   // lane i <-> 7 - i   within each 8
+constexpr int kDppMirror = 0x140;       // lane i <-> 15 - i  within each 16
+
+__device__ __forceinline__ void argmin_merge(double &b, unsigned &k, double ob, unsigned ok) {
+    const bool take = ob < b || (ob == b && ok < k);   // lexicographic (distance, enumeration index)
+    b = take ? ob : b;
+    k = take ? ok : k;
+}
+
+// One group: `len` (1..32) consecutive queries that share a home voxel, C candidates enumerated
+// in LDS.  W = 2^LW lanes serve each query, lane ci of them visiting candidates ci, ci+W, ...
+// Control flow is wave-uniform and branch-free inside the loop (indices are clamped, invalid
+// pairs are masked by select), which keeps the scalar unit — one per CU, shared by the four
+// SIMDs — out of the critical path.
+template <int LW>
+__device__ __forceinline__ void nn_group(const NnParams &P, const uint32_t *cand, int lane,
+                                         int start, int len, unsigned C) {
+    constexpr int W = 1 << LW;
+    const int qi = lane >> LW;                  // query of this lane within the group
+    const unsigned ci = lane & (W - 1);
+    const bool active = qi < len;
+    const Point4 p = P.src[start + min(qi, len - 1)];
+    const int pli = static_cast<int>(p.l);
+    const double th = P.sem_th;
+
+    double best = DBL_MAX;            // scaled squared distance (closest_distance2)
+    unsigned best_f = 0xFFFFFFFFu;    // flat candidate index == enumeration order: the tie-break
+
+    auto eval = [&](unsigned f, const Point4 &nb) {
+        const double dx = nb.x - p.x, dy = nb.y - p.y, dz = nb.z - p.z;
+        double d = dx * dx + (dy * dy + dz * dz);
+        // same label, or either side unlabelled (VoxelHashMap.cpp:87-88)
+        const bool same = static_cast<int>(nb.l) == pli || static_cast<int>(nb.l * p.l) == 0;
+        const double ds = d * th;
+        d = same ? ds : d;
+        const bool take = (f < C) && (d < best);      // strict <: first minimum wins in a lane
+        best = take ? d : best;
+        best_f = take ? f : best_f;
+    };
+
+    const unsigned last = C ? C - 1 : 0;
+    for (unsigned f0 = 0; f0 < C; f0 += 4 * W) {       // uniform trip count, 4 loads in flight
+        const unsigned f = f0 + ci, f1 = f + W, f2 = f + 2 * W, f3 = f + 3 * W;
+        const uint32_t i0 = cand[min(f, last)], i1 = cand[min(f1, last)],
+                       i2 = cand[min(f2, last)], i3 = cand[min(f3, last)];
+#if defined(SAGE_ABLATE_NOLOAD)      // ablation: no global candidate loads (compute + LDS only)
+        Point4 n0, n1, n2, n3;
+        n0.x = __uint_as_float(i0); n0.y = 1.0; n0.z = 2.0; n0.l = 3.0;
+        n1 = n0; n1.x = __uint_as_float(i1); n2 = n0; n2.x = __uint_as_float(i2);
+        n3 = n0; n3.x = __uint_as_float(i3);
+#else
+        const Point4 n0 = P.pts[i0], n1 = P.pts[i1], n2 = P.pts[i2], n3 = P.pts[i3];
+#endif
+#if defined(SAGE_ABLATE_NOEVAL)      // ablation: loads only, values kept live
+        asm volatile("" ::"v"(n0.x), "v"(n0.l), "v"(n1.x), "v"(n1.l), "v"(n2.x), "v"(n2.l),
+                     "v"(n3.x), "v"(n3.l));
+        best_f = f;
+#else
+        eval(f, n0);
+        eval(f1, n1);
+        eval(f2, n2);
+        eval(f3, n3);
+#endif
+    }
+
+    // argmin over the W lanes of each query
+    if (W >= 2) argmin_merge(best, best_f, dpp_f64<kDppXor1>(best), dpp_u32<kDppXor1>(best_f));
+    if (W >= 4) argmin_merge(best, best_f, dpp_f64<kDppXor2>(best), dpp_u32<kDppXor2>(best_f));
+    if (W >= 8) argmin_merge(best, best_f, dpp_f64<kDppHalfMirror>(best), dpp_u32<kDppHalfMirror>(best_f));
+    if (W >= 16) argmin_merge(best, best_f, dpp_f64<kDppMirror>(best), dpp_u32<kDppMirror>(best_f));
+    if (W >= 32) argmin_merge(best, best_f, __shfl_xor(best, 16, 64), __shfl_xor(best_f, 16, 64));
+    if (W >= 64) argmin_merge(best, best_f, __shfl_xor(best, 32, 64), __shfl_xor(best_f, 32, 64));
+
+    // The argmin is stored unconditionally; the acceptance test on the unscaled distance
+    // (VoxelHashMap.cpp:111) is applied where the pair is consumed (k_gn / the host join).
+    const uint32_t widx = cand[min(best_f, last)];
+    if (active && ci == 0)
+        P.nn_idx[start + qi] = (best_f == 0xFFFFFFFFu) ? -1 : static_cast<int>(widx);
+}
+
+#ifdef SAGE_NN_TIMING
+__device__ unsigned long long g_nn_phase[8];
+#define NN_T(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); tph[i] += _t - tprev; tprev = _t; } while (0)
+#else
+#define NN_T(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256) void k_nn(NnParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     if (P.check_done && P.st->done) return;
+#ifdef SAGE_NN_TIMING
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+    const unsigned long long tstart = tprev;
+#endif
 
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     uint32_t *cand = smem + wv * P.cand_stride;      // this wave's candidate list (absolute indices)
+    uint2 *tab = reinterpret_cast<uint2 *>(smem + 4u * P.cand_stride) + wv * 32;   // {offset, base} x 32
 
-    // workgroup b is dispatched to XCD b % 8 (observed; speed only): it serves group list b % 8
-    const unsigned list = blockIdx.x & 7u;
-    const unsigned ngroups = P.ngroups[list];
-    const int4 *groups = P.groups + list * P.list_stride;
-    const unsigned waves_per_list = (gridDim.x >> 3) * 4u;
-    // neighbour offset of this lane: x outer, y, z inner (VoxelHashMap.cpp:57-63)
-    const int ox = lane / 9 - 1, oy = (lane / 3) % 3 - 1, oz = lane % 3 - 1;
-    unsigned wave_candidates = 0;   // wave-uniform: sum over this wave's queries of C_q
+    // Workgroup b is dispatched to XCD b % 8 (observed; speed only): it serves group list b % 8,
+    // one compact region of the map per private L2.  Static striding: device-scope ticket
+    // counters were measured 20x slower here (cross-XCD atomics on a handful of addresses).
+    unsigned long long wave_candidates = 0;   // wave-uniform: sum over this wave's queries of C_q
+    {
+      const unsigned list = blockIdx.x & 7u;
+      const unsigned ngroups = P.ngroups[list];
+      const int4 *groups = P.groups + list * P.list_stride;
+      const uint2 *blks = P.blks + static_cast<size_t>(list) * P.list_stride * 32u;
+      const unsigned waves_per_list = (gridDim.x >> 3) * 4u;
+      {
+        for (unsigned g = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * 4u + wv); g < ngroups;
+             g += waves_per_list) {
+        // group record and the 32-entry {offset, base} table of k_probe: independent loads
+        const int startlen = __builtin_amdgcn_readfirstlane(groups[g].x);
+        uint2 ob;
+        ob.x = 0xFFFFFFFFu; ob.y = 0u;
+        if (lane < 32) ob = blks[g * 32u + lane];
+        const int start = startlen & 0x03FFFFFF;
+        const int len = static_cast<unsigned>(startlen) >> 26;
+#ifdef SAGE_NN_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        NN_T(0);
 
-    for (unsigned g = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * 4u + wv); g < ngroups;
-         g += waves_per_list) {
-        const int4 rec = groups[g];                 // wave-uniform 16-B record
-        const int start = rec.x & 0x03FFFFFF;
-        const int len = static_cast<unsigned>(rec.x) >> 26;
-
-        // ---- 27 parallel hash probes, one 16-B slot load per probe step
-        uint32_t blk = kEmptySlot;
-        if (lane < 27) {
-            const int vx = rec.y + ox, vy = rec.z + oy, vz = rec.w + oz;
-            uint32_t s = voxel_hash(vx, vy, vz) & P.mask;
-            for (;;) {
-                const int4 e = reinterpret_cast<const int4 *>(P.table)[s];
-                if (static_cast<uint32_t>(e.w) == kEmptySlot) break;
-                if (e.x == vx && e.y == vy && e.z == vz) { blk = static_cast<uint32_t>(e.w); break; }
-                s = (s + 1) & P.mask;
+        // Enumerate the candidates once, in reference order (x outer, y, z inner, then insertion
+        // order), into LDS.  No scalar loop over voxels: every lane finds the voxel of its flat
+        // candidate index by a fixed 5-step binary search over the 32 offsets (the scalar unit is
+        // shared by the CU's four SIMDs and was the bottleneck of a per-voxel readlane loop).
+        if (lane < 32) tab[lane] = ob;
+        const unsigned C = rl_u32(ob.x, 27);
+        for (unsigned f = lane; f < C; f += 64) {
+            unsigned pos = 0, o = 0, base = rl_u32(ob.y, 0);
+#pragma unroll
+            for (int stp = 16; stp >= 1; stp >>= 1) {
+                const uint2 t = tab[pos + stp];
+                const bool take = t.x <= f;
+                pos = take ? pos + stp : pos;
+                o = take ? t.x : o;
+                base = take ? t.y : base;
             }
+            cand[f] = base + (f - o);
         }
-        unsigned long long occupied = __ballot(blk != kEmptySlot);
+        wave_candidates += static_cast<unsigned long long>(C) * static_cast<unsigned>(len);
+#ifdef SAGE_NN_TIMING
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        NN_T(1);
 
-        // ---- enumerate the candidates once, in reference order, into LDS
-        unsigned C = 0;
-        while (occupied) {
-            const int v = __builtin_ctzll(occupied);
-            occupied &= occupied - 1;
-            const uint32_t vb = rl_u32(blk, v);
-            const uint32_t count = vb & 255u;
-            const uint32_t base = (vb >> 8) * static_cast<uint32_t>(P.cap);
-            for (uint32_t s0 = 0; s0 < count; s0 += 64)
-                if (s0 + lane < count) cand[C + s0 + lane] = base + s0 + lane;
-            C += count;
-        }
-        wave_candidates += C * static_cast<unsigned>(len);
-
-        // ---- (query x candidate) pairs over the lanes: W lanes per query
+        // (query x candidate) pairs over the lanes: W = 64 / pow2ceil(len) lanes per query
         const int lgq = (len <= 1) ? 0 : (32 - __builtin_clz(static_cast<unsigned>(len - 1)));
-        const int lw = 6 - lgq;                     // log2(W)
-        const int W = 1 << lw;
-        const int qi = lane >> lw;                  // query of this lane within the group
-        const int ci = lane & (W - 1);
-        const bool active = qi < len;
-        Point4 p;
-        p.x = p.y = p.z = p.l = 0.0;
-        if (active) p = P.src[start + qi];
-        const int pli = static_cast<int>(p.l);
-
-        double best = DBL_MAX;        // scaled squared distance (closest_distance2)
-        unsigned best_f = 0xFFFFFFFFu;  // flat candidate index == enumeration order: tie-break
-
-        auto eval = [&](unsigned f, const Point4 &nb) {
-            const double dx = nb.x - p.x, dy = nb.y - p.y, dz = nb.z - p.z;
-            double d = dx * dx + (dy * dy + dz * dz);
-            // same label, or either side unlabelled (VoxelHashMap.cpp:87-88)
-            if (static_cast<int>(nb.l) == pli || static_cast<int>(nb.l * p.l) == 0) d = d * P.sem_th;
-            if (d < best) { best = d; best_f = f; }   // strict <: first minimum wins
-        };
-
-        if (active) {
-            const unsigned step = W;
-            for (unsigned f = ci; f < C; f += 4 * step) {     // 4 candidates in flight per lane
-                const unsigned f1 = f + step, f2 = f + 2 * step, f3 = f + 3 * step;
-                const bool v1 = f1 < C, v2 = f2 < C, v3 = f3 < C;
-                const uint32_t i0 = cand[f];
-                const uint32_t i1 = v1 ? cand[f1] : i0;
-                const uint32_t i2 = v2 ? cand[f2] : i0;
-                const uint32_t i3 = v3 ? cand[f3] : i0;
-                const Point4 n0 = P.pts[i0], n1 = P.pts[i1], n2 = P.pts[i2], n3 = P.pts[i3];
-                eval(f, n0);
-                if (v1) eval(f1, n1);
-                if (v2) eval(f2, n2);
-                if (v3) eval(f3, n3);
-            }
+        switch (6 - lgq) {
+            case 6: nn_group<6>(P, cand, lane, start, len, C); break;
+            case 5: nn_group<5>(P, cand, lane, start, len, C); break;
+            case 4: nn_group<4>(P, cand, lane, start, len, C); break;
+            case 3: nn_group<3>(P, cand, lane, start, len, C); break;
+            case 2: nn_group<2>(P, cand, lane, start, len, C); break;
+            default: nn_group<1>(P, cand, lane, start, len, C); break;
         }
-
-        // ---- argmin over the W lanes of each query: lexicographic (distance, enumeration index)
-        double wbest = best;
-        unsigned wkey = best_f;
-        for (int off = W >> 1; off > 0; off >>= 1) {
-            const double ob = __shfl_xor(wbest, off, 64);
-            const unsigned ok = __shfl_xor(wkey, off, 64);
-            if (ob < wbest || (ob == wbest && ok < wkey)) { wbest = ob; wkey = ok; }
+#ifdef SAGE_NN_TIMING
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+        NN_T(2);
         }
-        if (active) {
-            if (wkey == 0xFFFFFFFFu) {
-                if (ci == 0) P.nn_idx[start + qi] = -1;      // no candidate at all -> rejected
-            } else if (best_f == wkey) {
-                // acceptance on the UNscaled Euclidean distance (VoxelHashMap.cpp:111)
-                const uint32_t idx = cand[wkey];
-                const Point4 nb = P.pts[idx];
-                const double dx = nb.x - p.x, dy = nb.y - p.y, dz = nb.z - p.z;
-                const double raw = dx * dx + (dy * dy + dz * dz);
-                P.nn_idx[start + qi] = (sqrt(raw) < P.max_dist) ? static_cast<int>(idx) : -1;
-            }
-        }
+      }
     }
+#ifdef SAGE_NN_TIMING
+    if (lane == 0) {
+        for (int i = 0; i < 3; ++i) atomicAdd(&g_nn_phase[i], tph[i]);
+        atomicAdd(&g_nn_phase[3], __builtin_amdgcn_s_memtime() - tstart);
+        atomicAdd(&g_nn_phase[4], 1ull);
+        atomicMax(&g_nn_phase[5], __builtin_amdgcn_s_memtime() - tstart);
+    }
+#endif
+    // sum_q C_q for the roofline accounting: one private slot per wave, summed by the host.  (A
+    // single device-scope atomic per wave serialised 8192 updates on one address and set a
+    // ~100 us floor under this kernel.)
     if (P.cand_counter && lane == 0 && wave_candidates)
-        atomicAdd(P.cand_counter, static_cast<unsigned long long>(wave_candidates));
+        P.cand_counter[blockIdx.x * 4u + wv] += wave_candidates;
 }
 
 // ------------------------------------------------------------------------------------ k_gn
@@ -245,6 +375,9 @@ __global__ __launch_bounds__(256) void k_gn(GnParams P) {
         const double sx = s.x, sy = s.y, sz = s.z;
         const double rx = sx - g.x, ry = sy - g.y, rz = sz - g.z;
         const double r2 = rx * rx + (ry * ry + rz * rz);
+        // acceptance: (closest_neighboor - point).norm() < max_correspondance_distance
+        // (VoxelHashMap.cpp:111); explicit pairs (align_clouds entry) are all taken
+        if (!P.tgt_pairs && !(sqrt(r2) < P.max_dist)) continue;
         const double den = k + r2;
         const double w = k2 / (den * den);   // square(th) / square(th + residual2)
         const double wsx = w * sx, wsy = w * sy, wsz = w * sz;
@@ -376,6 +509,16 @@ __global__ __launch_bounds__(256) void k_tf(Point4 *pts, int n, const IcpState *
     pts[i] = p;
 }
 
+#ifdef SAGE_NN_TIMING
+extern "C" void sageicp_debug_nn_phases(unsigned long long out[8], int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_phase), sizeof(unsigned long long) * 8);
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_nn_phase), z, sizeof(z));
+    }
+}
+#endif
+
 // ------------------------------------------------------------------------------------ launchers
 int nn_grid_for(int n) {
     // persistent waves striding over the groups; 2048 workgroups x 4 waves = every wave slot of
@@ -408,10 +551,16 @@ void launch_group(const GroupParams &p, bool apply_pose, hipStream_t s) {
         hipLaunchKernelGGL(k_group<false>, dim3(grid), dim3(256), 0, s, p);
 }
 
+void launch_probe(const ProbeParams &p, int n, hipStream_t s) {
+    if (n <= 0) return;
+    const unsigned slots = 8u * p.list_stride;
+    hipLaunchKernelGGL(k_probe, dim3((slots + 7u) / 8u), dim3(256), 0, s, p);
+}
+
 void launch_nn(const NnParams &p, hipStream_t s) {
     if (p.n <= 0) return;
     const int grid = nn_grid_for(p.n);
-    const size_t lds = 4u * p.cand_stride * sizeof(uint32_t);
+    const size_t lds = 4u * p.cand_stride * sizeof(uint32_t) + 4u * 32u * sizeof(uint2);
     hipLaunchKernelGGL(k_nn, dim3(grid), dim3(256), lds, s, p);
 }
 
