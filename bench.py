@@ -46,13 +46,6 @@ def parse():
     return ap.parse_args()
 
 
-def shard_bounds(n, rank, world):
-    """contiguous blocks of ceil(n / world) queries (keeps query order across ranks)"""
-    per = -(-n // world)
-    lo = min(n, rank * per)
-    return lo, min(n, lo + per)
-
-
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -78,6 +71,7 @@ def main():
 
     import sage_icp_amd as sage
     from sage_icp_amd import synthetic as syn
+    from sage_icp_amd.sharding import shard_bounds
 
     if sage.device_count() <= local_rank:
         raise SystemExit("HIP device %d not visible to libsageicp_hip.so" % local_rank)

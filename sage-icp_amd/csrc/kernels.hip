@@ -255,7 +255,7 @@ __device__ unsigned long long g_nn_phase[8];
 #define NN_T(i) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(256) void k_nn(NnParams P) {
+__global__ __launch_bounds__(256, 8) void k_nn(NnParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     if (P.check_done && P.st->done) return;
 #ifdef SAGE_NN_TIMING
