@@ -149,8 +149,8 @@ struct Scratch {
         const size_t cap = n + n / 4 + 1024;
         HIPCHK(hipMalloc(&d_sorted, cap * sizeof(Point4)));
         HIPCHK(hipMalloc(&d_src, cap * sizeof(Point4)));
-        HIPCHK(hipMalloc(&d_groups, 8 * static_cast<size_t>(group_list_stride(cap)) * sizeof(int4)));
-        HIPCHK(hipMalloc(&d_blks, 8 * static_cast<size_t>(group_list_stride(cap)) * 32 * sizeof(uint2)));
+        HIPCHK(hipMalloc(&d_groups, cap * sizeof(int4)));
+        HIPCHK(hipMalloc(&d_blks, cap * 32 * sizeof(uint2)));
         HIPCHK(hipMalloc(&d_keys, 2 * cap * sizeof(uint32_t)));
         HIPCHK(hipMalloc(&d_vals, 2 * cap * sizeof(uint32_t)));
         sort_temp_bytes_ = sort_temp_bytes(static_cast<int>(cap));
@@ -349,11 +349,11 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     }
 
     GroupParams grp{d_frame, static_cast<int>(n), sc.d_state, m->host.voxel_size, sc.d_src,
-                    sc.d_groups, sc.d_state->ngroups, group_list_stride(n), group_cap() - 1};
-    ProbeParams pp{sc.d_state, 1, sc.d_groups, sc.d_state->ngroups, group_list_stride(n), m->d_table,
-                   m->host.mask, m->host.cap, sc.d_blks};
-    NnParams np{sc.d_src, static_cast<int>(n), sc.d_state, 1, sc.d_groups, sc.d_state->ngroups,
-                group_list_stride(n), sc.d_blks, m->d_pts, m->host.cap,
+                    sc.d_groups, group_cap() - 1};
+    ProbeParams pp{sc.d_state, 1, sc.d_groups, static_cast<int>(n), m->d_table, m->host.mask,
+                   m->host.cap, sc.d_blks};
+    NnParams np{sc.d_src, static_cast<int>(n), sc.d_state, 1, sc.d_groups,
+                static_cast<unsigned>(group_cap()), sc.d_blks, m->d_pts, m->host.cap,
                 nn_cand_stride(m->host.cap), sem_th, sc.d_nn, sc.d_cand};
     HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * kNnMaxWaves, s));
     GnParams gp{sc.d_src, nullptr, static_cast<int>(n), sc.d_state, 1, m->d_pts, sc.d_nn, kernel,
@@ -567,13 +567,13 @@ int sageicp_get_correspondences(const sageicp_map *m, const double *q, uint64_t 
                       m->host.voxel_size, sc.d_keys, sc.d_vals, sc.d_sort_temp, sc.sort_temp_bytes_,
                       s));
     GroupParams grp{sc.d_sorted, static_cast<int>(n), sc.d_state, m->host.voxel_size, sc.d_src,
-                    sc.d_groups, sc.d_state->ngroups, group_list_stride(n), group_cap() - 1};
+                    sc.d_groups, group_cap() - 1};
     launch_group(grp, false, s);
-    ProbeParams pp{sc.d_state, 0, sc.d_groups, sc.d_state->ngroups, group_list_stride(n), m->d_table,
-                   m->host.mask, m->host.cap, sc.d_blks};
+    ProbeParams pp{sc.d_state, 0, sc.d_groups, static_cast<int>(n), m->d_table, m->host.mask,
+                   m->host.cap, sc.d_blks};
     launch_probe(pp, static_cast<int>(n), s);
-    NnParams np{sc.d_src, static_cast<int>(n), sc.d_state, 0, sc.d_groups, sc.d_state->ngroups,
-                group_list_stride(n), sc.d_blks, m->d_pts, m->host.cap,
+    NnParams np{sc.d_src, static_cast<int>(n), sc.d_state, 0, sc.d_groups,
+                static_cast<unsigned>(group_cap()), sc.d_blks, m->d_pts, m->host.cap,
                 nn_cand_stride(m->host.cap), sem_th, sc.d_nn, nullptr};
     launch_nn(np, s);
     HIPCHK(hipGetLastError());

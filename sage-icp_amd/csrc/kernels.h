@@ -13,9 +13,8 @@ struct GroupParams {
     const IcpState *st;       // pose to apply (apply_pose) and the done flag
     double voxel_size;
     Point4 *src;              // out: transformed queries (x, y, z, label)
-    int4 *groups;             // out: 8 lists of {start | len << 26, kx, ky, kz} records
-    unsigned *ngroups;        // out: 8 list lengths (appended atomically; zeroed by k_fin / upload)
-    unsigned list_stride;     // records reserved per list (group_list_stride(n))
+    int4 *groups;             // out: one record per query slot: {start | len << 26, kx, ky, kz}
+                              //      at a group's head query, x = -1 elsewhere
     int group_mask;           // group cap - 1 (cap is a power of two <= 32)
 };
 
@@ -23,12 +22,11 @@ struct ProbeParams {
     const IcpState *st;
     int check_done;
     const int4 *groups;
-    const unsigned *ngroups;
-    unsigned list_stride;
+    int n;                    // slots (== queries)
     const Slot *table;
     uint32_t mask;
     int cap;
-    uint2 *blks;              // out: [8 * list_stride][32] {candidate offset, first point} per voxel
+    uint2 *blks;              // out: [n][32] {candidate offset, first point} per neighbour voxel
 };
 
 struct NnParams {
@@ -37,8 +35,7 @@ struct NnParams {
     const IcpState *st;
     int check_done;           // 1 inside the ICP loop: later launches of a finished loop are no-ops
     const int4 *groups;
-    const unsigned *ngroups;
-    unsigned list_stride;
+    unsigned chunk;           // group cap: queries per chunk (a group never crosses a chunk)
     const uint2 *blks;        // {candidate offset, first point} tables of k_probe
     const Point4 *pts;
     int cap;
@@ -75,7 +72,6 @@ void launch_fin(IcpState *st, const double *partials, int nparts, int mode, int 
 void launch_tf(Point4 *pts, int n, const IcpState *st, hipStream_t s);
 int gn_grid_for(int n);
 unsigned nn_cand_stride(int cap);
-inline unsigned group_list_stride(uint64_t n) { return static_cast<unsigned>((n + 7) / 8 + 64); }
 
 // sort.hip: re-ordering of a frame along the Morton curve of its map-frame voxels
 size_t sort_temp_bytes(int n);

@@ -77,31 +77,24 @@ __global__ __launch_bounds__(256) void k_group(GroupParams P) {
     const int pkx = __shfl_up(kx, 1, 64), pky = __shfl_up(ky, 1, 64), pkz = __shfl_up(kz, 1, 64);
     const bool head = valid && ((lane & P.group_mask) == 0 || kx != pkx || ky != pky || kz != pkz);
     const unsigned long long heads = __ballot(head);
-    if (heads == 0) return;
     const unsigned long long live = __ballot(valid);
+    if (!valid) return;
 
-    // Eight group lists, one per eighth of the sorted frame: k_nn's workgroup b (dispatched to XCD
-    // b % 8) serves list b % 8, so each XCD's private L2 only ever sees one compact region of
-    // the map.  Within a list the append order is arbitrary (it only decides which wave serves
-    // which group, never a result).
-    const unsigned wave_q0 = blockIdx.x * 256u + (threadIdx.x & ~63u);
-    const unsigned list = static_cast<unsigned>((static_cast<unsigned long long>(wave_q0) * 8ull) /
-                                                static_cast<unsigned long long>(P.n));
-    unsigned base = 0;
-    if (lane == 0) base = atomicAdd(P.ngroups + list, static_cast<unsigned>(__popcll(heads)));
-    base = rl_u32(base, 0) + list * P.list_stride;
+    // Slot space: the record of a group lives at its head query's own index, every other slot is
+    // marked invalid.  No atomics, no compaction: k_probe and k_nn walk the slots in query order,
+    // so the work per wave is balanced by query count and each XCD's contiguous eighth of the
+    // (spatially sorted) slots is one compact region of the map.
+    int4 rec;
+    rec.x = -1; rec.y = kx; rec.z = ky; rec.w = kz;
     if (head) {
-        // length: distance to the next head, the end of this 32-query chunk or the end of the frame
+        // length: distance to the next head, the end of this chunk or the end of the frame
         const unsigned long long above = (lane == 63) ? 0ull : (heads >> (lane + 1)) << (lane + 1);
         int end = above ? __builtin_ctzll(above) : 64;
         end = min(end, (lane | P.group_mask) + 1);
         end = min(end, 64 - __builtin_clzll(live));
-        const unsigned rank = __popcll(heads & ((1ull << lane) - 1ull));
-        int4 rec;
         rec.x = q | ((end - lane) << 26);      // start (26 bits) | length (1..32)
-        rec.y = kx; rec.z = ky; rec.w = kz;
-        P.groups[base + rank] = rec;
     }
+    P.groups[q] = rec;
 }
 
 // ---------------------------------------------------------------------------------- k_probe
@@ -113,10 +106,10 @@ __global__ __launch_bounds__(256) void k_group(GroupParams P) {
 // neighbour v (x outer, y, z inner).
 __global__ __launch_bounds__(256) void k_probe(ProbeParams P) {
     if (P.check_done && P.st->done) return;
-    const unsigned slot = blockIdx.x * 8u + (threadIdx.x >> 5);      // group slot over all 8 lists
+    const unsigned slot = blockIdx.x * 8u + (threadIdx.x >> 5);      // one slot per query
     const unsigned v = threadIdx.x & 31u;
-    const unsigned list = slot / P.list_stride;
-    if (list >= 8u || slot - list * P.list_stride >= P.ngroups[list]) return;
+    if (slot >= static_cast<unsigned>(P.n)) return;
+    if (P.groups[slot].x == -1) return;                              // not a group head (uniform per 32 lanes)
     uint32_t blk = kEmptySlot;
     if (v < 27u) {
         const int4 rec = P.groups[slot];
@@ -269,21 +262,34 @@ __global__ __launch_bounds__(256, 8) void k_nn(NnParams P) {
     uint32_t *cand = smem + wv * P.cand_stride;      // this wave's candidate list (absolute indices)
     uint2 *tab = reinterpret_cast<uint2 *>(smem + 4u * P.cand_stride) + wv * 32;   // {offset, base} x 32
 
-    // Workgroup b is dispatched to XCD b % 8 (observed; speed only): it serves group list b % 8,
-    // one compact region of the map per private L2.  Static striding: device-scope ticket
-    // counters were measured 20x slower here (cross-XCD atomics on a handful of addresses).
+    // Workgroup b is dispatched to XCD b % 8 (observed; speed only): it serves the b % 8-th
+    // contiguous eighth of the sorted frame — one compact region of the map per private L2 — in
+    // chunks of `chunk` consecutive queries (a group never crosses a chunk), so every wave gets
+    // the same number of queries.  Static striding: device-scope ticket counters were measured
+    // 20x slower here (cross-XCD atomics on a handful of addresses).
     unsigned long long wave_candidates = 0;   // wave-uniform: sum over this wave's queries of C_q
     {
-      const unsigned list = blockIdx.x & 7u;
-      const unsigned ngroups = P.ngroups[list];
-      const int4 *groups = P.groups + list * P.list_stride;
-      const uint2 *blks = P.blks + static_cast<size_t>(list) * P.list_stride * 32u;
-      const unsigned waves_per_list = (gridDim.x >> 3) * 4u;
-      {
-        for (unsigned g = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * 4u + wv); g < ngroups;
-             g += waves_per_list) {
+      const unsigned chunk = P.chunk;
+      const unsigned nchunks = (static_cast<unsigned>(P.n) + chunk - 1u) / chunk;
+      const unsigned xcd = blockIdx.x & 7u;
+      const unsigned c_lo = static_cast<unsigned>((static_cast<unsigned long long>(xcd) * nchunks) >> 3);
+      const unsigned c_hi = static_cast<unsigned>((static_cast<unsigned long long>(xcd + 1u) * nchunks) >> 3);
+      const unsigned waves_per_xcd = (gridDim.x >> 3) * 4u;
+      const int4 *groups = P.groups;
+      const uint2 *blks = P.blks;
+      for (unsigned c = c_lo + __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * 4u + wv); c < c_hi;
+           c += waves_per_xcd) {
+        const unsigned q0 = c * chunk;
+        int sl = -1;
+        if (static_cast<unsigned>(lane) < chunk && q0 + lane < static_cast<unsigned>(P.n))
+            sl = groups[q0 + lane].x;
+        unsigned long long heads = __ballot(sl != -1);
+        while (heads) {
+        const int h = __builtin_ctzll(heads);
+        heads &= heads - 1;
+        const unsigned g = q0 + h;                  // slot of this group == its head query
         // group record and the 32-entry {offset, base} table of k_probe: independent loads
-        const int startlen = __builtin_amdgcn_readfirstlane(groups[g].x);
+        const int startlen = __builtin_amdgcn_readlane(sl, h);
         uint2 ob;
         ob.x = 0xFFFFFFFFu; ob.y = 0u;
         if (lane < 32) ob = blks[g * 32u + lane];
@@ -486,8 +492,6 @@ __global__ __launch_bounds__(256) void k_fin(IcpState *st, const double *partial
     const int it = st->iter;
     if (it < kHistory) st->n_corr[it] = static_cast<uint32_t>(S[kCount]);
     st->iter = it + 1;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) st->ngroups[i] = 0;   // k_group of the next iteration appends from zero
     if (nrm < kEstimationThreshold) {
         st->converged = 1;
         st->done = 1;
@@ -553,8 +557,7 @@ void launch_group(const GroupParams &p, bool apply_pose, hipStream_t s) {
 
 void launch_probe(const ProbeParams &p, int n, hipStream_t s) {
     if (n <= 0) return;
-    const unsigned slots = 8u * p.list_stride;
-    hipLaunchKernelGGL(k_probe, dim3((slots + 7u) / 8u), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_probe, dim3((static_cast<unsigned>(n) + 7u) / 8u), dim3(256), 0, s, p);
 }
 
 void launch_nn(const NnParams &p, hipStream_t s) {

@@ -61,7 +61,6 @@ struct IcpState {
     int32_t pad;
     double sums[kNumSums];          // last reduced GN sums (diagnostics / multi-GPU exchange)
     unsigned long long sum_candidates;  // sum over launches and queries of C_q (roofline bytes)
-    uint32_t ngroups[8];            // lengths of the 8 per-XCD group lists of this iteration
     uint32_t n_corr[kHistory];      // accepted correspondences per iteration (all ranks)
 };
 
