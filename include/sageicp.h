@@ -66,7 +66,7 @@ typedef struct sageicp_stats {
 int sageicp_abi_version(void);
 const char *sageicp_last_error(void);
 int sageicp_device_count(void);               /* number of visible HIP devices (0: none) */
-void sageicp_set_profiling(int enabled);      /* per-kernel HIP-event timing in stats */
+void sageicp_set_profiling(int level);        /* 0 off; 1 HIP events around k_nn; 2 around every kernel */
 
 /* ---- map: sage_icp::VoxelHashMap (core/VoxelHashMap.hpp:35-107) ------------------------ */
 /* ctor, VoxelHashMap.hpp:79-88.  device: HIP device ordinal that will hold the mirror. */

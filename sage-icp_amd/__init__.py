@@ -133,8 +133,9 @@ def device_count():
     return int(lib().sageicp_device_count())
 
 
-def set_profiling(on):
-    lib().sageicp_set_profiling(1 if on else 0)
+def set_profiling(level):
+    """0 off; 1 (or True) HIP events around k_nn only; 2 around every kernel of the loop"""
+    lib().sageicp_set_profiling(int(level))
 
 
 class Frame:

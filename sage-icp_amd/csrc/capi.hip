@@ -44,7 +44,7 @@ static int env_int(const char *name, int dflt) {
 }
 static int group_cap() {
     static int c = [] {
-        int v = env_int("SAGEICP_GROUP_MAX", 8);   // measured best on c2 (sweep in profiles/)
+        int v = env_int("SAGEICP_GROUP_MAX", 4);   // measured best on c2 (profiles/sweep2.sh)
         int p = 1;
         while (p * 2 <= v && p < 32) p *= 2;
         return p;
@@ -85,8 +85,7 @@ struct Scratch {
     // per-iteration work buffers: transformed queries and the group list (k_group)
     Point4 *d_src = nullptr; int4 *d_groups = nullptr; uint2 *d_blks = nullptr;
     double *d_partials = nullptr;
-    unsigned long long *d_cand = nullptr;      // per-wave candidate counters of k_nn
-    unsigned long long *h_cand = nullptr;      // pinned
+    unsigned long long *d_cand = nullptr;      // per-chunk candidate counters of k_nn [sort_cap]
     IcpState *d_state = nullptr;
     IcpState *h_state = nullptr;   // pinned
     std::vector<hipEvent_t> events;  // 5 per iteration of a chunk
@@ -102,8 +101,7 @@ struct Scratch {
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIPCHK(hipMalloc(&d_partials, sizeof(double) * kMaxGnBlocks * kNumSums));
         HIPCHK(hipMalloc(&d_state, sizeof(IcpState)));
-        HIPCHK(hipMalloc(&d_cand, sizeof(unsigned long long) * kNnMaxWaves));
-        HIPCHK(hipHostMalloc(&h_cand, sizeof(unsigned long long) * kNnMaxWaves, hipHostMallocDefault));
+
         HIPCHK(hipHostMalloc(&h_state, sizeof(IcpState), hipHostMallocDefault));
         return SAGEICP_OK;
     }
@@ -151,6 +149,9 @@ struct Scratch {
         HIPCHK(hipMalloc(&d_src, cap * sizeof(Point4)));
         HIPCHK(hipMalloc(&d_groups, cap * sizeof(int4)));
         HIPCHK(hipMalloc(&d_blks, cap * 32 * sizeof(uint2)));
+        if (d_cand) HIPCHK(hipFree(d_cand));
+        d_cand = nullptr;
+        HIPCHK(hipMalloc(&d_cand, cap * sizeof(unsigned long long)));
         HIPCHK(hipMalloc(&d_keys, 2 * cap * sizeof(uint32_t)));
         HIPCHK(hipMalloc(&d_vals, 2 * cap * sizeof(uint32_t)));
         sort_temp_bytes_ = sort_temp_bytes(static_cast<int>(cap));
@@ -183,7 +184,6 @@ struct Scratch {
         if (d_partials) (void)hipFree(d_partials);
         if (d_state) (void)hipFree(d_state);
         if (d_cand) (void)hipFree(d_cand);
-        if (h_cand) (void)hipHostFree(h_cand);
         if (h_state) (void)hipHostFree(h_state);
         (void)hipStreamDestroy(stream);
         *this = Scratch();
@@ -334,6 +334,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     int rc = sc.reserve_nn(n);
     if (rc) return rc;
     const bool prof = g_profiling != 0;
+    const bool prof2 = g_profiling >= 2;
     if (prof && (rc = sc.reserve_events())) return rc;
 
     fill_state(sc.h_state, init);
@@ -355,7 +356,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     NnParams np{sc.d_src, static_cast<int>(n), sc.d_state, 1, sc.d_groups,
                 static_cast<unsigned>(group_cap()), sc.d_blks, m->d_pts, m->host.cap,
                 nn_cand_stride(m->host.cap), sem_th, sc.d_nn, sc.d_cand};
-    HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * kNnMaxWaves, s));
+    HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * (n + 1), s));
     GnParams gp{sc.d_src, nullptr, static_cast<int>(n), sc.d_state, 1, m->d_pts, sc.d_nn, kernel,
                 max_dist, sc.d_partials};
     const int gn_blocks = gn_grid_for(static_cast<int>(n));
@@ -367,14 +368,16 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     for (;;) {
         const int todo = std::min(chunk, kMaxIterations - launched);
         for (int k = 0; k < todo; ++k) {
-            if (prof) HIPCHK(hipEventRecord(sc.events[5 * k + 0], s));
+            // profiling level 1: events around k_nn only (the roofline kernel; each record costs
+            // ~1 us of stream time); level 2: around every kernel
+            if (prof2) HIPCHK(hipEventRecord(sc.events[5 * k + 0], s));
             launch_group(grp, true, s);
             launch_probe(pp, static_cast<int>(n), s);
             if (prof) HIPCHK(hipEventRecord(sc.events[5 * k + 1], s));
             launch_nn(np, s);
             if (prof) HIPCHK(hipEventRecord(sc.events[5 * k + 2], s));
             launch_gn(gp, s);
-            if (prof) HIPCHK(hipEventRecord(sc.events[5 * k + 3], s));
+            if (prof2) HIPCHK(hipEventRecord(sc.events[5 * k + 3], s));
             if (comm) {
                 launch_fin(sc.d_state, sc.d_partials, gn_blocks, 1, 0, s);
                 ncclResult_t r = g_rccl.AllReduce(sc.d_state->sums, sc.d_state->sums, kNumSums,
@@ -386,7 +389,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
             } else {
                 launch_fin(sc.d_state, sc.d_partials, gn_blocks, 0, 0, s);
             }
-            if (prof) HIPCHK(hipEventRecord(sc.events[5 * k + 4], s));
+            if (prof2) HIPCHK(hipEventRecord(sc.events[5 * k + 4], s));
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(sc.h_state, sc.d_state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
@@ -396,10 +399,12 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
             const int executed = std::min(todo, iters - launched);   // the rest were no-ops
             for (int k = 0; k < executed; ++k) {
                 float g = 0, a = 0, b = 0, c = 0;
-                (void)hipEventElapsedTime(&g, sc.events[5 * k + 0], sc.events[5 * k + 1]);
                 (void)hipEventElapsedTime(&a, sc.events[5 * k + 1], sc.events[5 * k + 2]);
-                (void)hipEventElapsedTime(&b, sc.events[5 * k + 2], sc.events[5 * k + 3]);
-                (void)hipEventElapsedTime(&c, sc.events[5 * k + 3], sc.events[5 * k + 4]);
+                if (prof2) {
+                    (void)hipEventElapsedTime(&g, sc.events[5 * k + 0], sc.events[5 * k + 1]);
+                    (void)hipEventElapsedTime(&b, sc.events[5 * k + 2], sc.events[5 * k + 3]);
+                    (void)hipEventElapsedTime(&c, sc.events[5 * k + 3], sc.events[5 * k + 4]);
+                }
                 us_group += 1e3 * g; us_nn += 1e3 * a; us_gn += 1e3 * b; us_fin += 1e3 * c;
                 ++nn_launches;
             }
@@ -412,10 +417,11 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     for (int i = 0; i < 7; ++i) out[i] = st.T[i];
     unsigned long long sum_candidates = 0;
     if (stats) {
-        HIPCHK(hipMemcpyAsync(sc.h_cand, sc.d_cand, sizeof(unsigned long long) * kNnMaxWaves,
+        std::vector<unsigned long long> hc(n + 1);
+        HIPCHK(hipMemcpyAsync(hc.data(), sc.d_cand, sizeof(unsigned long long) * (n + 1),
                               hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        for (int i = 0; i < kNnMaxWaves; ++i) sum_candidates += sc.h_cand[i];
+        for (unsigned long long v : hc) sum_candidates += v;
     }
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
@@ -448,7 +454,7 @@ int sageicp_device_count(void) {
     if (hipGetDeviceCount(&c) != hipSuccess) return 0;
     return c;
 }
-void sageicp_set_profiling(int enabled) { g_profiling = enabled; }
+void sageicp_set_profiling(int level) { g_profiling = level; }
 
 // ---- map ----------------------------------------------------------------------------------
 sageicp_map *sageicp_map_create(double voxel_size, double max_distance, int basic, int critical,

@@ -43,7 +43,7 @@ struct NnParams {
     double sem_th;
     int32_t *nn_idx;          // out: block*cap+slot of the semantic nearest neighbour, -1 if the
                               //      27-voxel neighbourhood is empty (acceptance is applied later)
-    unsigned long long *cand_counter;  // optional: [kNnMaxWaves] per-wave running sums of C_q
+    unsigned long long *cand_counter;  // optional: [>= n] per-chunk running sums of C_q
 };
 
 struct GnParams {
@@ -60,7 +60,6 @@ struct GnParams {
 };
 
 constexpr int kMaxGnBlocks = 512;
-constexpr int kNnMaxWaves = 2048 * 4;   // k_nn grid is at most 2048 workgroups of 4 waves
 constexpr uint64_t kMaxQueries = (1ull << 26) - 1;   // group record packs start into 26 bits
 
 void launch_group(const GroupParams &p, bool apply_pose, hipStream_t s);

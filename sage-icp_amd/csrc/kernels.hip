@@ -33,6 +33,10 @@
 
 #include <cfloat>
 
+#ifndef SAGE_NN_WAVES
+#define SAGE_NN_WAVES 1
+#endif
+
 #include "kernels.h"
 #include "se3_math.h"
 #include "sageicp_types.h"
@@ -177,12 +181,11 @@ __device__ __forceinline__ void argmin_merge(double &b, unsigned &k, double ob, 
 // SIMDs — out of the critical path.
 template <int LW>
 __device__ __forceinline__ void nn_group(const NnParams &P, const uint32_t *cand, int lane,
-                                         int start, int len, unsigned C) {
+                                         int start, int len, unsigned C, const Point4 &p) {
     constexpr int W = 1 << LW;
     const int qi = lane >> LW;                  // query of this lane within the group
     const unsigned ci = lane & (W - 1);
     const bool active = qi < len;
-    const Point4 p = P.src[start + min(qi, len - 1)];
     const int pli = static_cast<int>(p.l);
     const double th = P.sem_th;
 
@@ -248,7 +251,9 @@ __device__ unsigned long long g_nn_phase[8];
 #define NN_T(i) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(256, 8) void k_nn(NnParams P) {
+constexpr int kNnWaves = SAGE_NN_WAVES;     // waves per k_nn workgroup
+
+__global__ __launch_bounds__(64 * kNnWaves, 8) void k_nn(NnParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     if (P.check_done && P.st->done) return;
 #ifdef SAGE_NN_TIMING
@@ -260,44 +265,64 @@ __global__ __launch_bounds__(256, 8) void k_nn(NnParams P) {
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     uint32_t *cand = smem + wv * P.cand_stride;      // this wave's candidate list (absolute indices)
-    uint2 *tab = reinterpret_cast<uint2 *>(smem + 4u * P.cand_stride) + wv * 32;   // {offset, base} x 32
+    uint2 *tab = reinterpret_cast<uint2 *>(smem + kNnWaves * P.cand_stride) + wv * 32;   // {offset, base} x 32
 
-    // Workgroup b is dispatched to XCD b % 8 (observed; speed only): it serves the b % 8-th
-    // contiguous eighth of the sorted frame — one compact region of the map per private L2 — in
-    // chunks of `chunk` consecutive queries (a group never crosses a chunk), so every wave gets
-    // the same number of queries.  Static striding: device-scope ticket counters were measured
-    // 20x slower here (cross-XCD atomics on a handful of addresses).
+    // One wave per chunk of `chunk` consecutive queries (a group never crosses a chunk), four
+    // chunks per workgroup, and many more workgroups than the chip holds at once: the hardware
+    // dispatcher hands the next workgroup to whichever CU frees a slot, which balances the
+    // load.  (Work per query varies 5x across the scene; persistent waves with a static share
+    // of the queries left the kernel waiting on its heaviest wave — 2.5x the mean — and
+    // device-scope ticket counters were 20x slower.)  Workgroup b is dispatched to XCD b % 8
+    // (observed; speed only): XCD x serves the stripes x, x+8, x+16, ... of kStripe consecutive
+    // workgroups' worth of the spatially sorted frame, so each private L2 sees a few compact
+    // regions of the map and every XCD gets the same mix of dense and sparse regions.
     unsigned long long wave_candidates = 0;   // wave-uniform: sum over this wave's queries of C_q
+    constexpr unsigned kStripe = 64 / kNnWaves;   // workgroups per stripe (64 chunks)
+    unsigned cand_slot = 0;
     {
       const unsigned chunk = P.chunk;
       const unsigned nchunks = (static_cast<unsigned>(P.n) + chunk - 1u) / chunk;
-      const unsigned xcd = blockIdx.x & 7u;
-      const unsigned c_lo = static_cast<unsigned>((static_cast<unsigned long long>(xcd) * nchunks) >> 3);
-      const unsigned c_hi = static_cast<unsigned>((static_cast<unsigned long long>(xcd + 1u) * nchunks) >> 3);
-      const unsigned waves_per_xcd = (gridDim.x >> 3) * 4u;
+      const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+      const unsigned quad = ((j / kStripe) * 8u + xcd) * kStripe + (j % kStripe);
+      const unsigned c_hi = nchunks;
+      const unsigned waves_per_xcd = 0xFFFFFFFFu;      // one chunk per wave
       const int4 *groups = P.groups;
       const uint2 *blks = P.blks;
-      for (unsigned c = c_lo + __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * 4u + wv); c < c_hi;
-           c += waves_per_xcd) {
+      // Every wave walks a dependent chain of memory round trips (chunk heads -> probe table ->
+      // query -> candidates); the loads that do not depend on the current group — the next
+      // chunk's heads, the next group's probe table, this group's query — are issued one step
+      // ahead so they overlap the LDS enumeration and the pair loop.
+      auto load_heads = [&](unsigned c) -> int {
+          const unsigned q0 = c * chunk;
+          int v = -1;
+          if (c < c_hi && static_cast<unsigned>(lane) < chunk && q0 + lane < static_cast<unsigned>(P.n))
+              v = groups[q0 + lane].x;
+          return v;
+      };
+      auto load_table = [&](unsigned g) -> uint2 {
+          uint2 ob;
+          ob.x = 0xFFFFFFFFu; ob.y = 0u;
+          if (lane < 32) ob = blks[g * 32u + lane];
+          return ob;
+      };
+      unsigned c = __builtin_amdgcn_readfirstlane(quad * kNnWaves + wv);
+      cand_slot = c;
+      int sl = load_heads(c);
+      if (c < c_hi) {
         const unsigned q0 = c * chunk;
-        int sl = -1;
-        if (static_cast<unsigned>(lane) < chunk && q0 + lane < static_cast<unsigned>(P.n))
-            sl = groups[q0 + lane].x;
         unsigned long long heads = __ballot(sl != -1);
+        uint2 ob = load_table(q0 + (heads ? __builtin_ctzll(heads) : 0));
         while (heads) {
         const int h = __builtin_ctzll(heads);
         heads &= heads - 1;
-        const unsigned g = q0 + h;                  // slot of this group == its head query
-        // group record and the 32-entry {offset, base} table of k_probe: independent loads
+        const uint2 ob_next = load_table(q0 + (heads ? __builtin_ctzll(heads) : h));   // prefetch
         const int startlen = __builtin_amdgcn_readlane(sl, h);
-        uint2 ob;
-        ob.x = 0xFFFFFFFFu; ob.y = 0u;
-        if (lane < 32) ob = blks[g * 32u + lane];
         const int start = startlen & 0x03FFFFFF;
         const int len = static_cast<unsigned>(startlen) >> 26;
-#ifdef SAGE_NN_TIMING
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+        // (query x candidate) pairs over the lanes: W = 64 / pow2ceil(len) lanes per query
+        const int lgq = (len <= 1) ? 0 : (32 - __builtin_clz(static_cast<unsigned>(len - 1)));
+        const int lw = 6 - lgq;
+        const Point4 p = P.src[start + min(lane >> lw, len - 1)];   // this lane's query, early
         NN_T(0);
 
         // Enumerate the candidates once, in reference order (x outer, y, z inner, then insertion
@@ -319,27 +344,21 @@ __global__ __launch_bounds__(256, 8) void k_nn(NnParams P) {
             cand[f] = base + (f - o);
         }
         wave_candidates += static_cast<unsigned long long>(C) * static_cast<unsigned>(len);
-#ifdef SAGE_NN_TIMING
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
         NN_T(1);
 
-        // (query x candidate) pairs over the lanes: W = 64 / pow2ceil(len) lanes per query
-        const int lgq = (len <= 1) ? 0 : (32 - __builtin_clz(static_cast<unsigned>(len - 1)));
-        switch (6 - lgq) {
-            case 6: nn_group<6>(P, cand, lane, start, len, C); break;
-            case 5: nn_group<5>(P, cand, lane, start, len, C); break;
-            case 4: nn_group<4>(P, cand, lane, start, len, C); break;
-            case 3: nn_group<3>(P, cand, lane, start, len, C); break;
-            case 2: nn_group<2>(P, cand, lane, start, len, C); break;
-            default: nn_group<1>(P, cand, lane, start, len, C); break;
+        switch (lw) {
+            case 6: nn_group<6>(P, cand, lane, start, len, C, p); break;
+            case 5: nn_group<5>(P, cand, lane, start, len, C, p); break;
+            case 4: nn_group<4>(P, cand, lane, start, len, C, p); break;
+            case 3: nn_group<3>(P, cand, lane, start, len, C, p); break;
+            case 2: nn_group<2>(P, cand, lane, start, len, C, p); break;
+            default: nn_group<1>(P, cand, lane, start, len, C, p); break;
         }
-#ifdef SAGE_NN_TIMING
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
         NN_T(2);
+        ob = ob_next;
         }
       }
+      (void)waves_per_xcd;
     }
 #ifdef SAGE_NN_TIMING
     if (lane == 0) {
@@ -349,11 +368,10 @@ __global__ __launch_bounds__(256, 8) void k_nn(NnParams P) {
         atomicMax(&g_nn_phase[5], __builtin_amdgcn_s_memtime() - tstart);
     }
 #endif
-    // sum_q C_q for the roofline accounting: one private slot per wave, summed by the host.  (A
+    // sum_q C_q for the roofline accounting: one private slot per chunk, summed by the host.  (A
     // single device-scope atomic per wave serialised 8192 updates on one address and set a
     // ~100 us floor under this kernel.)
-    if (P.cand_counter && lane == 0 && wave_candidates)
-        P.cand_counter[blockIdx.x * 4u + wv] += wave_candidates;
+    if (P.cand_counter && lane == 0 && wave_candidates) P.cand_counter[cand_slot] += wave_candidates;
 }
 
 // ------------------------------------------------------------------------------------ k_gn
@@ -524,14 +542,13 @@ extern "C" void sageicp_debug_nn_phases(unsigned long long out[8], int reset) {
 #endif
 
 // ------------------------------------------------------------------------------------ launchers
-int nn_grid_for(int n) {
-    // persistent waves striding over the groups; 2048 workgroups x 4 waves = every wave slot of
-    // the chip (256 CUs x 32 waves).  There are at least n/32 groups and at most n.  A multiple
-    // of 8 so that every XCD list gets the same number of waves.
-    long blocks = (static_cast<long>(n) + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
-    blocks = ((blocks + 7) / 8) * 8;
-    return static_cast<int>(blocks);
+int nn_grid_for(int n, int chunk) {
+    // one wave per chunk, 4 waves per workgroup, rounded up to whole stripes on all 8 XCDs
+    const long nchunks = (static_cast<long>(n) + chunk - 1) / chunk;
+    const long quads = (nchunks + kNnWaves - 1) / kNnWaves;
+    const long per_round = 8L * (64 / kNnWaves);   // 8 XCDs x kStripe
+    const long blocks = ((quads + per_round - 1) / per_round) * per_round;
+    return static_cast<int>(blocks < per_round ? per_round : blocks);
 }
 
 int gn_grid_for(int n) {
@@ -562,9 +579,9 @@ void launch_probe(const ProbeParams &p, int n, hipStream_t s) {
 
 void launch_nn(const NnParams &p, hipStream_t s) {
     if (p.n <= 0) return;
-    const int grid = nn_grid_for(p.n);
-    const size_t lds = 4u * p.cand_stride * sizeof(uint32_t) + 4u * 32u * sizeof(uint2);
-    hipLaunchKernelGGL(k_nn, dim3(grid), dim3(256), lds, s, p);
+    const int grid = nn_grid_for(p.n, static_cast<int>(p.chunk));
+    const size_t lds = kNnWaves * (p.cand_stride * sizeof(uint32_t) + 32u * sizeof(uint2));
+    hipLaunchKernelGGL(k_nn, dim3(grid), dim3(64 * kNnWaves), lds, s, p);
 }
 
 int launch_gn(const GnParams &p, hipStream_t s) {

@@ -145,6 +145,44 @@ def test_dense_queries_share_voxels(gpu_sage, oracle, n_q, box):
     assert np.array_equal(idx, oidx) and np.array_equal(tgt, otgt)
 
 
+def test_near_ties_and_exotic_labels_stay_exact(gpu_sage, oracle):
+    """adversarial input for k_nn's f32 filter: clusters of candidates whose distances differ by
+    far less than f32 resolution (many finalists / exact fallback), exact duplicates (index
+    tie-break), far-from-origin coordinates, fractional and huge labels (generic-label path)"""
+    rng = np.random.default_rng(15)
+    centre = np.array([4321.0, -2750.0, 12.0])
+    mp = rng.uniform(-4, 4, size=(6000, 4))
+    mp[:, :3] += centre
+    mp[:, 3] = rng.choice([0, 40, 50, 70], size=len(mp))
+    # shells of points at almost identical distance around 40 probe positions
+    probes = rng.uniform(-3, 3, size=(40, 3)) + centre
+    extra = []
+    for c in probes:
+        dirs = rng.normal(size=(12, 3))
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        r = 0.3 + rng.uniform(-1e-9, 1e-9, size=12)
+        pts = c + dirs * r[:, None]
+        extra.append(np.c_[pts, rng.choice([0, 40, 50], size=12)])
+        extra.append(np.c_[pts[:3], [40, 40, 40]])                 # exact duplicates
+    mp = np.vstack([mp] + extra)
+    q = np.c_[probes, rng.choice([0, 40, 50], size=len(probes))]
+    q = np.vstack([q, np.c_[rng.uniform(-4, 4, size=(3000, 3)) + centre,
+                            rng.choice([0, 40, 50, 70], size=3000)]])
+    for labels in ("int", "exotic"):
+        m2, q2 = mp.copy(), q.copy()
+        if labels == "exotic":
+            m2[::7, 3] = 40.5
+            m2[::11, 3] = 3.0e9
+            q2[::5, 3] = 0.25
+            q2[::13, 3] = -7.0
+        a, b = both_maps(gpu_sage, oracle, m2, vs=1.0)
+        for th in (0.4, 1.0, 2.5):
+            _, tgt, idx = a.GetCorrespondences(q2, 3.0, th, with_index=True)
+            _, otgt, oidx = b.get_correspondences(q2, 3.0, th, with_index=True)
+            assert len(oidx) > 2000
+            assert np.array_equal(idx, oidx) and np.array_equal(tgt, otgt), (labels, th)
+
+
 def test_mirror_refresh_after_updates(gpu_sage, oracle):
     """dirty-block / table refresh: search between successive map mutations stays exact"""
     rng = np.random.default_rng(13)
@@ -301,12 +339,12 @@ def test_register_frame_through_rccl_comm_world1(gpu_sage, oracle):
 
 def test_profiling_stats(gpu_sage, oracle):
     w, om = _workload(gpu_sage, oracle, "c2", 0.05)
-    gpu_sage.set_profiling(True)
+    gpu_sage.set_profiling(2)
     try:
         _, st = gpu_sage.register_frame(w["scan"], w["map"], gpu_sage.IDENTITY, 6.0, 2 / 3, 0.4,
                                         return_stats=True)
     finally:
-        gpu_sage.set_profiling(False)
+        gpu_sage.set_profiling(0)
     assert st.nn_launches == st.iterations and st.us_nn > 0 and st.us_gn > 0 and st.us_fin > 0
 
 
