@@ -48,6 +48,11 @@ def parse():
 
 def main():
     args = parse()
+    # RCCL prints a version banner on stdout when a communicator is created; the contract is ONE
+    # JSON line on stdout, so everything before the final print goes to stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -64,7 +69,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # SAGEICP_FORCE_COMM=1 runs the multi-GPU code path (process group, RCCL communicator, in-stream
+    # all-reduce) even with one rank, so it can be exercised on a 1-GPU box under torchrun.
+    force_comm = os.environ.get("SAGEICP_FORCE_COMM", "0") == "1" and "RANK" in os.environ
+    use_dist = world > 1 or force_comm
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", world_size=world, rank=rank,
                                 device_id=torch.device("cuda", local_rank))
@@ -89,7 +98,7 @@ def main():
     t_gen = time.time() - t_gen
 
     comm = None
-    if world > 1:
+    if use_dist:
         ids = [sage.Comm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         comm = sage.Comm(ids[0], rank, world, local_rank)
@@ -99,7 +108,7 @@ def main():
                                    prm["sem_th"], comm=comm, return_stats=True)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -117,13 +126,13 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     sage.set_profiling(0)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -140,7 +149,7 @@ def main():
         achieved = bytes_nn / (us_nn * 1e-6) / 1e9                # GB/s
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "nn_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.workload == "c2" and world == 1 and args.scale == 1.0:
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
@@ -210,7 +219,7 @@ def main():
                                % (args.workload, args.params, len(scan), vmap.size(), wl["voxel"],
                                   prm["max_dist"], prm["kernel"], prm["sem_th"]),
                    "parallelism": "query-sharded x%d, map replicated, RCCL all-reduce of 17 fp64 sums"
-                                  % world if world > 1 else "single GPU",
+                                  % world if use_dist else "single GPU",
                    "scan_points": len(scan), "map_points": vmap.size(),
                    "map_voxels": vmap.num_voxels(), "iterations_per_frame": iters,
                    "correspondences_first_last": [stats[-1][6], stats[-1][7]],
@@ -219,8 +228,10 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
