@@ -137,6 +137,40 @@ sageicp_comm *sageicp_comm_create(const uint8_t id[SAGEICP_UNIQUE_ID_BYTES], int
                                   int device);
 void sageicp_comm_destroy(sageicp_comm *comm);
 
+/* ---- per-frame pipeline counterpart: sage_icp::pipeline::sageICP (pipeline/sageICP.{hpp,cpp}) --
+ * Host-side orchestration around the hot path for a stream of scans:
+ * range crop + label zeroing (core/Preprocessing.cpp:173-187), two-level semantic voxel
+ * down-sampling (core/Preprocessing.cpp:44-84, pipeline/sageICP.cpp:97-101), adaptive threshold
+ * (core/Threshold.cpp:29-50), constant-velocity guess (pipeline/sageICP.cpp:110-115), RegisterFrame,
+ * map update.  The reference's own pipeline compiles unchanged against the header shims; this
+ * entry exists so that streams can be driven through the C ABI (tests, bench).  The PCL dynamic
+ * vehicle filter and deskewing are not reproduced (both off in the pre-labelled configurations). */
+typedef struct sageicp_pipeline sageicp_pipeline;
+typedef struct sageicp_pipeline_config {   /* sageConfig, pipeline/sageICP.hpp:39-65 */
+    double voxel_size_map, max_range, min_range, label_max_range, local_map_range;
+    int basic_points_per_voxel, critical_points_per_voxel;
+    const int *basic_parts_labels;
+    int n_basic_parts_labels;
+    double min_motion_th, initial_threshold, sem_th;
+    int n_groups;                     /* voxel_labels.size() == voxel_size.size() */
+    const int *group_label_counts;    /* [n_groups] */
+    const int *group_labels;          /* concatenated label lists of the groups */
+    const double *group_voxel_size;   /* [n_groups] */
+    int device;
+} sageicp_pipeline_config;
+
+sageicp_pipeline *sageicp_pipeline_create(const sageicp_pipeline_config *config);
+void sageicp_pipeline_destroy(sageicp_pipeline *p);
+/* sageICP::RegisterFrame(frame), pipeline/sageICP.cpp:54-95.  icp_seconds is the span the
+ * reference times around the hot path (:79-88); n_source the size of the registered cloud. */
+int sageicp_pipeline_register_frame(sageicp_pipeline *p, const double *frame_xyzl, uint64_t n,
+                                    double pose_out[7], double *icp_seconds, double *total_seconds,
+                                    uint64_t *n_source, sageicp_stats *stats /* optional */);
+int sageicp_pipeline_reinitialize(sageicp_pipeline *p);          /* pipeline/sageICP.hpp:94-99 */
+uint64_t sageicp_pipeline_num_poses(const sageicp_pipeline *p);  /* poses().size() */
+int sageicp_pipeline_pose(const sageicp_pipeline *p, uint64_t index, double pose_out[7]);
+const sageicp_map *sageicp_pipeline_local_map(const sageicp_pipeline *p);   /* LocalMap() */
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,6 +80,15 @@ def lib():
                            ("sgo_se3_mul", 2), ("sgo_se3_apply", 2), ("sgo_ldlt_solve6", 2)):
             getattr(L, name).argtypes = [_dp] * (n_in + 1)
         L.sgo_num_threads.restype = C.c_int
+        L.sgo_pipeline_create.restype = C.c_void_p
+        L.sgo_pipeline_create.argtypes = [C.c_void_p]
+        L.sgo_pipeline_destroy.argtypes = [C.c_void_p]
+        L.sgo_pipeline_local_map.restype = C.c_void_p
+        L.sgo_pipeline_local_map.argtypes = [C.c_void_p]
+        L.sgo_pipeline_num_poses.restype = C.c_uint64
+        L.sgo_pipeline_num_poses.argtypes = [C.c_void_p]
+        L.sgo_pipeline_register_frame.argtypes = [C.c_void_p, _dp, C.c_uint64, _dp, _u64p, _dp,
+                                                  C.POINTER(Stats), C.c_int]
         _lib = L
     return _lib
 
@@ -231,3 +240,36 @@ class Map:
 
 def num_threads():
     return int(lib().sgo_num_threads())
+
+
+class Pipeline:
+    """Oracle restatement of sage_icp::pipeline::sageICP (pipeline/sageICP.cpp:54-121).  `config`
+    is a ctypes struct laid out like sgo_pipeline_config (== sageicp_pipeline_config)."""
+
+    def __init__(self, config):
+        self.config = config
+        self._h = lib().sgo_pipeline_create(C.addressof(config))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().sgo_pipeline_destroy(self._h)
+            self._h = None
+
+    def register_frame(self, frame, nthreads=0):
+        """returns (pose[7], n_source, sigma, stats)"""
+        frame, fp = _d(frame)
+        out = np.empty(7)
+        ns = C.c_uint64(0)
+        sg = C.c_double(0)
+        st = Stats()
+        lib().sgo_pipeline_register_frame(self._h, fp, frame.reshape(-1, 4).shape[0],
+                                          out.ctypes.data_as(_dp), C.byref(ns), C.byref(sg),
+                                          C.byref(st), nthreads)
+        return out, ns.value, sg.value, st
+
+    def local_map(self):
+        h = lib().sgo_pipeline_local_map(self._h)
+        n = int(lib().sgo_map_size(h))
+        out = np.empty((n, 4))
+        lib().sgo_map_pointcloud(h, out.ctypes.data_as(_dp), n)
+        return out

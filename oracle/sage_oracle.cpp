@@ -670,4 +670,147 @@ int sgo_register_frame(const void *h, const double *frame, uint64_t n, const dou
 
 int sgo_num_threads(void) { return resolve_threads(0); }
 
+// ---- per-frame pipeline -------------------------------------------
+// Restates pipeline/sageICP.cpp:54-121, core/Threshold.cpp:29-50, core/Preprocessing.cpp:44-84
+// and :173-187 (dynamic_vehicle_filter == false; deskew off).  The down-sampled clouds are
+// emitted in insertion order per label group (the reference: tsl::robin_map bucket order, D3).
+struct sgo_pipeline_config {
+    double voxel_size_map, max_range, min_range, label_max_range, local_map_range;
+    int basic_points_per_voxel, critical_points_per_voxel;
+    const int *basic_parts_labels;
+    int n_basic_parts_labels;
+    double min_motion_th, initial_threshold, sem_th;
+    int n_groups;
+    const int *group_label_counts;
+    const int *group_labels;
+    const double *group_voxel_size;
+    int device;   // unused by the oracle (layout-compatible with sageicp_pipeline_config)
+};
+
+struct OraclePipeline {
+    sgo_pipeline_config cfg;
+    std::vector<std::vector<int>> groups;
+    std::vector<double> group_voxel;
+    void *map = nullptr;
+    std::vector<std::array<double, 7>> poses;
+    double sse2 = 0.0;
+    int num_samples = 0;
+    std::array<double, 7> model_deviation{{0, 0, 0, 1, 0, 0, 0}};
+};
+
+static void oracle_voxel_downsample(const OraclePipeline &P, const std::vector<double> &in,
+                                    double scale, std::vector<double> &out) {
+    const size_t G = P.groups.size();
+    std::vector<std::unordered_map<Voxel, char, VoxelHash>> grid(G);
+    std::vector<std::vector<double>> kept(G);
+    for (size_t i = 0; i < in.size() / 4; ++i) {
+        const double *p = &in[4 * i];
+        const int label = static_cast<int>(p[3]);
+        int group = -1;
+        for (size_t g = 0; g < G; ++g)
+            if (std::find(P.groups[g].begin(), P.groups[g].end(), label) != P.groups[g].end()) {
+                group = static_cast<int>(g);
+                break;
+            }
+        if (group == -1) continue;
+        const double vs = P.group_voxel[group] * scale;
+        const Voxel v{static_cast<int>(p[0] / vs), static_cast<int>(p[1] / vs),
+                      static_cast<int>(p[2] / vs)};
+        if (grid[group].count(v)) continue;
+        grid[group].emplace(v, 0);
+        kept[group].insert(kept[group].end(), p, p + 4);
+    }
+    out.clear();
+    for (size_t g = 0; g < G; ++g) out.insert(out.end(), kept[g].begin(), kept[g].end());
+}
+
+void *sgo_pipeline_create(const sgo_pipeline_config *c) {
+    OraclePipeline *P = new OraclePipeline;
+    P->cfg = *c;
+    const int *gl = c->group_labels;
+    for (int g = 0; g < c->n_groups; ++g) {
+        P->groups.emplace_back(gl, gl + c->group_label_counts[g]);
+        gl += c->group_label_counts[g];
+        P->group_voxel.push_back(c->group_voxel_size[g]);
+    }
+    P->map = sgo_map_create(c->voxel_size_map, c->local_map_range, c->basic_points_per_voxel,
+                            c->critical_points_per_voxel, c->basic_parts_labels,
+                            c->n_basic_parts_labels);
+    return P;
+}
+void sgo_pipeline_destroy(void *h) {
+    OraclePipeline *P = static_cast<OraclePipeline *>(h);
+    sgo_map_destroy(P->map);
+    delete P;
+}
+const void *sgo_pipeline_local_map(const void *h) { return static_cast<const OraclePipeline *>(h)->map; }
+uint64_t sgo_pipeline_num_poses(const void *h) { return static_cast<const OraclePipeline *>(h)->poses.size(); }
+
+int sgo_pipeline_register_frame(void *h, const double *frame, uint64_t n, double pose_out[7],
+                                uint64_t *n_source, double *sigma_out, sgo_stats *st, int nthreads) {
+    OraclePipeline &P = *static_cast<OraclePipeline *>(h);
+    const sgo_pipeline_config &c = P.cfg;
+    // Preprocess (Preprocessing.cpp:173-187)
+    std::vector<double> cropped;
+    for (uint64_t i = 0; i < n; ++i) {
+        const double *p = frame + 4 * i;
+        const double norm = std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+        if (norm < c.max_range && norm > c.min_range) {
+            const double l = (norm > c.label_max_range) ? 0.0 : p[3];
+            cropped.insert(cropped.end(), {p[0], p[1], p[2], l});
+        }
+    }
+    // Voxelize (sageICP.cpp:97-101)
+    std::vector<double> frame_downsample, source;
+    oracle_voxel_downsample(P, cropped, 0.5, frame_downsample);
+    oracle_voxel_downsample(P, frame_downsample, 1.5, source);
+    // GetAdaptiveThreshold (sageICP.cpp:103-108,117-121; Threshold.cpp:29-50)
+    double sigma = c.initial_threshold;
+    bool moved = false;
+    if (!P.poses.empty()) {
+        double inv[7], d[7];
+        se3_inv(P.poses.front().data(), inv);
+        se3_mul(inv, P.poses.back().data(), d);
+        moved = std::sqrt(d[4] * d[4] + d[5] * d[5] + d[6] * d[6]) > 5.0 * c.min_motion_th;
+    }
+    if (moved) {
+        const double *q = P.model_deviation.data();
+        const double theta = 2.0 * std::atan2(std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]),
+                                              std::abs(q[3]));
+        const double model_error = std::sqrt(q[4] * q[4] + q[5] * q[5] + q[6] * q[6]) +
+                                   2.0 * c.max_range * std::sin(theta / 2.0);
+        if (model_error > c.min_motion_th) {
+            P.sse2 += model_error * model_error;
+            P.num_samples++;
+        }
+        if (P.num_samples >= 1) sigma = std::sqrt(P.sse2 / P.num_samples);
+    }
+    // prediction / initial guess (sageICP.cpp:74-76,110-115)
+    double prediction[7] = {0, 0, 0, 1, 0, 0, 0};
+    const size_t N = P.poses.size();
+    if (N >= 2) {
+        double inv[7];
+        se3_inv(P.poses[N - 2].data(), inv);
+        se3_mul(inv, P.poses[N - 1].data(), prediction);
+    }
+    double last[7] = {0, 0, 0, 1, 0, 0, 0};
+    if (N) std::memcpy(last, P.poses.back().data(), 56);
+    double guess[7];
+    se3_mul(last, prediction, guess);
+    double new_pose[7];
+    sgo_register_frame(P.map, source.data(), source.size() / 4, guess, 3.0 * sigma, sigma / 3.0,
+                       c.sem_th, new_pose, st, nthreads);
+    double ginv[7];
+    se3_inv(guess, ginv);
+    se3_mul(ginv, new_pose, P.model_deviation.data());
+    sgo_map_update_pose(P.map, frame_downsample.data(), frame_downsample.size() / 4, new_pose);
+    std::array<double, 7> np;
+    std::memcpy(np.data(), new_pose, 56);
+    P.poses.push_back(np);
+    std::memcpy(pose_out, new_pose, 56);
+    if (n_source) *n_source = source.size() / 4;
+    if (sigma_out) *sigma_out = sigma;
+    return 0;
+}
+
 }  // extern "C"

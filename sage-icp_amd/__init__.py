@@ -60,6 +60,50 @@ class Stats(C.Structure):
     ]
 
 
+class PipelineConfig(C.Structure):
+    """sageicp_pipeline_config == sageConfig (pipeline/sageICP.hpp:39-65)"""
+    _fields_ = [
+        ("voxel_size_map", C.c_double), ("max_range", C.c_double), ("min_range", C.c_double),
+        ("label_max_range", C.c_double), ("local_map_range", C.c_double),
+        ("basic_points_per_voxel", C.c_int), ("critical_points_per_voxel", C.c_int),
+        ("basic_parts_labels", C.POINTER(C.c_int)), ("n_basic_parts_labels", C.c_int),
+        ("min_motion_th", C.c_double), ("initial_threshold", C.c_double), ("sem_th", C.c_double),
+        ("n_groups", C.c_int),
+        ("group_label_counts", C.POINTER(C.c_int)), ("group_labels", C.POINTER(C.c_int)),
+        ("group_voxel_size", C.POINTER(C.c_double)),
+        ("device", C.c_int),
+    ]
+
+
+# the SemanticKITTI parameter sets of ros/launch/odometry*.launch.py
+KITTI_VOXEL_LABELS = [[40, 44, 48, 49], [50, 51, 52], [70, 72], [60, 71, 80, 81, 99], [0],
+                      [10, 11, 13, 15, 16, 18, 20]]
+KITTI_VOXEL_SIZE = [0.6, 1.0, 0.9, 0.8, 1.0, 0.6]
+
+
+def make_pipeline_config(voxel_size_map=0.8, max_range=100.0, min_range=5.0, label_max_range=50.0,
+                         local_map_range=100.0, basic=20, critical=20,
+                         basic_parts_labels=(40, 44, 48, 49, 50, 70, 72), min_motion_th=0.1,
+                         initial_threshold=2.0, sem_th=0.05, voxel_labels=None, voxel_size=None,
+                         device=0):
+    """defaults: ros/launch/odometry_gt.launch.py (pre-labelled scans, dynamic filter off)"""
+    voxel_labels = KITTI_VOXEL_LABELS if voxel_labels is None else voxel_labels
+    voxel_size = KITTI_VOXEL_SIZE if voxel_size is None else voxel_size
+    assert len(voxel_labels) == len(voxel_size)
+    keep = {}
+    keep["basic"] = (C.c_int * len(basic_parts_labels))(*basic_parts_labels)
+    keep["counts"] = (C.c_int * len(voxel_labels))(*[len(g) for g in voxel_labels])
+    flat = [l for g in voxel_labels for l in g]
+    keep["labels"] = (C.c_int * len(flat))(*flat)
+    keep["sizes"] = (C.c_double * len(voxel_size))(*voxel_size)
+    cfg = PipelineConfig(voxel_size_map, max_range, min_range, label_max_range, local_map_range,
+                         basic, critical, keep["basic"], len(basic_parts_labels), min_motion_th,
+                         initial_threshold, sem_th, len(voxel_labels), keep["counts"],
+                         keep["labels"], keep["sizes"], device)
+    cfg._keep = keep          # the arrays must outlive the struct
+    return cfg
+
+
 # every symbol include/sageicp.h declares: (name, restype, argtypes)
 _SIGNATURES = [
     ("sageicp_abi_version", C.c_int, []),
@@ -95,6 +139,14 @@ _SIGNATURES = [
     ("sageicp_comm_unique_id", C.c_int, [_u8p]),
     ("sageicp_comm_create", C.c_void_p, [_u8p, C.c_int, C.c_int, C.c_int]),
     ("sageicp_comm_destroy", None, [C.c_void_p]),
+    ("sageicp_pipeline_create", C.c_void_p, [C.POINTER(PipelineConfig)]),
+    ("sageicp_pipeline_destroy", None, [C.c_void_p]),
+    ("sageicp_pipeline_register_frame", C.c_int,
+     [C.c_void_p, _dp, C.c_uint64, _dp, _dp, _dp, _u64p, C.POINTER(Stats)]),
+    ("sageicp_pipeline_reinitialize", C.c_int, [C.c_void_p]),
+    ("sageicp_pipeline_num_poses", C.c_uint64, [C.c_void_p]),
+    ("sageicp_pipeline_pose", C.c_int, [C.c_void_p, C.c_uint64, _dp]),
+    ("sageicp_pipeline_local_map", C.c_void_p, [C.c_void_p]),
 ]
 
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
@@ -304,3 +356,46 @@ def align_clouds(src, tgt, kernel, device=0):
                                       T.ctypes.data_as(_dp), JTJ.ctypes.data_as(_dp),
                                       JTr.ctypes.data_as(_dp), device))
     return T, JTJ.reshape(6, 6), JTr
+
+
+class SageICP:
+    """sage_icp::pipeline::sageICP (pipeline/sageICP.hpp:67-109) over the C ABI."""
+
+    def __init__(self, config=None, **kw):
+        self.config = config if config is not None else make_pipeline_config(**kw)
+        self._h = lib().sageicp_pipeline_create(C.byref(self.config))
+        if not self._h:
+            raise SageIcpError(ERR_INVALID, (lib().sageicp_last_error() or b"").decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().sageicp_pipeline_destroy(self._h)
+            self._h = None
+
+    def RegisterFrame(self, frame):
+        """returns (pose[7], icp_seconds, total_seconds, n_source, stats)"""
+        pts, pp = _d(frame)
+        out = np.empty(7)
+        icp, tot, ns = C.c_double(0), C.c_double(0), C.c_uint64(0)
+        st = Stats()
+        _check(lib().sageicp_pipeline_register_frame(self._h, pp, pts.reshape(-1, 4).shape[0],
+                                                     out.ctypes.data_as(_dp), C.byref(icp),
+                                                     C.byref(tot), C.byref(ns), C.byref(st)))
+        return out, icp.value, tot.value, ns.value, st
+
+    def reinitialize(self):
+        _check(lib().sageicp_pipeline_reinitialize(self._h))
+
+    def poses(self):
+        n = int(lib().sageicp_pipeline_num_poses(self._h))
+        out = np.empty((n, 7))
+        for i in range(n):
+            _check(lib().sageicp_pipeline_pose(self._h, i, out[i].ctypes.data_as(_dp)))
+        return out
+
+    def LocalMap(self):
+        h = lib().sageicp_pipeline_local_map(self._h)
+        n = int(lib().sageicp_map_size(h))
+        out = np.empty((n, 4))
+        lib().sageicp_map_pointcloud(h, out.ctypes.data_as(_dp), n)
+        return out

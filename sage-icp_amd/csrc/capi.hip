@@ -27,6 +27,7 @@
 #include "../../include/sageicp.h"
 #include "host_map.hpp"
 #include "kernels.h"
+#include "pipeline.hpp"
 #include "se3_math.h"
 #include "sageicp_types.h"
 
@@ -791,6 +792,46 @@ void sageicp_comm_destroy(sageicp_comm *c) {
         g_rccl.CommDestroy(c->comm);
     }
     delete c;
+}
+
+// ---- pipeline counterpart -----------------------------------------------------------------------
+struct sageicp_pipeline {
+    sageicp::Pipeline impl;
+    explicit sageicp_pipeline(const sageicp_pipeline_config &c) : impl(c) {}
+};
+
+sageicp_pipeline *sageicp_pipeline_create(const sageicp_pipeline_config *c) {
+    if (!c || c->n_groups < 0 || (c->n_groups && (!c->group_label_counts || !c->group_voxel_size))) {
+        fail(SAGEICP_ERR_INVALID, "sageicp_pipeline_create: bad config");
+        return nullptr;
+    }
+    sageicp_pipeline *p = new sageicp_pipeline(*c);
+    if (!p->impl.ok()) {
+        delete p;
+        return nullptr;
+    }
+    return p;
+}
+void sageicp_pipeline_destroy(sageicp_pipeline *p) { delete p; }
+int sageicp_pipeline_register_frame(sageicp_pipeline *p, const double *frame, uint64_t n,
+                                    double pose_out[7], double *icp_s, double *total_s,
+                                    uint64_t *n_source, sageicp_stats *stats) {
+    if (!p || !pose_out || (n && !frame)) return fail(SAGEICP_ERR_INVALID, "null argument");
+    return p->impl.register_frame(frame, n, pose_out, icp_s, total_s, n_source, stats);
+}
+int sageicp_pipeline_reinitialize(sageicp_pipeline *p) {
+    if (!p) return fail(SAGEICP_ERR_INVALID, "null pipeline");
+    p->impl.reinitialize();
+    return SAGEICP_OK;
+}
+uint64_t sageicp_pipeline_num_poses(const sageicp_pipeline *p) { return p ? p->impl.poses.size() : 0; }
+int sageicp_pipeline_pose(const sageicp_pipeline *p, uint64_t i, double out[7]) {
+    if (!p || !out || i >= p->impl.poses.size()) return fail(SAGEICP_ERR_INVALID, "bad pose index");
+    for (int k = 0; k < 7; ++k) out[k] = p->impl.poses[i].v[k];
+    return SAGEICP_OK;
+}
+const sageicp_map *sageicp_pipeline_local_map(const sageicp_pipeline *p) {
+    return p ? p->impl.map : nullptr;
 }
 
 }  // extern "C"

@@ -260,3 +260,28 @@ def make_workload(name, new_map, scale=1.0):
         m, stream = build_map_points(new_map, rng, half, int(w["map_points"] * scale))
     scan = make_scan(rng, int(w["scan"] * scale), half, T_GT_C2)
     return dict(map=m, scan=scan, T_gt=T_GT_C2.copy(), stream=stream, voxel=w["voxel"])
+
+
+def make_stream(seed, n_frames, points_per_frame=30000, half=120.0, step=(1.0, 0.0, 0.0),
+                yaw_step_deg=0.5, max_range=100.0):
+    """c3-style synthetic stream: a sensor advancing `step` metres and turning
+    `yaw_step_deg` per frame through the street scene; each frame is a labelled scan in the sensor
+    frame with KITTI-like content (x, y, z as f32 values, integer labels).  Returns
+    (frames list, true poses list)."""
+    rng = np.random.default_rng(seed)
+    frames, poses = [], []
+    T = pose_from_rpy_t([0, 0, 0], [-0.5 * n_frames * step[0], 0.0, 0.0])
+    dT = pose_from_rpy_t([0, 0, yaw_step_deg], list(step))
+    for _ in range(n_frames):
+        frames.append(make_scan(rng, points_per_frame, half, T, max_range=max_range))
+        poses.append(T.copy())
+        # T <- T * dT
+        R = quat_to_mat(T[:4])
+        t = R @ dT[4:] + T[4:]
+        a, b = T[:4], dT[:4]
+        q = np.array([a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1],
+                      a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0],
+                      a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3],
+                      a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2]])
+        T = np.concatenate([q / np.linalg.norm(q), t])
+    return frames, poses
