@@ -206,6 +206,10 @@ struct sageicp_map {
     mutable Point4 *d_pts = nullptr;
     mutable size_t d_blocks_cap = 0;     // blocks
     mutable bool mirror_stale_all = true;
+    // pinned staging + device landing buffers for the scattered refresh of changed records
+    mutable void *h_stage = nullptr;
+    mutable void *d_stage = nullptr;
+    mutable size_t stage_bytes = 0;
 };
 
 struct sageicp_frame {
@@ -257,6 +261,21 @@ int load_rccl() {
 }
 
 // ---- device mirror ------------------------------------------------------------------------
+int reserve_stage(const sageicp_map *m, size_t bytes) {
+    if (bytes <= m->stage_bytes) return SAGEICP_OK;
+    if (m->h_stage) HIPCHK(hipHostFree(m->h_stage));
+    if (m->d_stage) HIPCHK(hipFree(m->d_stage));
+    m->h_stage = nullptr; m->d_stage = nullptr; m->stage_bytes = 0;
+    const size_t cap = bytes + bytes / 2 + (1u << 20);
+    HIPCHK(hipHostMalloc(&m->h_stage, cap, hipHostMallocDefault));
+    HIPCHK(hipMalloc(&m->d_stage, cap));
+    m->stage_bytes = cap;
+    return SAGEICP_OK;
+}
+
+// Refresh the HBM mirror from the host-authoritative map.  Everything after a (re)allocation,
+// otherwise only the slots and points written since the last sync: they are packed into one
+// pinned staging buffer, copied once and scattered by a kernel.
 int sync_mirror(const sageicp_map *m) {
     int rc = m->sc.init(m->device);
     if (rc) return rc;
@@ -264,48 +283,57 @@ int sync_mirror(const sageicp_map *m) {
     const HostMap &h = m->host;
     hipStream_t s = m->sc.stream;
     bool any = false;
-    // slot table: whole-table refresh (16 B/slot; a few MB) whenever any slot changed
+    bool table_full = h.table_all_dirty || m->mirror_stale_all;
     if (h.table.size() != m->d_table_cap) {
         if (m->d_table) HIPCHK(hipFree(m->d_table));
         m->d_table = nullptr; m->d_table_cap = 0;
         HIPCHK(hipMalloc(&m->d_table, h.table.size() * sizeof(Slot)));
         m->d_table_cap = h.table.size();
-        m->mirror_stale_all = true;
+        table_full = true;
     }
-    if (h.table_dirty || m->mirror_stale_all) {
-        HIPCHK(hipMemcpyAsync(m->d_table, h.table.data(), h.table.size() * sizeof(Slot),
-                              hipMemcpyHostToDevice, s));
-        any = true;
-    }
-    // point blocks: full refresh after (re)allocation, otherwise coalesced dirty runs
     const size_t blocks_cap = h.cnt.size();
     const size_t block_bytes = static_cast<size_t>(h.cap) * sizeof(Point4);
-    bool full = m->mirror_stale_all;
+    bool points_full = h.points_all_dirty || m->mirror_stale_all;
     if (blocks_cap > m->d_blocks_cap) {
         if (m->d_pts) HIPCHK(hipFree(m->d_pts));
         m->d_pts = nullptr; m->d_blocks_cap = 0;
         HIPCHK(hipMalloc(&m->d_pts, std::max<size_t>(blocks_cap, 1) * block_bytes));
         m->d_blocks_cap = blocks_cap;
-        full = true;
+        points_full = true;
     }
-    if (full) {
-        if (h.blocks_hi) {
-            HIPCHK(hipMemcpyAsync(m->d_pts, h.pts.data(), h.blocks_hi * block_bytes,
-                                  hipMemcpyHostToDevice, s));
-            any = true;
-        }
-    } else if (!h.dirty_list.empty()) {
-        std::vector<uint32_t> d(h.dirty_list);
-        std::sort(d.begin(), d.end());
-        size_t i = 0;
-        while (i < d.size()) {
-            size_t j = i;
-            while (j + 1 < d.size() && d[j + 1] <= d[j] + 4) ++j;   // bridge small gaps
-            const size_t b0 = d[i], b1 = d[j] + 1;
-            HIPCHK(hipMemcpyAsync(m->d_pts + b0 * h.cap, h.pts.data() + b0 * h.cap,
-                                  (b1 - b0) * block_bytes, hipMemcpyHostToDevice, s));
-            i = j + 1;
-        }
+    if (table_full) {
+        HIPCHK(hipMemcpyAsync(m->d_table, h.table.data(), h.table.size() * sizeof(Slot),
+                              hipMemcpyHostToDevice, s));
+        any = true;
+    }
+    if (points_full && h.blocks_hi) {
+        HIPCHK(hipMemcpyAsync(m->d_pts, h.pts.data(), h.blocks_hi * block_bytes,
+                              hipMemcpyHostToDevice, s));
+        any = true;
+    }
+    const size_t ns = table_full ? 0 : h.dirty_slots.size();
+    const size_t np = points_full ? 0 : h.dirty_pts.size();
+    if (ns || np) {
+        // staging layout: [slot idx][point idx][slot values][point values], 32-B aligned parts
+        auto up = [](size_t x) { return (x + 31) & ~static_cast<size_t>(31); };
+        const size_t o_si = 0, o_pi = up(o_si + ns * 4), o_sv = up(o_pi + np * 4),
+                     o_pv = up(o_sv + ns * sizeof(Slot)), total = o_pv + np * sizeof(Point4);
+        if ((rc = reserve_stage(m, total))) return rc;
+        char *hs = static_cast<char *>(m->h_stage);
+        uint32_t *si = reinterpret_cast<uint32_t *>(hs + o_si);
+        uint32_t *pi = reinterpret_cast<uint32_t *>(hs + o_pi);
+        Slot *sv = reinterpret_cast<Slot *>(hs + o_sv);
+        Point4 *pv = reinterpret_cast<Point4 *>(hs + o_pv);
+        for (size_t i = 0; i < ns; ++i) { si[i] = h.dirty_slots[i]; sv[i] = h.table[h.dirty_slots[i]]; }
+        for (size_t i = 0; i < np; ++i) { pi[i] = h.dirty_pts[i]; pv[i] = h.pts[h.dirty_pts[i]]; }
+        HIPCHK(hipMemcpyAsync(m->d_stage, m->h_stage, total, hipMemcpyHostToDevice, s));
+        char *ds = static_cast<char *>(m->d_stage);
+        launch_scatter_slots(reinterpret_cast<uint32_t *>(ds + o_si), reinterpret_cast<Slot *>(ds + o_sv),
+                             static_cast<uint32_t>(ns), m->d_table, s);
+        launch_scatter_points(reinterpret_cast<uint32_t *>(ds + o_pi),
+                              reinterpret_cast<Point4 *>(ds + o_pv), static_cast<uint32_t>(np),
+                              m->d_pts, s);
+        HIPCHK(hipGetLastError());
         any = true;
     }
     if (any) HIPCHK(hipStreamSynchronize(s));
@@ -479,6 +507,8 @@ void sageicp_map_destroy(sageicp_map *m) {
         (void)hipStreamSynchronize(m->sc.stream);
         if (m->d_table) (void)hipFree(m->d_table);
         if (m->d_pts) (void)hipFree(m->d_pts);
+        if (m->d_stage) (void)hipFree(m->d_stage);
+        if (m->h_stage) (void)hipHostFree(m->h_stage);
     }
     m->sc.destroy();
     delete m;
@@ -488,7 +518,6 @@ sageicp_map *sageicp_map_clone(const sageicp_map *src) {
     if (!src) return nullptr;
     sageicp_map *m = new sageicp_map;
     m->host = src->host;
-    m->host.table_dirty = true;
     m->device = src->device;
     m->mirror_stale_all = true;   // the clone builds its own mirror on first use
     return m;

@@ -43,10 +43,12 @@ public:
     uint32_t blocks_hi = 0;           // high-water mark of allocated block indices
     uint64_t total_points = 0;
 
-    // dirty tracking for the device mirror
-    bool table_dirty = true;
-    std::vector<uint8_t> block_dirty;
-    std::vector<uint32_t> dirty_list;
+    // dirty tracking for the device mirror: the indices of the points and slots written since
+    // the last sync (duplicates allowed; values are read at sync time), or "everything"
+    bool table_all_dirty = true;
+    bool points_all_dirty = true;
+    std::vector<uint32_t> dirty_pts;
+    std::vector<uint32_t> dirty_slots;
     uint64_t generation = 0;          // bumps on every mutation
 
     HostMap() { reset_table(1024); }
@@ -68,11 +70,12 @@ public:
         cnt.clear();
         keys.clear();
         free_blocks.clear();
-        block_dirty.clear();
-        dirty_list.clear();
+        dirty_pts.clear();
+        dirty_slots.clear();
+        points_all_dirty = true;
         blocks_hi = 0;
         total_points = 0;
-        table_dirty = true;
+        table_all_dirty = true;
         ++generation;
     }
 
@@ -107,9 +110,10 @@ public:
     }
 
     void clear_dirty() {
-        for (uint32_t b : dirty_list) block_dirty[b] = 0;
-        dirty_list.clear();
-        table_dirty = false;
+        dirty_pts.clear();
+        dirty_slots.clear();
+        table_all_dirty = false;
+        points_all_dirty = false;
     }
 
 private:
@@ -140,14 +144,27 @@ private:
             if (e.blk == kEmptySlot) continue;
             table[probe(e.x, e.y, e.z)] = e;
         }
-        table_dirty = true;
+        table_all_dirty = true;
+        dirty_slots.clear();
     }
 
-    void mark_dirty(uint32_t b) {
-        if (!block_dirty[b]) {
-            block_dirty[b] = 1;
-            dirty_list.push_back(b);
+    void mark_point(size_t idx) {
+        if (points_all_dirty) return;
+        if (dirty_pts.size() > pts.size() / 4) {      // cheaper to refresh everything
+            points_all_dirty = true;
+            dirty_pts.clear();
+            return;
         }
+        dirty_pts.push_back(static_cast<uint32_t>(idx));
+    }
+    void mark_slot(uint32_t s) {
+        if (table_all_dirty) return;
+        if (dirty_slots.size() > table.size() / 4) {
+            table_all_dirty = true;
+            dirty_slots.clear();
+            return;
+        }
+        dirty_slots.push_back(s);
     }
 
     uint32_t alloc_block() {
@@ -160,7 +177,6 @@ private:
             if (blocks_hi > cnt.size()) {
                 const size_t nb = std::max<size_t>(1024, cnt.size() * 2);
                 cnt.resize(nb, 0);
-                block_dirty.resize(nb, 0);
                 keys.resize(nb * 3, 0);
                 pts.resize(nb * cap, Point4{0, 0, 0, 0});
             }
@@ -188,8 +204,8 @@ private:
             table[s] = Slot{vx, vy, vz, (b << 8) | 1u};
             ++num_voxels;
             ++total_points;
-            table_dirty = true;
-            mark_dirty(b);
+            mark_slot(s);
+            mark_point(static_cast<size_t>(b) * cap);
             return;
         }
         const uint32_t b = table[s].blk >> 8;
@@ -200,14 +216,14 @@ private:
             cnt[b] = static_cast<uint8_t>(c + 1);
             table[s].blk = (b << 8) | static_cast<uint32_t>(c + 1);
             ++total_points;
-            table_dirty = true;
-            mark_dirty(b);
+            mark_slot(s);
+            mark_point(static_cast<size_t>(b) * cap + c);
         };
         auto replace_first_unlabelled = [&]() {
             for (int j = 0; j < c; ++j)
                 if (static_cast<int>(blk[j].l) == 0) {
                     blk[j] = np;
-                    mark_dirty(b);
+                    mark_point(static_cast<size_t>(b) * cap + j);
                     break;
                 }
         };
@@ -238,14 +254,15 @@ private:
             const bool stays = (i <= j) ? (i < k && k <= j) : (i < k || k <= j);
             if (stays) continue;
             table[i] = e;
+            mark_slot(i);
             i = j;
         }
         table[i] = Slot{0, 0, 0, kEmptySlot};
+        mark_slot(i);
         total_points -= cnt[b];
         cnt[b] = 0;
         free_blocks.push_back(b);
         --num_voxels;
-        table_dirty = true;
     }
 };
 

@@ -69,6 +69,10 @@ int launch_gn(const GnParams &p, hipStream_t s);   // returns the number of part
 void launch_fin(IcpState *st, const double *partials, int nparts, int mode, int standalone,
                 hipStream_t s);
 void launch_tf(Point4 *pts, int n, const IcpState *st, hipStream_t s);
+void launch_scatter_points(const uint32_t *idx, const Point4 *vals, uint32_t n, Point4 *pts,
+                           hipStream_t s);
+void launch_scatter_slots(const uint32_t *idx, const Slot *vals, uint32_t n, Slot *table,
+                          hipStream_t s);
 int gn_grid_for(int n);
 unsigned nn_cand_stride(int cap);
 

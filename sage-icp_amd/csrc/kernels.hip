@@ -541,7 +541,30 @@ extern "C" void sageicp_debug_nn_phases(unsigned long long out[8], int reset) {
 }
 #endif
 
+// ------------------------------------------------------------------------------- mirror refresh
+// Scatter the records the host changed since the last sync into the HBM mirror: one staged copy
+// + one kernel per array instead of thousands of small hipMemcpy calls.
+__global__ __launch_bounds__(256) void k_scatter_points(const uint32_t *idx, const Point4 *vals,
+                                                        uint32_t n, Point4 *pts) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) pts[idx[i]] = vals[i];
+}
+__global__ __launch_bounds__(256) void k_scatter_slots(const uint32_t *idx, const Slot *vals,
+                                                       uint32_t n, Slot *table) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) table[idx[i]] = vals[i];
+}
+
 // ------------------------------------------------------------------------------------ launchers
+void launch_scatter_points(const uint32_t *idx, const Point4 *vals, uint32_t n, Point4 *pts,
+                           hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_scatter_points, dim3((n + 255) / 256), dim3(256), 0, s, idx, vals, n, pts);
+}
+void launch_scatter_slots(const uint32_t *idx, const Slot *vals, uint32_t n, Slot *table,
+                          hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_scatter_slots, dim3((n + 255) / 256), dim3(256), 0, s, idx, vals, n, table);
+}
+
 int nn_grid_for(int n, int chunk) {
     // one wave per chunk, 4 waves per workgroup, rounded up to whole stripes on all 8 XCDs
     const long nchunks = (static_cast<long>(n) + chunk - 1) / chunk;

@@ -21,7 +21,6 @@
 #include <chrono>
 #include <cmath>
 #include <cstdint>
-#include <unordered_set>
 #include <vector>
 
 #include "../../include/sageicp.h"
@@ -44,6 +43,12 @@ public:
             groups.emplace_back(gl, gl + c.group_label_counts[g]);
             gl += c.group_label_counts[g];
             group_voxel.push_back(c.group_voxel_size[g]);
+        }
+        for (int l = 0; l < 256; ++l) {
+            lut[l] = -1;
+            for (size_t g = 0; g < groups.size() && lut[l] < 0; ++g)
+                if (std::find(groups[g].begin(), groups[g].end(), l) != groups[g].end())
+                    lut[l] = static_cast<int>(g);
         }
         map = sageicp_map_create(c.voxel_size_map, c.local_map_range, c.basic_points_per_voxel,
                                  c.critical_points_per_voxel, c.basic_parts_labels,
@@ -122,32 +127,45 @@ private:
         }
     }
 
-    struct KeyHash {
-        size_t operator()(const std::array<int, 3> &k) const {
-            return static_cast<size_t>(voxel_hash(k[0], k[1], k[2]));
-        }
-    };
+    // label -> first group that lists it (Preprocessing.cpp:57-64), -1 if none
+    int group_of(int label) const {
+        if (label >= 0 && label < 256) return lut[label];
+        for (size_t g = 0; g < groups.size(); ++g)
+            if (std::find(groups[g].begin(), groups[g].end(), label) != groups[g].end())
+                return static_cast<int>(g);
+        return -1;
+    }
 
-    // core/Preprocessing.cpp:44-84: first point per voxel wins, one grid per label group
+    // core/Preprocessing.cpp:44-84: first point per voxel wins, one grid per label group.
+    // The grids are one flat open-addressed set keyed by (group, voxel): membership is all that
+    // is needed, and the kept points are emitted group by group in insertion order.
     void voxel_downsample(const std::vector<double> &in, double scale, std::vector<double> &out) const {
         const size_t G = groups.size();
-        std::vector<std::unordered_set<std::array<int, 3>, KeyHash>> seen(G);
-        std::vector<std::vector<double>> kept(G);
         const size_t n = in.size() / 4;
+        size_t capacity = 64;
+        while (capacity < 2 * n + 16) capacity <<= 1;
+        struct Key { int g, x, y, z; };
+        std::vector<Key> set(capacity, Key{-1, 0, 0, 0});
+        const size_t mask = capacity - 1;
+        std::vector<std::vector<double>> kept(G);
+        for (size_t g = 0; g < G; ++g) kept[g].reserve(in.size() / (G ? G : 1) + 64);
         for (size_t i = 0; i < n; ++i) {
             const double *p = &in[4 * i];
-            const int label = static_cast<int>(p[3]);
-            int group = -1;
-            for (size_t g = 0; g < G; ++g)
-                if (std::find(groups[g].begin(), groups[g].end(), label) != groups[g].end()) {
-                    group = static_cast<int>(g);
-                    break;
-                }
+            const int group = group_of(static_cast<int>(p[3]));
             if (group < 0) continue;
             const double vs = group_voxel[group] * scale;
-            const std::array<int, 3> key = {static_cast<int>(p[0] / vs), static_cast<int>(p[1] / vs),
-                                            static_cast<int>(p[2] / vs)};
-            if (!seen[group].insert(key).second) continue;
+            const Key key{group, static_cast<int>(p[0] / vs), static_cast<int>(p[1] / vs),
+                          static_cast<int>(p[2] / vs)};
+            size_t s = (voxel_hash(key.x, key.y, key.z) + 0x9E3779B9u * static_cast<uint32_t>(group)) & mask;
+            bool present = false;
+            for (;;) {
+                const Key &e = set[s];
+                if (e.g < 0) break;
+                if (e.g == key.g && e.x == key.x && e.y == key.y && e.z == key.z) { present = true; break; }
+                s = (s + 1) & mask;
+            }
+            if (present) continue;
+            set[s] = key;
             kept[group].insert(kept[group].end(), p, p + 4);
         }
         out.clear();
@@ -185,6 +203,7 @@ private:
     double min_motion_th, initial_threshold, sem_th;
     std::vector<std::vector<int>> groups;
     std::vector<double> group_voxel;
+    int lut[256];
     double model_error_sse2 = 0.0;
     int num_samples = 0;
     Pose7 model_deviation;
