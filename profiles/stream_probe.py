@@ -6,15 +6,22 @@ import sage_icp_amd as sage
 from sage_icp_amd import synthetic as syn
 frames, truth = syn.make_stream(21, 40, points_per_frame=120000)
 p = sage.SageICP(sage.make_pipeline_config())
+sage.set_profiling(2 if len(sys.argv) > 1 else 0)
+kt = []
 rows = []
 for k, f in enumerate(frames):
     t = time.perf_counter()
     pose, icp_s, tot_s, ns, st = p.RegisterFrame(f)
     wall = time.perf_counter() - t
     rows.append((wall, tot_s, icp_s, ns, st.iterations, st.us_upload))
+    if st.nn_launches: kt.append((st.us_group / st.nn_launches, st.us_nn / st.nn_launches, st.us_gn / st.nn_launches, st.us_fin / st.nn_launches, st.us_wall / max(st.iterations, 1)))
 r = np.array(rows[5:])
 print("frames %d  source pts %.0f  iterations %.1f" % (len(r), r[:, 3].mean(), r[:, 4].mean()))
 print("per frame ms: wall %.2f  (preprocess+voxelize %.2f, ICP %.2f [mirror refresh+upload %.2f], map update+rest %.2f)"
       % (1e3 * r[:, 0].mean(), 1e3 * (r[:, 1] - r[:, 2]).mean(), 1e3 * r[:, 2].mean(),
          1e-3 * r[:, 5].mean(), 1e3 * (r[:, 0] - r[:, 1]).mean()))
 print("map points", len(p.LocalMap()))
+
+if kt:
+    k = np.array(kt[5:]).mean(0)
+    print("per iteration us (HIP events, level 2): group+probe %.1f  nn %.1f  gn %.1f  fin %.1f   | host wall per iteration %.1f" % tuple(k))

@@ -387,7 +387,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
                 nn_cand_stride(m->host.cap), sem_th, sc.d_nn, sc.d_cand};
     HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * (n + 1), s));
     GnParams gp{sc.d_src, nullptr, static_cast<int>(n), sc.d_state, 1, m->d_pts, sc.d_nn, kernel,
-                max_dist, sc.d_partials};
+                max_dist, sc.d_partials, comm ? 1 : 0, sc.d_state, &sc.d_state->gn_ticket};
     const int gn_blocks = gn_grid_for(static_cast<int>(n));
 
     double us_group = 0, us_nn = 0, us_gn = 0, us_fin = 0;
@@ -407,17 +407,14 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
             if (prof) HIPCHK(hipEventRecord(sc.events[5 * k + 2], s));
             launch_gn(gp, s);
             if (prof2) HIPCHK(hipEventRecord(sc.events[5 * k + 3], s));
-            if (comm) {
-                launch_fin(sc.d_state, sc.d_partials, gn_blocks, 1, 0, s);
+            if (comm) {     // k_gn's last workgroup left the local sums in state->sums
                 ncclResult_t r = g_rccl.AllReduce(sc.d_state->sums, sc.d_state->sums, kNumSums,
                                                   ncclDouble, ncclSum, comm->comm, s);
                 if (r != ncclSuccess)
                     return fail(SAGEICP_ERR_RCCL, std::string("ncclAllReduce: ") +
                                                       (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
                 launch_fin(sc.d_state, sc.d_partials, gn_blocks, 2, 0, s);
-            } else {
-                launch_fin(sc.d_state, sc.d_partials, gn_blocks, 0, 0, s);
-            }
+            }               // single GPU: k_gn's last workgroup already finished the iteration
             if (prof2) HIPCHK(hipEventRecord(sc.events[5 * k + 4], s));
         }
         HIPCHK(hipGetLastError());
@@ -660,9 +657,8 @@ int sageicp_align_clouds(const double *src, const double *tgt, uint64_t n, doubl
         fill_state(sc.h_state, I);
         HIPCHK(hipMemcpyAsync(sc.d_state, sc.h_state, sizeof(IcpState), hipMemcpyHostToDevice, s));
         GnParams gp{sc.d_frame, sc.d_tgt, static_cast<int>(n), sc.d_state, 0, nullptr, nullptr,
-                    kernel, 0.0, sc.d_partials};
-        const int blocks = launch_gn(gp, s);
-        launch_fin(sc.d_state, sc.d_partials, blocks, 0, 1, s);
+                    kernel, 0.0, sc.d_partials, 0, sc.d_state, &sc.d_state->gn_ticket};
+        launch_gn(gp, s);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(sc.h_state, sc.d_state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));

@@ -57,6 +57,9 @@ struct GnParams {
     double kernel;
     double max_dist;          // acceptance threshold on the unscaled distance
     double *partials;         // [gridDim.x][kNumSums]
+    int fuse_mode;            // -1: partials only; 0 / 1: the last workgroup runs finish_iteration
+    IcpState *st_rw;          // state written by finish_iteration
+    unsigned *ticket;         // last-arriver ticket (zero before the first launch)
 };
 
 constexpr int kMaxGnBlocks = 512;

@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <cstdlib>
 
 #ifndef SAGE_NN_WAVES
 #define SAGE_NN_WAVES 1
@@ -374,73 +375,16 @@ __global__ __launch_bounds__(64 * kNnWaves, 8) void k_nn(NnParams P) {
     if (P.cand_counter && lane == 0 && wave_candidates) P.cand_counter[cand_slot] += wave_candidates;
 }
 
-// ------------------------------------------------------------------------------------ k_gn
-__global__ __launch_bounds__(256) void k_gn(GnParams P) {
-    if (P.check_done && P.st->done) return;
-    __shared__ double lds[4][kNumSums];
-
-    double acc[kCount + 1];
-#pragma unroll
-    for (int i = 0; i <= kCount; ++i) acc[i] = 0.0;
-
-    const double k = P.kernel;
-    const double k2 = k * k;
-
-    for (int q = blockIdx.x * 256 + threadIdx.x; q < P.n; q += gridDim.x * 256) {
-        Point4 g;
-        if (P.tgt_pairs) {
-            g = P.tgt_pairs[q];
-        } else {
-            const int idx = P.nn_idx[q];
-            if (idx < 0) continue;
-            g = P.pts[idx];
-        }
-        const Point4 s = P.src[q];
-        const double sx = s.x, sy = s.y, sz = s.z;
-        const double rx = sx - g.x, ry = sy - g.y, rz = sz - g.z;
-        const double r2 = rx * rx + (ry * ry + rz * rz);
-        // acceptance: (closest_neighboor - point).norm() < max_correspondance_distance
-        // (VoxelHashMap.cpp:111); explicit pairs (align_clouds entry) are all taken
-        if (!P.tgt_pairs && !(sqrt(r2) < P.max_dist)) continue;
-        const double den = k + r2;
-        const double w = k2 / (den * den);   // square(th) / square(th + residual2)
-        const double wsx = w * sx, wsy = w * sy, wsz = w * sz;
-        acc[kW] += w;
-        acc[kWsx] += wsx; acc[kWsy] += wsy; acc[kWsz] += wsz;
-        acc[kWxx] += wsx * sx; acc[kWxy] += wsx * sy; acc[kWxz] += wsx * sz;
-        acc[kWyy] += wsy * sy; acc[kWyz] += wsy * sz; acc[kWzz] += wsz * sz;
-        acc[kWrx] += w * rx; acc[kWry] += w * ry; acc[kWrz] += w * rz;
-        acc[kWcx] += w * (sy * rz - sz * ry);
-        acc[kWcy] += w * (sz * rx - sx * rz);
-        acc[kWcz] += w * (sx * ry - sy * rx);
-        acc[kCount] += 1.0;
-    }
-
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i <= kCount; ++i) {
-        double v = acc[i];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) lds[wv][i] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < kNumSums) {
-        double v = 0.0;
-        if (threadIdx.x <= kCount)
-            v = ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) +
-                lds[3][threadIdx.x];
-        P.partials[blockIdx.x * kNumSums + threadIdx.x] = v;
-    }
-}
-
-// ------------------------------------------------------------------------------------ k_fin
-// mode 0: reduce partials + solve      (single GPU)
-// mode 1: reduce partials -> st->sums  (multi GPU, before the RCCL all-reduce)
-// mode 2: solve from st->sums          (multi GPU, after the all-reduce)
-__global__ __launch_bounds__(256) void k_fin(IcpState *st, const double *partials, int nparts,
-                                             int mode, int standalone) {
-    if (!standalone && st->done) return;
+// ------------------------------------------------------------------------------ finish_iteration
+// Executed by ONE workgroup of 256 threads once per ICP iteration: fixed-order reduction of the
+// k_gn workgroup partials (bit-reproducible), then one lane assembles the 6x6 normal equations
+// from the 16 closed-form sums, solves them (register-resident pivoted LDL^T), applies SE3 exp,
+// composes the pose and tests convergence (Registration.cpp:92-93,135-137).
+//   mode 0: reduce partials + solve      (single GPU)
+//   mode 1: reduce partials -> st->sums  (multi GPU, before the RCCL all-reduce)
+//   mode 2: solve from st->sums          (multi GPU, after the all-reduce)
+__device__ __forceinline__ void finish_iteration(IcpState *st, const double *partials, int nparts,
+                                                 int mode) {
     __shared__ double slice[8][32];
     __shared__ double S[kNumSums];
 
@@ -518,6 +462,99 @@ __global__ __launch_bounds__(256) void k_fin(IcpState *st, const double *partial
     }
 }
 
+// ------------------------------------------------------------------------------------ k_gn
+__global__ __launch_bounds__(256) void k_gn(GnParams P) {
+    if (P.check_done && P.st->done) return;
+    __shared__ double lds[4][kNumSums];
+
+    double acc[kCount + 1];
+#pragma unroll
+    for (int i = 0; i <= kCount; ++i) acc[i] = 0.0;
+
+    const double k = P.kernel;
+    const double k2 = k * k;
+
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < P.n; q += gridDim.x * 256) {
+        Point4 g;
+        if (P.tgt_pairs) {
+            g = P.tgt_pairs[q];
+        } else {
+            const int idx = P.nn_idx[q];
+            if (idx < 0) continue;
+            g = P.pts[idx];
+        }
+        const Point4 s = P.src[q];
+        const double sx = s.x, sy = s.y, sz = s.z;
+        const double rx = sx - g.x, ry = sy - g.y, rz = sz - g.z;
+        const double r2 = rx * rx + (ry * ry + rz * rz);
+        // acceptance: (closest_neighboor - point).norm() < max_correspondance_distance
+        // (VoxelHashMap.cpp:111); explicit pairs (align_clouds entry) are all taken
+        if (!P.tgt_pairs && !(sqrt(r2) < P.max_dist)) continue;
+        const double den = k + r2;
+        const double w = k2 / (den * den);   // square(th) / square(th + residual2)
+        const double wsx = w * sx, wsy = w * sy, wsz = w * sz;
+        acc[kW] += w;
+        acc[kWsx] += wsx; acc[kWsy] += wsy; acc[kWsz] += wsz;
+        acc[kWxx] += wsx * sx; acc[kWxy] += wsx * sy; acc[kWxz] += wsx * sz;
+        acc[kWyy] += wsy * sy; acc[kWyz] += wsy * sz; acc[kWzz] += wsz * sz;
+        acc[kWrx] += w * rx; acc[kWry] += w * ry; acc[kWrz] += w * rz;
+        acc[kWcx] += w * (sy * rz - sz * ry);
+        acc[kWcy] += w * (sz * rx - sx * rz);
+        acc[kWcz] += w * (sx * ry - sy * rx);
+        acc[kCount] += 1.0;
+    }
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i <= kCount; ++i) {
+        double v = acc[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) lds[wv][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNumSums) {
+        double v = 0.0;
+        if (threadIdx.x <= kCount)
+            v = ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) +
+                lds[3][threadIdx.x];
+        P.partials[blockIdx.x * kNumSums + threadIdx.x] = v;
+    }
+    if (P.fuse_mode < 0) return;
+
+    // Last-arriver hand-off (placement independent): partials are published with an agent-scope
+    // release before the ticket, the workgroup that draws the last ticket acquires (drops its
+    // CU's stale L1 lines of `partials`, which other CUs rewrite every iteration) and finishes the
+    // iteration.  One returning atomic per workgroup (<= 512 per launch) on a private word.
+    __shared__ unsigned s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(P.ticket, 1u, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(P.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
+    }
+    __syncthreads();
+    finish_iteration(P.st_rw, P.partials, static_cast<int>(gridDim.x), P.fuse_mode);
+}
+
+// ------------------------------------------------------------------------------------ k_fin
+// Stand-alone launch of finish_iteration: the post-all-reduce solve of the multi-GPU path
+// (mode 2).  On a single GPU the last workgroup of k_gn runs it instead (no extra launch).
+__global__ __launch_bounds__(256) void k_fin(IcpState *st, const double *partials, int nparts,
+                                             int mode, int standalone) {
+    if (!standalone && st->done) return;
+    finish_iteration(st, partials, nparts, mode);
+}
+
 // ------------------------------------------------------------------------------------ k_tf
 __global__ __launch_bounds__(256) void k_tf(Point4 *pts, int n, const IcpState *st) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -575,8 +612,13 @@ int nn_grid_for(int n, int chunk) {
 }
 
 int gn_grid_for(int n) {
+    static const int cap = [] {
+        const char *v = std::getenv("SAGEICP_GN_BLOCKS");
+        int c = v ? std::atoi(v) : 128;   // measured best with the fused finish (ticket per block)
+        return c < 1 ? 1 : (c > kMaxGnBlocks ? kMaxGnBlocks : c);
+    }();
     long blocks = (static_cast<long>(n) + 255) / 256;
-    if (blocks > kMaxGnBlocks) blocks = kMaxGnBlocks;
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return static_cast<int>(blocks);
 }

@@ -58,7 +58,7 @@ struct IcpState {
     int32_t iter;       // iterations completed
     int32_t done;       // 1: converged or hit kMaxIterations -> later launches are no-ops
     int32_t converged;
-    int32_t pad;
+    uint32_t gn_ticket; // last-arriver ticket of k_gn (returns to 0 after every launch)
     double sums[kNumSums];          // last reduced GN sums (diagnostics / multi-GPU exchange)
     unsigned long long sum_candidates;  // sum over launches and queries of C_q (roofline bytes)
     uint32_t n_corr[kHistory];      // accepted correspondences per iteration (all ranks)
