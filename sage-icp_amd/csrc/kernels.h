@@ -27,6 +27,7 @@ struct ProbeParams {
     uint32_t mask;
     int cap;
     uint2 *blks;              // out: [n][32] {candidate offset, first point} per neighbour voxel
+    int4 *tabkey;             // [n] home voxel each row was built for (y, z, w), reset per call
 };
 
 struct NnParams {

@@ -114,10 +114,16 @@ __global__ __launch_bounds__(256) void k_probe(ProbeParams P) {
     const unsigned slot = blockIdx.x * 8u + (threadIdx.x >> 5);      // one slot per query
     const unsigned v = threadIdx.x & 31u;
     if (slot >= static_cast<unsigned>(P.n)) return;
-    if (P.groups[slot].x == -1) return;                              // not a group head (uniform per 32 lanes)
+    const int4 rec0 = P.groups[slot];
+    if (rec0.x == -1) return;                                        // not a group head (uniform per 32 lanes)
+    // The map does not change during a registration and the pose moves by millimetres per
+    // iteration, so a slot's home voxel — hence its 27 neighbours and its whole table row — is
+    // almost always the one of the previous iteration: keep the row and skip the probes.
+    const int4 key0 = P.tabkey[slot];
+    if (key0.y == rec0.y && key0.z == rec0.z && key0.w == rec0.w) return;
     uint32_t blk = kEmptySlot;
     if (v < 27u) {
-        const int4 rec = P.groups[slot];
+        const int4 rec = rec0;
         const int vx = rec.y + static_cast<int>(v / 9u) - 1;
         const int vy = rec.z + static_cast<int>((v / 3u) % 3u) - 1;
         const int vz = rec.w + static_cast<int>(v % 3u) - 1;
@@ -146,6 +152,7 @@ __global__ __launch_bounds__(256) void k_probe(ProbeParams P) {
     rec2.x = off;
     rec2.y = (blk == kEmptySlot) ? 0u : (blk >> 8) * static_cast<uint32_t>(P.cap);   // first point
     P.blks[slot * 32u + v] = rec2;
+    if (v == 0u) P.tabkey[slot] = rec0;      // the row now describes this home voxel
 }
 
 // ------------------------------------------------------------------------------------- k_nn
@@ -372,7 +379,8 @@ __global__ __launch_bounds__(64 * kNnWaves, 8) void k_nn(NnParams P) {
     // sum_q C_q for the roofline accounting: one private slot per chunk, summed by the host.  (A
     // single device-scope atomic per wave serialised 8192 updates on one address and set a
     // ~100 us floor under this kernel.)
-    if (P.cand_counter && lane == 0 && wave_candidates) P.cand_counter[cand_slot] += wave_candidates;
+    if (P.cand_counter && lane == 0 && wave_candidates)
+        atomicAdd(P.cand_counter + cand_slot, wave_candidates);   // fire-and-forget, private address
 }
 
 // ------------------------------------------------------------------------------ finish_iteration
