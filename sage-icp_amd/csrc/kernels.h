@@ -16,6 +16,9 @@ struct GroupParams {
     int4 *groups;             // out: one record per query slot: {start | len << 26, kx, ky, kz}
                               //      at a group's head query, x = -1 elsewhere
     int group_mask;           // group cap - 1 (cap is a power of two <= 32)
+    const int4 *tabkey;       // home voxel each cached probe-table row was built for
+    unsigned *need_cnt;       // out: [ceil(n/64)] stale rows per wave
+    unsigned *need_list;      // out: [ceil(n/64)][64] their slots
 };
 
 struct ProbeParams {
@@ -28,6 +31,8 @@ struct ProbeParams {
     int cap;
     uint2 *blks;              // out: [n][32] {candidate offset, first point} per neighbour voxel
     int4 *tabkey;             // [n] home voxel each row was built for (y, z, w), reset per call
+    const unsigned *need_cnt; // k_group's per-wave lists of stale rows
+    const unsigned *need_list;
 };
 
 struct NnParams {

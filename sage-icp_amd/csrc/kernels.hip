@@ -100,27 +100,36 @@ __global__ __launch_bounds__(256) void k_group(GroupParams P) {
         rec.x = q | ((end - lane) << 26);      // start (26 bits) | length (1..32)
     }
     P.groups[q] = rec;
+
+    // Which probe-table rows must be (re)built?  The map does not change during a registration
+    // and the pose moves by millimetres per iteration, so a slot's home voxel — hence its 27
+    // neighbours and its whole table row — is almost always the one of the previous iteration.
+    // Heads whose cached row is for another voxel go into this wave's compact list for k_probe
+    // (ballot rank, no atomics); in steady state the lists are empty.
+    const int4 key0 = P.tabkey[q];
+    const bool stale = head && !(key0.y == kx && key0.z == ky && key0.w == kz);
+    const unsigned long long sm = __ballot(stale);
+    const unsigned wave_global = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (stale) P.need_list[wave_global * 64u + __popcll(sm & ((1ull << lane) - 1ull))] = q;
+    if (lane == 0) P.need_cnt[wave_global] = static_cast<unsigned>(__popcll(sm));
 }
 
 // ---------------------------------------------------------------------------------- k_probe
-// One lane per (group, neighbour voxel): 32 lanes per group slot, 27 of them probing the GPU-
-// resident open-addressed hash (linear probing, 16-B slots, load factor <= 0.25).  Doing the
+// One lane per (group, neighbour voxel) for every group whose probe-table row is stale (k_group's
+// per-wave lists): 32 lanes per group slot, 27 of them probing the GPU-resident open-addressed
+// hash (linear probing, 16-B slots, load factor <= 0.25).  Doing the
 // probes here — 1.4 M independent look-ups, no serial chain — instead of at the head of k_nn's
 // per-group dependency chain takes one to three memory round trips off every k_nn wave.
 // blks[slot][v] = {exclusive candidate offset, index of the voxel block's first point} of
 // neighbour v (x outer, y, z inner).
 __global__ __launch_bounds__(256) void k_probe(ProbeParams P) {
     if (P.check_done && P.st->done) return;
-    const unsigned slot = blockIdx.x * 8u + (threadIdx.x >> 5);      // one slot per query
+    // workgroup b serves the list of k_group's wave b; 8 teams of 32 lanes, one slot per team
+    const unsigned cnt_b = P.need_cnt[blockIdx.x];
     const unsigned v = threadIdx.x & 31u;
-    if (slot >= static_cast<unsigned>(P.n)) return;
+    for (unsigned i = threadIdx.x >> 5; i < cnt_b; i += 8u) {
+    const unsigned slot = P.need_list[blockIdx.x * 64u + i];
     const int4 rec0 = P.groups[slot];
-    if (rec0.x == -1) return;                                        // not a group head (uniform per 32 lanes)
-    // The map does not change during a registration and the pose moves by millimetres per
-    // iteration, so a slot's home voxel — hence its 27 neighbours and its whole table row — is
-    // almost always the one of the previous iteration: keep the row and skip the probes.
-    const int4 key0 = P.tabkey[slot];
-    if (key0.y == rec0.y && key0.z == rec0.z && key0.w == rec0.w) return;
     uint32_t blk = kEmptySlot;
     if (v < 27u) {
         const int4 rec = rec0;
@@ -153,6 +162,7 @@ __global__ __launch_bounds__(256) void k_probe(ProbeParams P) {
     rec2.y = (blk == kEmptySlot) ? 0u : (blk >> 8) * static_cast<uint32_t>(P.cap);   // first point
     P.blks[slot * 32u + v] = rec2;
     if (v == 0u) P.tabkey[slot] = rec0;      // the row now describes this home voxel
+    }
 }
 
 // ------------------------------------------------------------------------------------- k_nn
@@ -647,7 +657,7 @@ void launch_group(const GroupParams &p, bool apply_pose, hipStream_t s) {
 
 void launch_probe(const ProbeParams &p, int n, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_probe, dim3((static_cast<unsigned>(n) + 7u) / 8u), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_probe, dim3((static_cast<unsigned>(n) + 63u) / 64u), dim3(256), 0, s, p);
 }
 
 void launch_nn(const NnParams &p, hipStream_t s) {
