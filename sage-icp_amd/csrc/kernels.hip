@@ -492,22 +492,15 @@ __global__ __launch_bounds__(256) void k_gn(GnParams P) {
     const double k = P.kernel;
     const double k2 = k * k;
 
-    for (int q = blockIdx.x * 256 + threadIdx.x; q < P.n; q += gridDim.x * 256) {
-        Point4 g;
-        if (P.tgt_pairs) {
-            g = P.tgt_pairs[q];
-        } else {
-            const int idx = P.nn_idx[q];
-            if (idx < 0) continue;
-            g = P.pts[idx];
-        }
-        const Point4 s = P.src[q];
+    // per-pair accumulation; `use` masks rejected / out-of-range pairs (w = 0 adds exact zeros)
+    auto accumulate = [&](const Point4 &s, const Point4 &g, bool use) {
         const double sx = s.x, sy = s.y, sz = s.z;
         const double rx = sx - g.x, ry = sy - g.y, rz = sz - g.z;
         const double r2 = rx * rx + (ry * ry + rz * rz);
         // acceptance: (closest_neighboor - point).norm() < max_correspondance_distance
         // (VoxelHashMap.cpp:111); explicit pairs (align_clouds entry) are all taken
-        if (!P.tgt_pairs && !(sqrt(r2) < P.max_dist)) continue;
+        if (!P.tgt_pairs && !(sqrt(r2) < P.max_dist)) use = false;
+        if (!use) return;
         const double den = k + r2;
         const double w = k2 / (den * den);   // square(th) / square(th + residual2)
         const double wsx = w * sx, wsy = w * sy, wsz = w * sz;
@@ -520,6 +513,31 @@ __global__ __launch_bounds__(256) void k_gn(GnParams P) {
         acc[kWcy] += w * (sz * rx - sx * rz);
         acc[kWcz] += w * (sx * ry - sy * rx);
         acc[kCount] += 1.0;
+    };
+
+    // grid-stride over the queries, two per step so that the dependent gathers
+    // (nn_idx -> target point) of both are in flight together
+    const int stride = gridDim.x * 256;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < P.n; q += 2 * stride) {
+        const int q2 = q + stride;
+        const bool has2 = q2 < P.n;
+        int i1 = 0, i2 = 0;
+        if (!P.tgt_pairs) {
+            i1 = P.nn_idx[q];
+            i2 = has2 ? P.nn_idx[q2] : -1;
+        }
+        const Point4 s1 = P.src[q];
+        const Point4 s2 = P.src[has2 ? q2 : q];
+        Point4 g1, g2;
+        if (P.tgt_pairs) {
+            g1 = P.tgt_pairs[q];
+            g2 = P.tgt_pairs[has2 ? q2 : q];
+        } else {
+            g1 = P.pts[i1 < 0 ? 0 : i1];
+            g2 = P.pts[i2 < 0 ? 0 : i2];
+        }
+        accumulate(s1, g1, i1 >= 0);
+        accumulate(s2, g2, has2 && i2 >= 0);
     }
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
