@@ -1,30 +1,37 @@
 // Hand-written HIP kernels for gfx950 (CDNA4, wave64) — SAGE-ICP registration hot path.
+// One ICP iteration = k_group -> k_probe -> k_nn -> k_gn, all on one stream, no host round trip.
 //
 //   k_group  per query: apply the cumulative pose to the pristine frame (TransformPoints,
 //            reference core/Registration.cpp:103-111,133, fused: `source` is never rewritten in
 //            place), compute its home voxel with the reference's exact fp64 divide + truncation
 //            (core/VoxelHashMap.cpp:52-54) and cut the spatially sorted frame into GROUPS: runs
-//            of consecutive queries that share a home voxel (<= 32 long).  All queries of a
-//            group see the same 27-voxel candidate list.
-//   k_nn     one wavefront per group: lanes 0..26 probe the 27 neighbour voxels of the GPU-
-//            resident open-addressed hash in parallel, the occupied voxels' points are
+//            of consecutive queries that share a home voxel (<= 4 long by default).  All queries
+//            of a group see the same 27-voxel candidate list.  Also lists the groups whose cached
+//            probe-table row belongs to another voxel.
+//   k_probe  for those groups only: 27 lanes probe the GPU-resident open-addressed voxel hash
+//            (core/VoxelHashMap.cpp:66-78: 27 x map_.find), a 32-lane prefix sum turns the counts
+//            into candidate offsets.  Rows are reused across the iterations of a call.
+//   k_nn     one wavefront per chunk of queries: per group the occupied voxels' points are
 //            enumerated once in reference order (x outer, y, z inner, then insertion order) into
 //            an LDS candidate list, and the (query x candidate) pairs are spread over the 64
 //            lanes — W = 64 / pow2(group size) lanes per query, each lane striding the list —
 //            followed by a W-lane argmin.  Replaces VoxelHashMap::GetCorrespondences' per-point
-//            lambda (core/VoxelHashMap.cpp:51-96) and its acceptance test (:109-115).
-//   k_gn     robust-weighted point-to-point Gauss-Newton accumulation (Registration.cpp:62-90) as
-//            16 closed-form fp64 sums + count, wave-shuffle -> LDS -> one partial per workgroup.
-//   k_fin    fixed-order reduction of the workgroup partials, 6x6 LDL^T solve, SE3 exp, pose
-//            composition and the convergence test (Registration.cpp:92-93,135-137), all on device
-//            so the host never round-trips inside the ICP loop.
+//            lambda (core/VoxelHashMap.cpp:51-96).
+//   k_gn     acceptance test (core/VoxelHashMap.cpp:109-115) + robust-weighted point-to-point
+//            Gauss-Newton accumulation (Registration.cpp:62-90) as 16 closed-form fp64 sums +
+//            count, wave-shuffle -> LDS -> one partial per workgroup; the last-arriving workgroup
+//            then finishes the iteration: fixed-order reduction of the partials, 6x6 LDL^T solve,
+//            SE3 exp, pose composition and the convergence test (Registration.cpp:92-93,135-137).
+//   k_fin    the same finish as its own launch (multi-GPU: after the RCCL all-reduce).
 //   k_tf     TransformPoints for the stand-alone API entry (Registration.cpp:103-111).
+//   k_scatter_points / k_scatter_slots   refresh of the HBM mirror of the host map.
 //
 // Roofline: HBM-bound integer/byte + fp64 compare work (~0.1 flop/B) — no MFMA (a 6x6 outer
 // product sum is not a dense contraction).  What matters here is coalescing (a voxel block is
 // one contiguous run of 32-B records; identical addresses across the lanes of a group collapse
-// into one request), LDS staging of the candidate enumeration, enough loads in flight per wave
-// (the pair loop is unrolled 4x) and wave-uniform control flow.
+// into one request), LDS staging of the candidate enumeration, wave-uniform branch-free inner
+// loops (one scalar unit per CU), no device-scope atomics on hot words, and load balance by
+// hardware dispatch of many small workgroups.
 //
 // Built with -ffp-contract=off: distances are the plain IEEE sequence
 // dx*dx + (dy*dy + dz*dz) the CPU evaluates, so the argmin is index-exact against the oracle.
