@@ -1,0 +1,95 @@
+"""KITTI-format readers/writers on synthetic SemanticKITTI-format files."""
+import os
+
+import numpy as np
+import pytest
+
+
+def _rodrigues(axis, angle):
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0.0]])
+    return np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * (K @ K)
+
+
+def test_correct_kitti_scan_is_a_rotation_about_p_cross_z(sage):
+    from sage_icp_amd import kitti_io
+    rng = np.random.default_rng(1)
+    p = rng.normal(size=(200, 3)) * 30
+    p[0] = [0.0, 0.0, 5.0]                       # on the z axis: no rotation axis, left unchanged
+    out = kitti_io.correct_kitti_scan(p)
+    assert np.array_equal(out[0], p[0])
+    for a, b in zip(p[1:], out[1:]):
+        axis = np.cross(a, [0, 0, 1.0])
+        axis /= np.linalg.norm(axis)
+        assert np.allclose(b, _rodrigues(axis, 0.205 * np.pi / 180) @ a, atol=1e-12)
+    assert np.allclose(np.linalg.norm(out, axis=1), np.linalg.norm(p, axis=1), rtol=1e-13)
+    # the correction tilts points up by 0.205 deg for positive ranges
+    el_in = np.arctan2(p[1:, 2], np.hypot(p[1:, 0], p[1:, 1]))
+    el_out = np.arctan2(out[1:, 2], np.hypot(out[1:, 0], out[1:, 1]))
+    assert np.allclose(np.abs(el_out - el_in), 0.205 * np.pi / 180, atol=1e-9)
+
+
+def test_sequence_roundtrip_and_label_wrap(tmp_path, sage):
+    from sage_icp_amd import kitti_io, synthetic as syn
+    frames, _ = syn.make_stream(3, 3, points_per_frame=2000)
+    frames[1][:5, 3] = [252, 253, 256, 259, 65535 + 1 + 40]     # moving classes / instance bits
+    kitti_io.write_sequence(str(tmp_path), frames)
+    vel, lab = kitti_io.list_sequence(str(tmp_path))
+    assert len(vel) == len(lab) == 3
+    ts = kitti_io.read_timestamps(os.path.join(tmp_path, "times.txt"))
+    assert ts[0] == 0.0001 and np.allclose(ts[1:], [0.1, 0.2])   # 0.0 -> 0.0001 (kitti_pub.py:118-119)
+    f1 = kitti_io.load_frame(vel[1], lab[1], correct=False)
+    assert f1.dtype == np.float64 and np.array_equal(f1[:, :3], frames[1][:, :3])
+    # & 0xFFFF then uint8: 252 -> 252, 256 -> 0, 259 -> 3, instance bits dropped
+    assert list(f1[:5, 3]) == [252, 253, 0, 3, 40]
+    f1c = kitti_io.load_frame(vel[1], lab[1], correct=True)
+    assert np.array_equal(f1c[:, :3], f1c[:, :3].astype(np.float32).astype(np.float64))
+    assert not np.array_equal(f1c[:, :3], f1[:, :3])
+    with pytest.raises(ValueError):
+        np.zeros(7, dtype=np.int32).tofile(lab[2])
+        kitti_io.load_frame(vel[2], lab[2])
+
+
+def test_tum_and_gt_pose_conversion(tmp_path, sage):
+    from sage_icp_amd import kitti_io, synthetic as syn
+    poses = np.array([syn.pose_from_rpy_t([1, 2, 30 * k], [k, 2 * k, 0.1 * k]) for k in range(4)])
+    path = os.path.join(tmp_path, "path.txt")
+    kitti_io.write_tum(path, [0.1 * k for k in range(4)], poses)
+    first = open(path).readline().split()
+    assert len(first) == 8 and float(first[0]) == 0.0
+    ts, back = kitti_io.read_tum(path)
+    assert np.allclose(back, poses, atol=1e-8) and np.allclose(ts, [0, 0.1, 0.2, 0.3])
+    # calib + poses: Tr^-1 P Tr
+    Tr = np.eye(4)
+    Tr[:3, :3] = [[0, -1, 0], [0, 0, -1], [1, 0, 0]]
+    Tr[:3, 3] = [0.1, -0.2, 0.3]
+    with open(os.path.join(tmp_path, "calib.txt"), "w") as f:
+        f.write("P0: 1 0 0 0 0 1 0 0 0 0 1 0\n")
+        f.write("Tr: " + " ".join("%.9g" % v for v in Tr[:3, :4].ravel()) + "\n")
+    P = np.eye(4)
+    P[:3, 3] = [1.0, 2.0, 3.0]
+    with open(os.path.join(tmp_path, "poses.txt"), "w") as f:
+        f.write(" ".join("%.9g" % v for v in P[:3, :4].ravel()) + "\n")
+    Tr_read = kitti_io.read_calib_tr(os.path.join(tmp_path, "calib.txt"))
+    assert np.allclose(Tr_read, Tr)
+    gt = kitti_io.read_poses_file(os.path.join(tmp_path, "poses.txt"), Tr_read)
+    assert np.allclose(gt[0], np.linalg.inv(Tr) @ P @ Tr)
+
+
+@pytest.mark.gpu
+def test_kitti_format_stream_through_pipeline(tmp_path, gpu_sage, oracle):
+    """files -> reader -> pipeline on the GPU, vs the oracle pipeline fed by the same reader"""
+    from sage_icp_amd import kitti_io, synthetic as syn
+    frames, _ = syn.make_stream(5, 5, points_per_frame=20000)
+    kitti_io.write_sequence(str(tmp_path), frames)
+    vel, lab = kitti_io.list_sequence(str(tmp_path))
+    cfg = gpu_sage.make_pipeline_config()
+    a, b = gpu_sage.SageICP(cfg), oracle.Pipeline(cfg)
+    for v, l in zip(vel, lab):
+        f = kitti_io.load_frame(v, l, correct=False)
+        pa = a.RegisterFrame(f)[0]
+        pb = b.register_frame(f)[0]
+        e = oracle.se3_log(oracle.se3_mul(oracle.se3_inv(pb), pa))
+        assert np.linalg.norm(e[:3]) < 1e-6 and np.linalg.norm(e[3:]) < 1e-6
+    out = os.path.join(tmp_path, "path.txt")
+    kitti_io.write_tum(out, kitti_io.read_timestamps(os.path.join(tmp_path, "times.txt")), a.poses())
+    assert len(open(out).readlines()) == 5
