@@ -137,6 +137,20 @@ sageicp_comm *sageicp_comm_create(const uint8_t id[SAGEICP_UNIQUE_ID_BYTES], int
                                   int device);
 void sageicp_comm_destroy(sageicp_comm *comm);
 
+/* ---- Preprocess / VoxelDownsample (core/Preprocessing.hpp:33-45) on the device ------------------
+ * sageicp_preprocess: core/Preprocessing.cpp:173-187 (dynamic_vehicle_filter == false): keep points
+ * with min_range < |p| < max_range, zero the label beyond label_max_range; order preserved.
+ * sageicp_voxel_downsample: core/Preprocessing.cpp:44-84: per label group g, the first point that
+ * falls into a voxel of size group_voxel_size[g] * vox_scale is kept; points whose label is in no
+ * group are dropped.  Output is group by group in input order (the reference: hash-map order).
+ * out: capacity n*4 doubles.  At most 8 groups; voxel indices must fit +-2^19. */
+int sageicp_preprocess(const double *frame_xyzl, uint64_t n, double max_range, double min_range,
+                       double label_max_range, double *out_xyzl, uint64_t *n_out, int device);
+int sageicp_voxel_downsample(const double *frame_xyzl, uint64_t n, int n_groups,
+                             const int *group_label_counts, const int *group_labels,
+                             const double *group_voxel_size, double vox_scale, double *out_xyzl,
+                             uint64_t *n_out, int device);
+
 /* ---- per-frame pipeline counterpart: sage_icp::pipeline::sageICP (pipeline/sageICP.{hpp,cpp}) --
  * Host-side orchestration around the hot path for a stream of scans:
  * range crop + label zeroing (core/Preprocessing.cpp:173-187), two-level semantic voxel

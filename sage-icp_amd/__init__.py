@@ -139,6 +139,11 @@ _SIGNATURES = [
     ("sageicp_comm_unique_id", C.c_int, [_u8p]),
     ("sageicp_comm_create", C.c_void_p, [_u8p, C.c_int, C.c_int, C.c_int]),
     ("sageicp_comm_destroy", None, [C.c_void_p]),
+    ("sageicp_preprocess", C.c_int,
+     [_dp, C.c_uint64, C.c_double, C.c_double, C.c_double, _dp, _u64p, C.c_int]),
+    ("sageicp_voxel_downsample", C.c_int,
+     [_dp, C.c_uint64, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
+      C.c_double, _dp, _u64p, C.c_int]),
     ("sageicp_pipeline_create", C.c_void_p, [C.POINTER(PipelineConfig)]),
     ("sageicp_pipeline_destroy", None, [C.c_void_p]),
     ("sageicp_pipeline_register_frame", C.c_int,
@@ -399,3 +404,29 @@ class SageICP:
         out = np.empty((n, 4))
         lib().sageicp_map_pointcloud(h, out.ctypes.data_as(_dp), n)
         return out
+
+
+def preprocess(frame, max_range, min_range, label_max_range, device=0):
+    """sage_icp::Preprocess with dynamic_vehicle_filter off (core/Preprocessing.cpp:173-187)"""
+    pts, pp = _d(frame)
+    n = pts.reshape(-1, 4).shape[0]
+    out = np.empty((n, 4))
+    k = C.c_uint64(0)
+    _check(lib().sageicp_preprocess(pp, n, max_range, min_range, label_max_range,
+                                    out.ctypes.data_as(_dp), C.byref(k), device))
+    return out[:k.value].copy()
+
+
+def voxel_downsample(frame, voxel_labels, voxel_size, vox_scale, device=0):
+    """sage_icp::VoxelDownsample (core/Preprocessing.cpp:44-84)"""
+    pts, pp = _d(frame)
+    n = pts.reshape(-1, 4).shape[0]
+    counts = (C.c_int * len(voxel_labels))(*[len(g) for g in voxel_labels])
+    flat = [l for g in voxel_labels for l in g]
+    labels = (C.c_int * max(len(flat), 1))(*flat)
+    sizes = (C.c_double * len(voxel_size))(*voxel_size)
+    out = np.empty((n, 4))
+    k = C.c_uint64(0)
+    _check(lib().sageicp_voxel_downsample(pp, n, len(voxel_labels), counts, labels, sizes, vox_scale,
+                                          out.ctypes.data_as(_dp), C.byref(k), device))
+    return out[:k.value].copy()

@@ -201,6 +201,154 @@ struct Scratch {
     }
 };
 
+
+// ---- device preprocessing (preprocess.hip): buffers of one pipeline ------------------------------
+struct Prep {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    size_t cap = 0;                     // points
+    Point4 *d_in = nullptr, *d_tmp = nullptr, *d_fd = nullptr, *d_src = nullptr;
+    uint32_t *d_slot = nullptr, *d_skey = nullptr, *d_sval = nullptr, *d_winner = nullptr;
+    unsigned long long *d_keys = nullptr;
+    uint32_t table_cap = 0;
+    void *d_sort_temp = nullptr;
+    size_t sort_bytes = 0;
+    uint32_t *d_nkept = nullptr;        // [2]
+    int *d_overflow = nullptr;
+    int *d_gcounts = nullptr, *d_glabels = nullptr;
+    size_t glabels_cap = 0;
+    void *h_pin = nullptr;              // pinned staging for the raw frame and the results
+    size_t pin_bytes = 0;
+
+    int init(int dev) {
+        if (stream) return SAGEICP_OK;
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+            return fail(SAGEICP_ERR_NO_DEVICE, "no HIP device visible (gfx950 required; no CPU fallback)");
+        if (dev < 0 || dev >= count) return fail(SAGEICP_ERR_INVALID, "device ordinal out of range");
+        device = dev;
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIPCHK(hipMalloc(&d_nkept, 2 * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&d_overflow, sizeof(int)));
+        HIPCHK(hipMalloc(&d_gcounts, 8 * sizeof(int)));
+        return SAGEICP_OK;
+    }
+    int reserve(size_t n, size_t nlabels) {
+        if (nlabels > glabels_cap) {
+            if (d_glabels) HIPCHK(hipFree(d_glabels));
+            d_glabels = nullptr;
+            HIPCHK(hipMalloc(&d_glabels, (nlabels + 16) * sizeof(int)));
+            glabels_cap = nlabels + 16;
+        }
+        if (n <= cap) return SAGEICP_OK;
+        free_points();
+        const size_t c = n + n / 4 + 1024;
+        uint32_t t = 1024;
+        while (t < 2 * c) t <<= 1;
+        HIPCHK(hipMalloc(&d_in, c * sizeof(Point4)));
+        HIPCHK(hipMalloc(&d_tmp, c * sizeof(Point4)));
+        HIPCHK(hipMalloc(&d_fd, c * sizeof(Point4)));
+        HIPCHK(hipMalloc(&d_src, c * sizeof(Point4)));
+        HIPCHK(hipMalloc(&d_slot, c * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&d_skey, 2 * c * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&d_sval, 2 * c * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&d_keys, static_cast<size_t>(t) * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc(&d_winner, static_cast<size_t>(t) * sizeof(uint32_t)));
+        table_cap = t;
+        sort_bytes = vds_sort_temp_bytes(static_cast<int>(c));
+        HIPCHK(hipMalloc(&d_sort_temp, sort_bytes));
+        HIPCHK(hipHostMalloc(&h_pin, 3 * c * sizeof(Point4), hipHostMallocDefault));
+        pin_bytes = 3 * c * sizeof(Point4);
+        cap = c;
+        return SAGEICP_OK;
+    }
+    void free_points() {
+        if (d_in) (void)hipFree(d_in);
+        if (d_tmp) (void)hipFree(d_tmp);
+        if (d_fd) (void)hipFree(d_fd);
+        if (d_src) (void)hipFree(d_src);
+        if (d_slot) (void)hipFree(d_slot);
+        if (d_skey) (void)hipFree(d_skey);
+        if (d_sval) (void)hipFree(d_sval);
+        if (d_keys) (void)hipFree(d_keys);
+        if (d_winner) (void)hipFree(d_winner);
+        if (d_sort_temp) (void)hipFree(d_sort_temp);
+        if (h_pin) (void)hipHostFree(h_pin);
+        d_in = d_tmp = d_fd = d_src = nullptr;
+        d_slot = d_skey = d_sval = d_winner = nullptr;
+        d_keys = nullptr; d_sort_temp = nullptr; h_pin = nullptr;
+        cap = 0;
+    }
+    void destroy() {
+        if (!stream) return;
+        (void)hipSetDevice(device);
+        (void)hipStreamSynchronize(stream);
+        free_points();
+        if (d_nkept) (void)hipFree(d_nkept);
+        if (d_overflow) (void)hipFree(d_overflow);
+        if (d_gcounts) (void)hipFree(d_gcounts);
+        if (d_glabels) (void)hipFree(d_glabels);
+        (void)hipStreamDestroy(stream);
+        *this = Prep();
+    }
+
+    // levels: each {do_crop, scale}; a scale <= 0 means "crop only" (no voxel test).  Runs the
+    // levels in sequence on the device, each feeding the next, and returns every level's cloud.
+    int run(const double *frame, uint64_t n, double max_range, double min_range,
+            double label_max_range, int n_groups, const int *gcounts, const int *glabels,
+            const double *gvs, const int *crop, const double *scales, int n_levels,
+            std::vector<std::vector<double>> &out) {
+        if (n > kMaxQueries) return fail(SAGEICP_ERR_INVALID, "frame too large (2^26 points max)");
+        if (n_groups > 8) return fail(SAGEICP_ERR_INVALID, "at most 8 label groups");
+        size_t nlabels = 0;
+        for (int g = 0; g < n_groups; ++g) nlabels += static_cast<size_t>(gcounts[g]);
+        int rc = reserve(n, nlabels);
+        if (rc) return rc;
+        HIPCHK(hipSetDevice(device));
+        out.assign(n_levels, std::vector<double>());
+        if (n == 0) return SAGEICP_OK;
+        if (n_groups > 0) {
+            HIPCHK(hipMemcpyAsync(d_gcounts, gcounts, n_groups * sizeof(int), hipMemcpyHostToDevice, stream));
+            HIPCHK(hipMemcpyAsync(d_glabels, glabels, nlabels * sizeof(int), hipMemcpyHostToDevice, stream));
+        }
+        HIPCHK(hipMemsetAsync(d_overflow, 0, sizeof(int), stream));
+        std::memcpy(h_pin, frame, n * sizeof(Point4));
+        HIPCHK(hipMemcpyAsync(d_in, h_pin, n * sizeof(Point4), hipMemcpyHostToDevice, stream));
+        const Point4 *in = d_in;
+        Point4 *outs[2] = {d_fd, d_src};
+        uint64_t cur = n;
+        for (int l = 0; l < n_levels; ++l) {
+            VdsParams P{};
+            P.in = in; P.n = static_cast<int>(cur); P.do_crop = crop[l];
+            P.max_range = max_range; P.min_range = min_range; P.label_max_range = label_max_range;
+            P.n_groups = scales[l] > 0.0 ? n_groups : -1;
+            P.group_counts = d_gcounts; P.group_labels = d_glabels;
+            for (int g = 0; g < n_groups; ++g) P.group_vs[g] = gvs[g];
+            P.scale = scales[l];
+            P.keys = d_keys; P.winner = d_winner; P.mask = table_cap - 1;
+            P.tmp = d_tmp; P.slot_of = d_slot; P.sort_key = d_skey; P.sort_val = d_sval;
+            P.overflow = d_overflow;
+            Point4 *dst = outs[l & 1];
+            HIPCHK(voxel_downsample_device(P, d_sort_temp, sort_bytes, d_nkept + (l & 1), dst, stream));
+            uint32_t kept = 0;
+            HIPCHK(hipMemcpyAsync(&kept, d_nkept + (l & 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            char *hp = static_cast<char *>(h_pin) + static_cast<size_t>(1 + (l & 1)) * cap * sizeof(Point4);
+            if (kept) HIPCHK(hipMemcpyAsync(hp, dst, kept * sizeof(Point4), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            out[l].resize(4 * static_cast<size_t>(kept));
+            if (kept) std::memcpy(out[l].data(), hp, kept * sizeof(Point4));
+            in = dst;
+            cur = kept;
+        }
+        int ovf = 0;
+        HIPCHK(hipMemcpy(&ovf, d_overflow, sizeof(int), hipMemcpyDeviceToHost));
+        if (ovf) return fail(SAGEICP_ERR_CAPACITY, "voxel index beyond +-2^19 in VoxelDownsample");
+        return SAGEICP_OK;
+    }
+};
+
 }  // namespace sageicp
 
 using namespace sageicp;
@@ -832,10 +980,53 @@ void sageicp_comm_destroy(sageicp_comm *c) {
     delete c;
 }
 
+// ---- Preprocess / VoxelDownsample on the device --------------------------------------------------
+int sageicp_preprocess(const double *frame, uint64_t n, double max_range, double min_range,
+                       double label_max_range, double *out, uint64_t *n_out, int device) {
+    if (!n_out || (n && (!frame || !out))) return fail(SAGEICP_ERR_INVALID, "null argument");
+    Prep pr;
+    int rc = pr.init(device);
+    if (rc) return rc;
+    std::vector<std::vector<double>> res;
+    const int crop = 1;
+    const double scale = 0.0;       // crop only
+    rc = pr.run(frame, n, max_range, min_range, label_max_range, 0, nullptr, nullptr, nullptr, &crop,
+                &scale, 1, res);
+    pr.destroy();
+    if (rc) return rc;
+    *n_out = res[0].size() / 4;
+    if (!res[0].empty()) std::memcpy(out, res[0].data(), res[0].size() * sizeof(double));
+    return SAGEICP_OK;
+}
+
+int sageicp_voxel_downsample(const double *frame, uint64_t n, int n_groups,
+                             const int *group_label_counts, const int *group_labels,
+                             const double *group_voxel_size, double vox_scale, double *out,
+                             uint64_t *n_out, int device) {
+    if (!n_out || (n && (!frame || !out)) || n_groups < 0 ||
+        (n_groups && (!group_label_counts || !group_labels || !group_voxel_size)) || !(vox_scale > 0.0))
+        return fail(SAGEICP_ERR_INVALID, "bad argument");
+    Prep pr;
+    int rc = pr.init(device);
+    if (rc) return rc;
+    std::vector<std::vector<double>> res;
+    const int crop = 0;
+    rc = pr.run(frame, n, 0, 0, 0, n_groups, group_label_counts, group_labels, group_voxel_size, &crop,
+                &vox_scale, 1, res);
+    pr.destroy();
+    if (rc) return rc;
+    *n_out = res[0].size() / 4;
+    if (!res[0].empty()) std::memcpy(out, res[0].data(), res[0].size() * sizeof(double));
+    return SAGEICP_OK;
+}
+
 // ---- pipeline counterpart -----------------------------------------------------------------------
 struct sageicp_pipeline {
     sageicp::Pipeline impl;
-    explicit sageicp_pipeline(const sageicp_pipeline_config &c) : impl(c) {}
+    sageicp::Prep prep;
+    int device;
+    explicit sageicp_pipeline(const sageicp_pipeline_config &c) : impl(c), device(c.device) {}
+    ~sageicp_pipeline() { prep.destroy(); }
 };
 
 sageicp_pipeline *sageicp_pipeline_create(const sageicp_pipeline_config *c) {
@@ -855,7 +1046,25 @@ int sageicp_pipeline_register_frame(sageicp_pipeline *p, const double *frame, ui
                                     double pose_out[7], double *icp_s, double *total_s,
                                     uint64_t *n_source, sageicp_stats *stats) {
     if (!p || !pose_out || (n && !frame)) return fail(SAGEICP_ERR_INVALID, "null argument");
-    return p->impl.register_frame(frame, n, pose_out, icp_s, total_s, n_source, stats);
+    int rc = p->prep.init(p->device);
+    if (rc) return rc;
+    // Preprocess + Voxelize on the device (preprocess.hip): crop + scale 0.5, then scale 1.5
+    auto voxelize = [&](const double *f, uint64_t m, std::vector<double> &fd, std::vector<double> &src) -> int {
+        std::vector<int> counts, labels;
+        std::vector<double> vs;
+        p->impl.group_tables(counts, labels, vs);
+        const int crop[2] = {1, 0};
+        const double scales[2] = {0.5, 1.5};
+        std::vector<std::vector<double>> res;
+        int r = p->prep.run(f, m, p->impl.max_range_(), p->impl.min_range_(), p->impl.label_max_range_(),
+                            static_cast<int>(counts.size()), counts.data(), labels.data(), vs.data(),
+                            crop, scales, 2, res);
+        if (r) return r;
+        fd.swap(res[0]);
+        src.swap(res[1]);
+        return SAGEICP_OK;
+    };
+    return p->impl.register_frame(frame, n, pose_out, icp_s, total_s, n_source, stats, voxelize);
 }
 int sageicp_pipeline_reinitialize(sageicp_pipeline *p) {
     if (!p) return fail(SAGEICP_ERR_INVALID, "null pipeline");

@@ -85,6 +85,30 @@ void launch_scatter_slots(const uint32_t *idx, const Slot *vals, uint32_t n, Slo
 int gn_grid_for(int n);
 unsigned nn_cand_stride(int cap);
 
+// preprocess.hip: one level of per-label-group voxel down-sampling (optionally with the range crop)
+struct VdsParams {
+    const Point4 *in;
+    int n;
+    int do_crop;                       // 1: apply Preprocess() first (range crop + label zeroing)
+    double max_range, min_range, label_max_range;
+    int n_groups;                      // -1: no grouping / no voxel test (crop only)
+    const int *group_counts;           // device: [n_groups]
+    const int *group_labels;           // device: concatenated label lists
+    double group_vs[8];                // voxel size per group
+    double scale;                      // vox_scale
+    unsigned long long *keys;          // device hash set: (group, voxel) keys, capacity mask + 1
+    uint32_t *winner;                  // lowest original index per key
+    uint32_t mask;
+    Point4 *tmp;                       // [n] cropped points
+    uint32_t *slot_of;                 // [n]
+    uint32_t *sort_key;                // [2n]
+    uint32_t *sort_val;                // [2n]
+    int *overflow;                     // set when a voxel index does not fit the key
+};
+size_t vds_sort_temp_bytes(int n);
+hipError_t voxel_downsample_device(const VdsParams &P, void *sort_temp, size_t sort_temp_bytes,
+                                   uint32_t *d_n_kept, Point4 *out, hipStream_t s);
+
 // sort.hip: re-ordering of a frame along the Morton curve of its map-frame voxels
 size_t sort_temp_bytes(int n);
 hipError_t sort_frame(const Point4 *d_in, Point4 *d_out, int n, const IcpState *st, bool apply_pose,

@@ -1,8 +1,8 @@
 // Per-frame pipeline counterpart: the host-side logic that decides the
-// ARGUMENTS of the hot path for a stream of scans — range crop, two-level semantic voxel
-// down-sampling, adaptive threshold, constant-velocity guess, map update.  Plain C++ on the
-// host (it is scalar bookkeeping plus O(N) hash inserts once per frame); the registration and
-// the map live behind the same C ABI the shims use.
+// ARGUMENTS of the hot path for a stream of scans — adaptive threshold, constant-velocity guess,
+// map update — around the device stages: range crop + two-level semantic voxel down-sampling
+// (preprocess.hip, f-3) and the registration itself.  The map lives behind the same C ABI the
+// shims use.
 //
 // Reference (cpp/sage_icp/):
 //   pipeline/sageICP.cpp:54-95     sageICP::RegisterFrame           -> Pipeline::register_frame
@@ -44,12 +44,6 @@ public:
             gl += c.group_label_counts[g];
             group_voxel.push_back(c.group_voxel_size[g]);
         }
-        for (int l = 0; l < 256; ++l) {
-            lut[l] = -1;
-            for (size_t g = 0; g < groups.size() && lut[l] < 0; ++g)
-                if (std::find(groups[g].begin(), groups[g].end(), l) != groups[g].end())
-                    lut[l] = static_cast<int>(g);
-        }
         map = sageicp_map_create(c.voxel_size_map, c.local_map_range, c.basic_points_per_voxel,
                                  c.critical_points_per_voxel, c.basic_parts_labels,
                                  c.n_basic_parts_labels, c.device);
@@ -70,14 +64,17 @@ public:
     }
 
     // pipeline/sageICP.cpp:54-95
+    // `voxelize(frame, n, frame_downsample, source)` is the device implementation of
+    // Preprocess() + Voxelize() (preprocess.hip; core/Preprocessing.cpp:173-187,44-84,
+    // pipeline/sageICP.cpp:57-67,97-101)
+    template <typename Voxelize>
     int register_frame(const double *frame, uint64_t n, double pose_out[7], double *icp_s,
-                       double *total_s, uint64_t *n_source, sageicp_stats *stats) {
+                       double *total_s, uint64_t *n_source, sageicp_stats *stats,
+                       Voxelize &&voxelize) {
         const auto t_pre = std::chrono::steady_clock::now();
-        std::vector<double> cropped;
-        preprocess(frame, n, cropped);
         std::vector<double> frame_downsample, source;
-        voxel_downsample(cropped, 0.5, frame_downsample);     // Voxelize(), sageICP.cpp:97-101
-        voxel_downsample(frame_downsample, 1.5, source);
+        int rc = voxelize(frame, n, frame_downsample, source);
+        if (rc) return rc;
         const double sigma = adaptive_threshold();
         Pose7 prediction;                                     // GetPredictionModel()
         const size_t N = poses.size();
@@ -92,7 +89,7 @@ public:
 
         const auto t_icp = std::chrono::steady_clock::now();
         Pose7 new_pose;
-        int rc = sageicp_register_frame(map, source.data(), source.size() / 4, guess.v, 3.0 * sigma,
+        rc = sageicp_register_frame(map, source.data(), source.size() / 4, guess.v, 3.0 * sigma,
                                         sigma / 3.0, sem_th, new_pose.v, stats);
         const auto t_end = std::chrono::steady_clock::now();
         if (rc) return rc;
@@ -114,65 +111,19 @@ public:
     std::vector<Pose7> poses;
     sageicp_map *map = nullptr;
 
+    // label groups as flat tables for the device kernels
+    void group_tables(std::vector<int> &counts, std::vector<int> &labels, std::vector<double> &vs) const {
+        counts.clear(); labels.clear(); vs = group_voxel;
+        for (const auto &g : groups) {
+            counts.push_back(static_cast<int>(g.size()));
+            labels.insert(labels.end(), g.begin(), g.end());
+        }
+    }
+    double max_range_() const { return max_range; }
+    double min_range_() const { return min_range; }
+    double label_max_range_() const { return label_max_range; }
+
 private:
-    // core/Preprocessing.cpp:173-187 (dynamic_vehicle_filter == false)
-    void preprocess(const double *f, uint64_t n, std::vector<double> &out) const {
-        out.reserve(4 * n);
-        for (uint64_t i = 0; i < n; ++i) {
-            const double *p = f + 4 * i;
-            const double norm = std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
-            if (norm < max_range && norm > min_range) {
-                out.insert(out.end(), {p[0], p[1], p[2], norm > label_max_range ? 0.0 : p[3]});
-            }
-        }
-    }
-
-    // label -> first group that lists it (Preprocessing.cpp:57-64), -1 if none
-    int group_of(int label) const {
-        if (label >= 0 && label < 256) return lut[label];
-        for (size_t g = 0; g < groups.size(); ++g)
-            if (std::find(groups[g].begin(), groups[g].end(), label) != groups[g].end())
-                return static_cast<int>(g);
-        return -1;
-    }
-
-    // core/Preprocessing.cpp:44-84: first point per voxel wins, one grid per label group.
-    // The grids are one flat open-addressed set keyed by (group, voxel): membership is all that
-    // is needed, and the kept points are emitted group by group in insertion order.
-    void voxel_downsample(const std::vector<double> &in, double scale, std::vector<double> &out) const {
-        const size_t G = groups.size();
-        const size_t n = in.size() / 4;
-        size_t capacity = 64;
-        while (capacity < 2 * n + 16) capacity <<= 1;
-        struct Key { int g, x, y, z; };
-        std::vector<Key> set(capacity, Key{-1, 0, 0, 0});
-        const size_t mask = capacity - 1;
-        std::vector<std::vector<double>> kept(G);
-        for (size_t g = 0; g < G; ++g) kept[g].reserve(in.size() / (G ? G : 1) + 64);
-        for (size_t i = 0; i < n; ++i) {
-            const double *p = &in[4 * i];
-            const int group = group_of(static_cast<int>(p[3]));
-            if (group < 0) continue;
-            const double vs = group_voxel[group] * scale;
-            const Key key{group, static_cast<int>(p[0] / vs), static_cast<int>(p[1] / vs),
-                          static_cast<int>(p[2] / vs)};
-            size_t s = (voxel_hash(key.x, key.y, key.z) + 0x9E3779B9u * static_cast<uint32_t>(group)) & mask;
-            bool present = false;
-            for (;;) {
-                const Key &e = set[s];
-                if (e.g < 0) break;
-                if (e.g == key.g && e.x == key.x && e.y == key.y && e.z == key.z) { present = true; break; }
-                s = (s + 1) & mask;
-            }
-            if (present) continue;
-            set[s] = key;
-            kept[group].insert(kept[group].end(), p, p + 4);
-        }
-        out.clear();
-        out.reserve(in.size());
-        for (size_t g = 0; g < G; ++g) out.insert(out.end(), kept[g].begin(), kept[g].end());
-    }
-
     // pipeline/sageICP.cpp:103-108,117-121 + core/Threshold.cpp:29-50
     double adaptive_threshold() {
         bool moved = false;
@@ -203,7 +154,6 @@ private:
     double min_motion_th, initial_threshold, sem_th;
     std::vector<std::vector<int>> groups;
     std::vector<double> group_voxel;
-    int lut[256];
     double model_error_sse2 = 0.0;
     int num_samples = 0;
     Pose7 model_deviation;

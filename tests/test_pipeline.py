@@ -2,10 +2,10 @@
 range crop, two-level semantic voxel down-sampling, adaptive threshold, constant-velocity guess,
 map update — in the product library vs its restatement in the oracle.
 
-CPU part: everything up to the first RegisterFrame against a non-empty map needs no device
-(the first frame registers against an empty map and returns the guess), so the preprocessing and
-map-update logic is compared on frame 0.  GPU part: a c3-style synthetic stream, per-frame pose
-parity with both sides restarted from the same state, and free-running."""
+Preprocess + VoxelDownsample run on the device (preprocess.hip, f-3), so every test here needs the
+GPU: the two kernels against a pure-Python restatement of core/Preprocessing.cpp, frame 0 of the
+pipeline (crop, down-sampling, map update) against the oracle pipeline, and a c3-style synthetic
+stream with per-frame pose parity, free-running."""
 import numpy as np
 import pytest
 
@@ -19,7 +19,9 @@ def _sorted(a):
     return a[np.lexsort(a.T)]
 
 
-def test_first_frame_preprocessing_and_map_update_match_oracle(sage, oracle):
+@pytest.mark.gpu
+def test_first_frame_preprocessing_and_map_update_match_oracle(gpu_sage, oracle):
+    sage = gpu_sage
     from sage_icp_amd import synthetic as syn
     frames, _ = syn.make_stream(7, 1, points_per_frame=40000)
     f = frames[0].copy()
@@ -45,7 +47,9 @@ def test_first_frame_preprocessing_and_map_update_match_oracle(sage, oracle):
     assert len(a.poses()) == 0 and len(a.LocalMap()) == 0
 
 
-def test_downsample_keeps_first_point_per_voxel_per_group(sage, oracle):
+@pytest.mark.gpu
+def test_downsample_keeps_first_point_per_voxel_per_group(gpu_sage, oracle):
+    sage = gpu_sage
     # two label groups with different voxel sizes; second point in the same voxel is dropped
     cfg = sage.make_pipeline_config(voxel_labels=[[40], [50]], voxel_size=[1.0, 4.0], min_range=0.1)
     pts = np.array([[10.1, 0.1, 0.1, 40], [10.2, 0.1, 0.1, 40], [10.9, 0.1, 0.1, 40],
@@ -87,3 +91,59 @@ def test_stream_pose_parity_restarted_and_free_running(gpu_sage, oracle):
     rel_true = oracle.se3_mul(oracle.se3_inv(truth[-2]), truth[-1])
     dt, dr = _pose_err(oracle, rel_true, rel_est)
     assert dt < 0.15 and dr < 0.01
+
+
+def _py_preprocess(frame, max_range, min_range, label_max_range):
+    out = []
+    for p in frame:
+        norm = float(np.sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]))
+        if norm < max_range and norm > min_range:
+            out.append([p[0], p[1], p[2], 0.0 if norm > label_max_range else p[3]])
+    return np.array(out).reshape(-1, 4)
+
+
+def _py_voxel_downsample(frame, voxel_labels, voxel_size, scale):
+    """core/Preprocessing.cpp:44-84 restated: first point per voxel per group; emitted group by
+    group in input order"""
+    grids = [dict() for _ in voxel_labels]
+    for p in frame:
+        label = int(p[3])
+        group = next((g for g, ls in enumerate(voxel_labels) if label in ls), -1)
+        if group < 0:
+            continue
+        vs = voxel_size[group] * scale
+        key = (int(p[0] / vs), int(p[1] / vs), int(p[2] / vs))
+        if key not in grids[group]:
+            grids[group][key] = p
+    out = [p for g in grids for p in g.values()]
+    return np.array(out).reshape(-1, 4)
+
+
+@pytest.mark.gpu
+def test_device_preprocess_matches_python(gpu_sage):
+    rng = np.random.default_rng(31)
+    f = rng.normal(size=(20000, 4)) * [40, 40, 3, 0]
+    f[:, 3] = rng.choice([0, 10, 40, 50, 70, 81, 252], size=len(f))
+    f[:4, :3] = [[5.0, 0, 0], [100.0, 0, 0], [0, 50.0, 0], [3.0, 4.0, 0]]     # on the thresholds
+    out = gpu_sage.preprocess(f, 100.0, 5.0, 50.0)
+    ref = _py_preprocess(f, 100.0, 5.0, 50.0)
+    assert np.array_equal(out, ref) and 0 < len(out) < len(f)
+    assert gpu_sage.preprocess(np.zeros((0, 4)), 100.0, 5.0, 50.0).shape == (0, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale", [0.5, 1.5])
+def test_device_voxel_downsample_matches_python(gpu_sage, scale):
+    from sage_icp_amd import synthetic as syn
+    frames, _ = syn.make_stream(33, 1, points_per_frame=60000)
+    f = frames[0]
+    f[::19, 3] = 77                                     # label of no group -> dropped
+    f[1::23, :3] *= -1.0                                # negative coordinates: trunc toward zero
+    labels, sizes = gpu_sage.KITTI_VOXEL_LABELS, gpu_sage.KITTI_VOXEL_SIZE
+    out = gpu_sage.voxel_downsample(f, labels, sizes, scale)
+    ref = _py_voxel_downsample(f, labels, sizes, scale)
+    assert len(ref) > 1000 and out.shape == ref.shape
+    assert np.array_equal(out, ref), "same survivors in the same (group, input) order"
+    # every point in one voxel: a single survivor, the first
+    one = np.tile([[0.31, 0.32, 0.33, 40.0]], (500, 1)) + np.arange(500)[:, None] * [1e-6, 0, 0, 0]
+    assert np.array_equal(gpu_sage.voxel_downsample(one, [[40]], [1.0], 1.0), one[:1])
