@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <vector>
 
+#include "sage_icp/core/Preprocessing.hpp"
 #include "sage_icp/core/Registration.hpp"
 #include "sage_icp/core/VoxelHashMap.hpp"
 
@@ -35,6 +36,13 @@ int main() {
         Sophus::SE3d pose = sage_icp::RegisterFrame(pts, c, guess, 6.0, 0.6, 0.4);
         (void)pose;
         sage_icp::TransformPoints(T, pts);
+        // Voxelize() as pipeline/sageICP.cpp:97-101 calls it
+        const std::vector<std::vector<int>> labels = {{40, 44}, {50}};
+        const std::vector<double> sizes = {0.5, 1.0};
+        auto down = sage_icp::VoxelDownsample(pts, labels, sizes, 0.5);
+        if (down.empty() || down.size() > pts.size()) return 6;
+        auto crop = sage_icp::Preprocess(pts, 100.0, 0.05, 50.0, false, 0.5, {10}, {44, 48});
+        if (crop.empty() || crop.size() > pts.size()) return 7;
     }
     std::puts("shim ok");
     return 0;
