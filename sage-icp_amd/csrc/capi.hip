@@ -85,7 +85,7 @@ struct Scratch {
     void *d_sort_temp = nullptr; size_t sort_cap = 0; size_t sort_temp_bytes_ = 0;
     // per-iteration work buffers: transformed queries and the group list (k_group)
     Point4 *d_src = nullptr; int4 *d_groups = nullptr; uint2 *d_blks = nullptr;
-    int4 *d_tabkey = nullptr; unsigned *d_need_cnt = nullptr; unsigned *d_need_list = nullptr;
+    int4 *d_tabkey = nullptr;
     double *d_partials = nullptr;
     unsigned long long *d_cand = nullptr;      // per-chunk candidate counters of k_nn [sort_cap]
     IcpState *d_state = nullptr;
@@ -144,9 +144,7 @@ struct Scratch {
         if (d_groups) HIPCHK(hipFree(d_groups));
         if (d_blks) HIPCHK(hipFree(d_blks));
         if (d_tabkey) HIPCHK(hipFree(d_tabkey));
-        if (d_need_cnt) HIPCHK(hipFree(d_need_cnt));
-        if (d_need_list) HIPCHK(hipFree(d_need_list));
-        d_blks = nullptr; d_tabkey = nullptr; d_need_cnt = nullptr; d_need_list = nullptr;
+        d_blks = nullptr; d_tabkey = nullptr;
         d_sorted = nullptr; d_keys = d_vals = nullptr; d_sort_temp = nullptr; sort_cap = 0;
         d_src = nullptr; d_groups = nullptr;
         const size_t cap = n + n / 4 + 1024;
@@ -155,8 +153,6 @@ struct Scratch {
         HIPCHK(hipMalloc(&d_groups, cap * sizeof(int4)));
         HIPCHK(hipMalloc(&d_blks, cap * 32 * sizeof(uint2)));
         HIPCHK(hipMalloc(&d_tabkey, cap * sizeof(int4)));
-        HIPCHK(hipMalloc(&d_need_cnt, (cap / 64 + 2) * sizeof(unsigned)));
-        HIPCHK(hipMalloc(&d_need_list, (cap / 64 + 2) * 64 * sizeof(unsigned)));
         if (d_cand) HIPCHK(hipFree(d_cand));
         d_cand = nullptr;
         HIPCHK(hipMalloc(&d_cand, cap * sizeof(unsigned long long)));
@@ -190,8 +186,6 @@ struct Scratch {
         if (d_groups) (void)hipFree(d_groups);
         if (d_blks) (void)hipFree(d_blks);
         if (d_tabkey) (void)hipFree(d_tabkey);
-        if (d_need_cnt) (void)hipFree(d_need_cnt);
-        if (d_need_list) (void)hipFree(d_need_list);
         if (d_partials) (void)hipFree(d_partials);
         if (d_state) (void)hipFree(d_state);
         if (d_cand) (void)hipFree(d_cand);
@@ -537,9 +531,8 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     }
 
     GroupParams grp{d_frame, static_cast<int>(n), sc.d_state, m->host.voxel_size, sc.d_src,
-                    sc.d_groups, group_cap() - 1, sc.d_tabkey, sc.d_need_cnt, sc.d_need_list};
-    ProbeParams pp{sc.d_state, 1, sc.d_groups, static_cast<int>(n), m->d_table, m->host.mask,
-                   m->host.cap, sc.d_blks, sc.d_tabkey, sc.d_need_cnt, sc.d_need_list};
+                    sc.d_groups, group_cap() - 1, sc.d_tabkey, m->d_table, m->host.mask,
+                    m->host.cap, sc.d_blks};
     // no cached probe-table row is valid for a new call (0x7F7F7F7F is not a reachable voxel index)
     HIPCHK(hipMemsetAsync(sc.d_tabkey, 0x7F, (n + 1) * sizeof(int4), s));
     NnParams np{sc.d_src, static_cast<int>(n), sc.d_state, 1, sc.d_groups,
@@ -561,7 +554,6 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
             // ~1 us of stream time); level 2: around every kernel
             if (prof2) HIPCHK(hipEventRecord(sc.events[5 * k + 0], s));
             launch_group(grp, true, s);
-            launch_probe(pp, static_cast<int>(n), s);
             if (prof) HIPCHK(hipEventRecord(sc.events[5 * k + 1], s));
             launch_nn(np, s);
             if (prof) HIPCHK(hipEventRecord(sc.events[5 * k + 2], s));
@@ -760,12 +752,10 @@ int sageicp_get_correspondences(const sageicp_map *m, const double *q, uint64_t 
                       m->host.voxel_size, sc.d_keys, sc.d_vals, sc.d_sort_temp, sc.sort_temp_bytes_,
                       s));
     GroupParams grp{sc.d_sorted, static_cast<int>(n), sc.d_state, m->host.voxel_size, sc.d_src,
-                    sc.d_groups, group_cap() - 1, sc.d_tabkey, sc.d_need_cnt, sc.d_need_list};
-    ProbeParams pp{sc.d_state, 0, sc.d_groups, static_cast<int>(n), m->d_table, m->host.mask,
-                   m->host.cap, sc.d_blks, sc.d_tabkey, sc.d_need_cnt, sc.d_need_list};
+                    sc.d_groups, group_cap() - 1, sc.d_tabkey, m->d_table, m->host.mask,
+                    m->host.cap, sc.d_blks};
     HIPCHK(hipMemsetAsync(sc.d_tabkey, 0x7F, (n + 1) * sizeof(int4), s));
     launch_group(grp, false, s);
-    launch_probe(pp, static_cast<int>(n), s);
     NnParams np{sc.d_src, static_cast<int>(n), sc.d_state, 0, sc.d_groups,
                 static_cast<unsigned>(group_cap()), sc.d_blks, m->d_pts, m->host.cap,
                 nn_cand_stride(m->host.cap), sem_th, sc.d_nn, nullptr};

@@ -16,23 +16,11 @@ struct GroupParams {
     int4 *groups;             // out: one record per query slot: {start | len << 26, kx, ky, kz}
                               //      at a group's head query, x = -1 elsewhere
     int group_mask;           // group cap - 1 (cap is a power of two <= 32)
-    const int4 *tabkey;       // home voxel each cached probe-table row was built for
-    unsigned *need_cnt;       // out: [ceil(n/64)] stale rows per wave
-    unsigned *need_list;      // out: [ceil(n/64)][64] their slots
-};
-
-struct ProbeParams {
-    const IcpState *st;
-    int check_done;
-    const int4 *groups;
-    int n;                    // slots (== queries)
-    const Slot *table;
+    int4 *tabkey;             // [n] home voxel each cached probe-table row was built for (y, z, w)
+    const Slot *table;        // the open-addressed voxel hash
     uint32_t mask;
     int cap;
-    uint2 *blks;              // out: [n][32] {candidate offset, first point} per neighbour voxel
-    int4 *tabkey;             // [n] home voxel each row was built for (y, z, w), reset per call
-    const unsigned *need_cnt; // k_group's per-wave lists of stale rows
-    const unsigned *need_list;
+    uint2 *blks;              // [n][32] probe-table rows {candidate offset, first point}
 };
 
 struct NnParams {
@@ -72,7 +60,6 @@ constexpr int kMaxGnBlocks = 512;
 constexpr uint64_t kMaxQueries = (1ull << 26) - 1;   // group record packs start into 26 bits
 
 void launch_group(const GroupParams &p, bool apply_pose, hipStream_t s);
-void launch_probe(const ProbeParams &p, int n, hipStream_t s);
 void launch_nn(const NnParams &p, hipStream_t s);
 int launch_gn(const GnParams &p, hipStream_t s);   // returns the number of partials written
 void launch_fin(IcpState *st, const double *partials, int nparts, int mode, int standalone,

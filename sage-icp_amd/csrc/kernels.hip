@@ -1,16 +1,16 @@
 // Hand-written HIP kernels for gfx950 (CDNA4, wave64) — SAGE-ICP registration hot path.
-// One ICP iteration = k_group -> k_probe -> k_nn -> k_gn, all on one stream, no host round trip.
+// One ICP iteration = k_group -> k_nn -> k_gn, all on one stream, no host round trip.
 //
 //   k_group  per query: apply the cumulative pose to the pristine frame (TransformPoints,
 //            reference core/Registration.cpp:103-111,133, fused: `source` is never rewritten in
 //            place), compute its home voxel with the reference's exact fp64 divide + truncation
 //            (core/VoxelHashMap.cpp:52-54) and cut the spatially sorted frame into GROUPS: runs
 //            of consecutive queries that share a home voxel (<= 4 long by default).  All queries
-//            of a group see the same 27-voxel candidate list.  Also lists the groups whose cached
-//            probe-table row belongs to another voxel.
-//   k_probe  for those groups only: 27 lanes probe the GPU-resident open-addressed voxel hash
-//            (core/VoxelHashMap.cpp:66-78: 27 x map_.find), a 32-lane prefix sum turns the counts
-//            into candidate offsets.  Rows are reused across the iterations of a call.
+//            of a group see the same 27-voxel candidate list.  For the groups whose cached
+//            probe-table row belongs to another voxel, 27 lanes probe the GPU-resident
+//            open-addressed voxel hash (core/VoxelHashMap.cpp:66-78: 27 x map_.find) and a 32-lane
+//            prefix sum turns the counts into candidate offsets; rows are reused across the
+//            iterations of a call.
 //   k_nn     one wavefront per chunk of queries: per group the occupied voxels' points are
 //            enumerated once in reference order (x outer, y, z inner, then insertion order) into
 //            an LDS candidate list, and the (query x candidate) pairs are spread over the 64
@@ -90,85 +90,90 @@ __global__ __launch_bounds__(256) void k_group(GroupParams P) {
     const bool head = valid && ((lane & P.group_mask) == 0 || kx != pkx || ky != pky || kz != pkz);
     const unsigned long long heads = __ballot(head);
     const unsigned long long live = __ballot(valid);
-    if (!valid) return;
+    if (live == 0) return;
 
     // Slot space: the record of a group lives at its head query's own index, every other slot is
-    // marked invalid.  No atomics, no compaction: k_probe and k_nn walk the slots in query order,
-    // so the work per wave is balanced by query count and each XCD's contiguous eighth of the
-    // (spatially sorted) slots is one compact region of the map.
-    int4 rec;
-    rec.x = -1; rec.y = kx; rec.z = ky; rec.w = kz;
-    if (head) {
-        // length: distance to the next head, the end of this chunk or the end of the frame
-        const unsigned long long above = (lane == 63) ? 0ull : (heads >> (lane + 1)) << (lane + 1);
-        int end = above ? __builtin_ctzll(above) : 64;
-        end = min(end, (lane | P.group_mask) + 1);
-        end = min(end, 64 - __builtin_clzll(live));
-        rec.x = q | ((end - lane) << 26);      // start (26 bits) | length (1..32)
-    }
-    P.groups[q] = rec;
-
-    // Which probe-table rows must be (re)built?  The map does not change during a registration
-    // and the pose moves by millimetres per iteration, so a slot's home voxel — hence its 27
-    // neighbours and its whole table row — is almost always the one of the previous iteration.
-    // Heads whose cached row is for another voxel go into this wave's compact list for k_probe
-    // (ballot rank, no atomics); in steady state the lists are empty.
-    const int4 key0 = P.tabkey[q];
-    const bool stale = head && !(key0.y == kx && key0.z == ky && key0.w == kz);
-    const unsigned long long sm = __ballot(stale);
-    const unsigned wave_global = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (stale) P.need_list[wave_global * 64u + __popcll(sm & ((1ull << lane) - 1ull))] = q;
-    if (lane == 0) P.need_cnt[wave_global] = static_cast<unsigned>(__popcll(sm));
-}
-
-// ---------------------------------------------------------------------------------- k_probe
-// One lane per (group, neighbour voxel) for every group whose probe-table row is stale (k_group's
-// per-wave lists): 32 lanes per group slot, 27 of them probing the GPU-resident open-addressed
-// hash (linear probing, 16-B slots, load factor <= 0.25).  Doing the
-// probes here — 1.4 M independent look-ups, no serial chain — instead of at the head of k_nn's
-// per-group dependency chain takes one to three memory round trips off every k_nn wave.
-// blks[slot][v] = {exclusive candidate offset, index of the voxel block's first point} of
-// neighbour v (x outer, y, z inner).
-__global__ __launch_bounds__(256) void k_probe(ProbeParams P) {
-    if (P.check_done && P.st->done) return;
-    // workgroup b serves the list of k_group's wave b; 8 teams of 32 lanes, one slot per team
-    const unsigned cnt_b = P.need_cnt[blockIdx.x];
-    const unsigned v = threadIdx.x & 31u;
-    for (unsigned i = threadIdx.x >> 5; i < cnt_b; i += 8u) {
-    const unsigned slot = P.need_list[blockIdx.x * 64u + i];
-    const int4 rec0 = P.groups[slot];
-    uint32_t blk = kEmptySlot;
-    if (v < 27u) {
-        const int4 rec = rec0;
-        const int vx = rec.y + static_cast<int>(v / 9u) - 1;
-        const int vy = rec.z + static_cast<int>((v / 3u) % 3u) - 1;
-        const int vz = rec.w + static_cast<int>(v % 3u) - 1;
-        uint32_t s = voxel_hash(vx, vy, vz) & P.mask;
-        for (;;) {
-            int4 e = reinterpret_cast<const int4 *>(P.table)[s];
-            asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(e.z), "+v"(e.w));   // one 16-B load
-            if (static_cast<uint32_t>(e.w) == kEmptySlot) break;
-            if (e.x == vx && e.y == vy && e.z == vz) { blk = static_cast<uint32_t>(e.w); break; }
-            s = (s + 1) & P.mask;
+    // marked invalid.  No atomics, no compaction: k_nn walks the slots in query order, so the
+    // work per wave is balanced by query count and each XCD's stripes of the (spatially sorted)
+    // slots are compact regions of the map.
+    if (valid) {
+        int4 rec;
+        rec.x = -1; rec.y = kx; rec.z = ky; rec.w = kz;
+        if (head) {
+            // length: distance to the next head, the end of this chunk or the end of the frame
+            const unsigned long long above = (lane == 63) ? 0ull : (heads >> (lane + 1)) << (lane + 1);
+            int end = above ? __builtin_ctzll(above) : 64;
+            end = min(end, (lane | P.group_mask) + 1);
+            end = min(end, 64 - __builtin_clzll(live));
+            rec.x = q | ((end - lane) << 26);      // start (26 bits) | length (1..32)
         }
+        P.groups[q] = rec;
     }
-    // exclusive prefix of the candidate counts over the group's 32 lanes (reference enumeration
-    // order); entry 27 carries the total C and 28..31 a sentinel, so k_nn can locate the voxel
-    // of any flat candidate index with a fixed 5-step binary search over 32 entries.
-    const uint32_t cnt = (blk == kEmptySlot) ? 0u : (blk & 255u);
-    uint32_t incl = cnt;
+
+    // Probe-table rows: blks[slot][v] = {exclusive candidate offset, index of the voxel block's
+    // first point} of neighbour voxel v (x outer, y, z inner) of the group's home voxel.  The map
+    // does not change during a registration and the pose moves by millimetres per iteration, so
+    // a slot's home voxel — hence its 27 neighbours and its whole row — is almost always the one
+    // of the previous iteration: rows are cached per slot together with the voxel they were built
+    // for, and only heads whose cached row is for another voxel are probed (all of them in the
+    // first iteration, a handful afterwards).  Two teams of 32 lanes, one stale head each per pass:
+    // 27 lanes probe the open-addressed hash (linear probing, 16-B slots, load factor <= 0.25,
+    // one 16-B load per step; reference core/VoxelHashMap.cpp:66-78: 27 x map_.find), then a
+    // 32-lane prefix sum turns the counts into candidate offsets; entry 27 carries the total and
+    // 28..31 a sentinel, so k_nn can locate the voxel of any flat candidate index with a fixed
+    // 5-step binary search over 32 entries.
+    int4 key0;
+    key0.x = 0; key0.y = 0x7F7F7F7F; key0.z = 0; key0.w = 0;
+    if (head) key0 = P.tabkey[q];
+    const bool stale = head && !(key0.y == kx && key0.z == ky && key0.w == kz);
+    unsigned long long todo = __ballot(stale);
+    const int team = lane >> 5;
+    const unsigned v = lane & 31u;
+    const unsigned wave_q0 = blockIdx.x * 256u + (threadIdx.x & ~63u);
+    while (todo) {
+        const int h0 = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        int h1 = -1;
+        if (todo) { h1 = __builtin_ctzll(todo); todo &= todo - 1; }
+        const int h = team ? h1 : h0;
+        const bool on = h >= 0;                       // this team has a head in this pass
+        const int hs = on ? h : h0;
+        const int hx = __shfl(kx, hs, 64), hy = __shfl(ky, hs, 64), hz = __shfl(kz, hs, 64);
+        uint32_t blk = kEmptySlot;
+        if (on && v < 27u) {
+            const int vx = hx + static_cast<int>(v / 9u) - 1;
+            const int vy = hy + static_cast<int>((v / 3u) % 3u) - 1;
+            const int vz = hz + static_cast<int>(v % 3u) - 1;
+            uint32_t sl = voxel_hash(vx, vy, vz) & P.mask;
+            for (;;) {
+                int4 e = reinterpret_cast<const int4 *>(P.table)[sl];
+                asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(e.z), "+v"(e.w));   // one 16-B load
+                if (static_cast<uint32_t>(e.w) == kEmptySlot) break;
+                if (e.x == vx && e.y == vy && e.z == vz) { blk = static_cast<uint32_t>(e.w); break; }
+                sl = (sl + 1) & P.mask;
+            }
+        }
+        const uint32_t cnt = (blk == kEmptySlot) ? 0u : (blk & 255u);
+        uint32_t incl = cnt;
 #pragma unroll
-    for (int d = 1; d < 32; d <<= 1) {
-        const uint32_t t = __shfl_up(incl, d, 32);
-        if (v >= static_cast<unsigned>(d)) incl += t;
-    }
-    uint32_t off = incl - cnt;
-    if (v > 27u) off = 0xFFFFFFFFu;
-    uint2 rec2;
-    rec2.x = off;
-    rec2.y = (blk == kEmptySlot) ? 0u : (blk >> 8) * static_cast<uint32_t>(P.cap);   // first point
-    P.blks[slot * 32u + v] = rec2;
-    if (v == 0u) P.tabkey[slot] = rec0;      // the row now describes this home voxel
+        for (int d = 1; d < 32; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d, 32);
+            if (v >= static_cast<unsigned>(d)) incl += t;
+        }
+        uint32_t off = incl - cnt;
+        if (v > 27u) off = 0xFFFFFFFFu;
+        if (on) {
+            const unsigned slot = wave_q0 + static_cast<unsigned>(h);
+            uint2 row;
+            row.x = off;
+            row.y = (blk == kEmptySlot) ? 0u : (blk >> 8) * static_cast<uint32_t>(P.cap);   // first point
+            P.blks[slot * 32u + v] = row;
+            if (v == 0u) {
+                int4 k;
+                k.x = 0; k.y = hx; k.z = hy; k.w = hz;
+                P.tabkey[slot] = k;                   // the row now describes this home voxel
+            }
+        }
     }
 }
 
@@ -678,11 +683,6 @@ void launch_group(const GroupParams &p, bool apply_pose, hipStream_t s) {
         hipLaunchKernelGGL(k_group<true>, dim3(grid), dim3(256), 0, s, p);
     else
         hipLaunchKernelGGL(k_group<false>, dim3(grid), dim3(256), 0, s, p);
-}
-
-void launch_probe(const ProbeParams &p, int n, hipStream_t s) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_probe, dim3((static_cast<unsigned>(n) + 63u) / 64u), dim3(256), 0, s, p);
 }
 
 void launch_nn(const NnParams &p, hipStream_t s) {
