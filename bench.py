@@ -78,6 +78,16 @@ def main():
         dist.init_process_group(backend="nccl", world_size=world, rank=rank,
                                 device_id=torch.device("cuda", local_rank))
 
+    # the .so is a build artefact (git-ignored): build it in-tree if a fresh checkout has none
+    if local_rank == 0 and not os.path.exists(os.path.join(ROOT, "sage-icp_amd", "libsageicp_hip.so")):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location(
+            "_sageicp_build", os.path.join(ROOT, "sage-icp_amd", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build()
+    if use_dist:
+        dist.barrier()
     import sage_icp_amd as sage
     from sage_icp_amd import synthetic as syn
     from sage_icp_amd.sharding import shard_bounds

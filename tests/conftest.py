@@ -20,8 +20,21 @@ def oracle():
     return orc
 
 
+def _ensure_product_library():
+    """The .so is git-ignored: build it in-tree (hipcc cross-compiles gfx950 without a GPU) when a
+    fresh checkout has none or the sources are newer.  Loading still fails loudly if that fails."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "_sageicp_build", os.path.join(ROOT, "sage-icp_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if mod.needs_build():
+        mod.build()
+
+
 @pytest.fixture(scope="session")
 def sage():
+    _ensure_product_library()
     import sage_icp_amd
     sage_icp_amd.lib()
     return sage_icp_amd
