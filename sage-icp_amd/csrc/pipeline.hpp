@@ -35,8 +35,7 @@ struct Pose7 {
 class Pipeline {
 public:
     explicit Pipeline(const sageicp_pipeline_config &c)
-        : voxel_size_map(c.voxel_size_map), max_range(c.max_range), min_range(c.min_range),
-          label_max_range(c.label_max_range), local_map_range(c.local_map_range),
+        : max_range(c.max_range), min_range(c.min_range), label_max_range(c.label_max_range),
           min_motion_th(c.min_motion_th), initial_threshold(c.initial_threshold), sem_th(c.sem_th) {
         const int *gl = c.group_labels;
         for (int g = 0; g < c.n_groups; ++g) {
@@ -150,7 +149,7 @@ private:
         return std::sqrt(model_error_sse2 / num_samples);
     }
 
-    double voxel_size_map, max_range, min_range, label_max_range, local_map_range;
+    double max_range, min_range, label_max_range;
     double min_motion_th, initial_threshold, sem_th;
     std::vector<std::vector<int>> groups;
     std::vector<double> group_voxel;
