@@ -405,6 +405,41 @@ __global__ __launch_bounds__(64 * kNnWaves, 8) void k_nn(NnParams P) {
         atomicAdd(P.cand_counter + cand_slot, wave_candidates);   // fire-and-forget, private address
 }
 
+// ------------------------------------------------------------------------------------ WaveLanes
+// Lane policy (se3_math.h) for the wave that finishes an iteration: its 64 lanes all hold the
+// same (uniform) values, so independent fp64 divisions / sincos arguments are moved to separate
+// lanes, evaluated by ONE vector instruction sequence, and read back with v_readlane.  A serial
+// lane spent ~2 us of every iteration in the 21 divisions of the 6x6 LDL^T alone.
+// Must be called with lanes 0..5 active and uniform operands.
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+struct WaveLanes {
+    static __device__ __forceinline__ void divide6(const double (&n)[6], const double (&d)[6],
+                                                   double (&q)[6]) {
+        const int lane = static_cast<int>(threadIdx.x & 63u);
+        double nn = n[0], dd = d[0];
+#pragma unroll
+        for (int i = 1; i < 6; ++i) {
+            nn = (lane == i) ? n[i] : nn;
+            dd = (lane == i) ? d[i] : dd;
+        }
+        const double qq = nn / dd;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) q[i] = readlane_f64(qq, i);
+    }
+    static __device__ __forceinline__ void sincos2(double a0, double a1, double &s0, double &c0,
+                                                   double &s1, double &c1) {
+        const int lane = static_cast<int>(threadIdx.x & 63u);
+        double sv, cv;
+        sincos(lane == 1 ? a1 : a0, &sv, &cv);
+        s0 = readlane_f64(sv, 0); c0 = readlane_f64(cv, 0);
+        s1 = readlane_f64(sv, 1); c1 = readlane_f64(cv, 1);
+    }
+};
+
 // ------------------------------------------------------------------------------ finish_iteration
 // Executed by ONE workgroup of 256 threads once per ICP iteration: fixed-order reduction of the
 // k_gn workgroup partials (bit-reproducible), then one lane assembles the 6x6 normal equations
@@ -413,10 +448,20 @@ __global__ __launch_bounds__(64 * kNnWaves, 8) void k_nn(NnParams P) {
 //   mode 0: reduce partials + solve      (single GPU)
 //   mode 1: reduce partials -> st->sums  (multi GPU, before the RCCL all-reduce)
 //   mode 2: solve from st->sums          (multi GPU, after the all-reduce)
+#ifdef SAGE_GN_TIMING
+__device__ unsigned long long g_gn_phase[16];
+#define FIN_STAMP(i) do { if (threadIdx.x == 0) fin_t[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FIN_STAMP(i) do { } while (0)
+#endif
 __device__ __forceinline__ void finish_iteration(IcpState *st, const double *partials, int nparts,
                                                  int mode) {
     __shared__ double slice[8][32];
     __shared__ double S[kNumSums];
+#ifdef SAGE_GN_TIMING
+    unsigned long long fin_t[8];
+#endif
+    FIN_STAMP(0);
 
     if (mode != 2) {
         const int comp = threadIdx.x & 31, sl = threadIdx.x >> 5;
@@ -449,22 +494,31 @@ __device__ __forceinline__ void finish_iteration(IcpState *st, const double *par
         __syncthreads();
     }
 
-    if (threadIdx.x != 0) return;
+    if (threadIdx.x >= 64) return;
+    // wave 0, all 64 lanes, uniform data (see WaveLanes); lane 0 / lane 1 publish the state
+    FIN_STAMP(1);
+    const int lane = static_cast<int>(threadIdx.x);
     double JTJ[36], JTr[6], neg[6], x[6], est[7];
     assemble_normal_equations(S, JTJ, JTr);
 #pragma unroll
     for (int i = 0; i < 6; ++i) neg[i] = -JTr[i];
-    ldlt_solve6(JTJ, neg, x);
-    se3_exp(x, est);
+    ldlt_solve6_t<WaveLanes>(JTJ, neg, x);
+    FIN_STAMP(2);
+    se3_exp_t<WaveLanes>(x, est);
+    FIN_STAMP(3);
 
-    double Tn[7];
-    se3_mul(est, st->T, Tn);
+    // the two compositions (Registration.cpp:135 and the cumulative pose) on lanes 0 and 1
+    double rhs[7], Tn[7];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) st->T[i] = Tn[i];
+    for (int i = 0; i < 7; ++i) rhs[i] = (lane == 1) ? st->T_icp[i] : st->T[i];
+    se3_mul(est, rhs, Tn);
+    if (lane < 2) {
+        double *dst = (lane == 1) ? st->T_icp : st->T;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) dst[i] = Tn[i];
+    }
+    if (lane != 0) return;
     quat_to_mat(Tn, st->R);
-    se3_mul(est, st->T_icp, Tn);
-#pragma unroll
-    for (int i = 0; i < 7; ++i) st->T_icp[i] = Tn[i];
 
     // ||log(exp(x))|| == ||x|| (principal branch, |omega| < pi, which a Gauss-Newton step of a
     // converging registration always satisfies): the reference's estimation.log().norm()
@@ -490,16 +544,34 @@ __device__ __forceinline__ void finish_iteration(IcpState *st, const double *par
     } else if (it + 1 >= kMaxIterations) {
         st->done = 1;
     }
+#ifdef SAGE_GN_TIMING
+    fin_t[4] = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < 4; ++i) atomicAdd(&g_gn_phase[8 + i], fin_t[i + 1] - fin_t[i]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------ k_gn
+#ifdef SAGE_GN_TIMING
+#define GN_STAMP(i) do { if (threadIdx.x == 0) gn_t[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GN_STAMP(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256) void k_gn(GnParams P) {
     if (P.check_done && P.st->done) return;
-    __shared__ double lds[4][kNumSums];
+    // block reduction scratch: component c of thread t at red[c][(t >> 4) * 17 + (t & 15)]
+    // (rows of 16 values padded to 17 doubles: conflict-free for both the write and the read)
+    __shared__ double red[kCount][16 * 17];
+    __shared__ unsigned wave_pairs[4];
+#ifdef SAGE_GN_TIMING
+    unsigned long long gn_t[8];
+    GN_STAMP(0);
+#endif
 
-    double acc[kCount + 1];
+    double acc[kCount];
 #pragma unroll
-    for (int i = 0; i <= kCount; ++i) acc[i] = 0.0;
+    for (int i = 0; i < kCount; ++i) acc[i] = 0.0;
+    unsigned pairs = 0;   // accepted pairs of this wave (wave-uniform, exact in any order)
 
     const double k = P.kernel;
     const double k2 = k * k;
@@ -512,6 +584,7 @@ __global__ __launch_bounds__(256) void k_gn(GnParams P) {
         // acceptance: (closest_neighboor - point).norm() < max_correspondance_distance
         // (VoxelHashMap.cpp:111); explicit pairs (align_clouds entry) are all taken
         if (!P.tgt_pairs && !(sqrt(r2) < P.max_dist)) use = false;
+        pairs += static_cast<unsigned>(__popcll(__ballot(use)));
         if (!use) return;
         const double den = k + r2;
         const double w = k2 / (den * den);   // square(th) / square(th + residual2)
@@ -524,7 +597,6 @@ __global__ __launch_bounds__(256) void k_gn(GnParams P) {
         acc[kWcx] += w * (sy * rz - sz * ry);
         acc[kWcy] += w * (sz * rx - sx * rz);
         acc[kWcz] += w * (sx * ry - sy * rx);
-        acc[kCount] += 1.0;
     };
 
     // grid-stride over the queries, two per step so that the dependent gathers
@@ -552,23 +624,35 @@ __global__ __launch_bounds__(256) void k_gn(GnParams P) {
         accumulate(s2, g2, has2 && i2 >= 0);
     }
 
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    GN_STAMP(1);
+    // Block reduction in a fixed order (bit-reproducible): every thread parks its 16 sums in LDS,
+    // then 16 threads per component each add 16 parked values and finish with four DPP exchange
+    // steps inside their row of 16 lanes.  (A shuffle tree per component and wave cost ~3.9 us
+    // of LDS-permute traffic per launch.)
+    {
+        const int t = static_cast<int>(threadIdx.x);
+        const int slot = (t >> 4) * 17 + (t & 15);
 #pragma unroll
-    for (int i = 0; i <= kCount; ++i) {
-        double v = acc[i];
+        for (int c = 0; c < kCount; ++c) red[c][slot] = acc[c];
+        if ((t & 63) == 0) wave_pairs[t >> 6] = pairs;
+        __syncthreads();
+        const double *row = &red[t >> 4][(t & 15) * 17];
+        double v = row[0];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) lds[wv][i] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < kNumSums) {
-        double v = 0.0;
-        if (threadIdx.x <= kCount)
-            v = ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) +
-                lds[3][threadIdx.x];
-        P.partials[blockIdx.x * kNumSums + threadIdx.x] = v;
+        for (int i = 1; i < 16; ++i) v += row[i];
+        v += dpp_f64<kDppXor1>(v);
+        v += dpp_f64<kDppXor2>(v);
+        v += dpp_f64<kDppHalfMirror>(v);
+        v += dpp_f64<kDppMirror>(v);
+        double *out = P.partials + static_cast<size_t>(blockIdx.x) * kNumSums;
+        if ((t & 15) == 0) out[t >> 4] = v;
+        if (t == 0)
+            out[kCount] = static_cast<double>((wave_pairs[0] + wave_pairs[1]) +
+                                              (wave_pairs[2] + wave_pairs[3]));
+        if (t > kCount && t < kNumSums) out[t] = 0.0;
     }
     if (P.fuse_mode < 0) return;
+    GN_STAMP(2);
 
     // Last-arriver hand-off (placement independent): partials are published with an agent-scope
     // release before the ticket, the workgroup that draws the last ticket acquires (drops its
@@ -591,7 +675,15 @@ __global__ __launch_bounds__(256) void k_gn(GnParams P) {
         __hip_atomic_store(P.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
     }
     __syncthreads();
+    GN_STAMP(3);
     finish_iteration(P.st_rw, P.partials, static_cast<int>(gridDim.x), P.fuse_mode);
+#ifdef SAGE_GN_TIMING
+    if (threadIdx.x == 0) {
+        gn_t[4] = __builtin_amdgcn_s_memrealtime();
+        for (int i = 0; i < 4; ++i) atomicAdd(&g_gn_phase[i], gn_t[i + 1] - gn_t[i]);
+        atomicAdd(&g_gn_phase[4], 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------ k_fin
@@ -616,6 +708,15 @@ __global__ __launch_bounds__(256) void k_tf(Point4 *pts, int n, const IcpState *
     pts[i] = p;
 }
 
+#ifdef SAGE_GN_TIMING
+extern "C" void sageicp_debug_gn_phases(unsigned long long out[16], int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gn_phase), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gn_phase), z, sizeof(z));
+    }
+}
+#endif
 #ifdef SAGE_NN_TIMING
 extern "C" void sageicp_debug_nn_phases(unsigned long long out[8], int reset) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_phase), sizeof(unsigned long long) * 8);

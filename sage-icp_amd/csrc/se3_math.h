@@ -60,8 +60,24 @@ SAGE_HD inline void se3_inv(const double A[7], double O[7]) {
     O[4] = -t[0]; O[5] = -t[1]; O[6] = -t[2];
 }
 
+// Lane policy of the few expensive scalar operations (fp64 divide, sincos) inside the 6x6 solve
+// and the SE3 exponential.  SerialLanes evaluates them one after another (host code, and any
+// single-lane caller); kernels.hip supplies a wavefront policy that spreads independent
+// divisions / sincos arguments over lanes of the (otherwise idle) wave that finishes an ICP
+// iteration.  Operands and operation order per element are the same, so results are bit-identical.
+struct SerialLanes {
+    static SAGE_HD void divide6(const double (&n)[6], const double (&d)[6], double (&q)[6]) {
+        for (int i = 0; i < 6; ++i) q[i] = n[i] / d[i];
+    }
+    static SAGE_HD void sincos2(double a0, double a1, double &s0, double &c0, double &s1, double &c1) {
+        s0 = sin(a0); c0 = cos(a0);
+        s1 = sin(a1); c1 = cos(a1);
+    }
+};
+
 // exp: tangent a = (upsilon, omega), translation first.
-SAGE_HD inline void se3_exp(const double a[6], double T[7]) {
+template <class Lanes>
+SAGE_HD inline void se3_exp_t(const double a[6], double T[7]) {
     const double wx = a[3], wy = a[4], wz = a[5];
     const double th2 = wx * wx + wy * wy + wz * wz;
     const double th = sqrt(th2);
@@ -74,10 +90,16 @@ SAGE_HD inline void se3_exp(const double a[6], double T[7]) {
         B = 1.0 / 6.0 - th2 / 120.0;
     } else {
         const double half = 0.5 * th;
-        imag = sin(half) / th;
-        real = cos(half);
-        A = (1.0 - cos(th)) / th2;
-        B = (th - sin(th)) / (th2 * th);
+        double sh, ch, sf, cf;
+        Lanes::sincos2(half, th, sh, ch, sf, cf);
+        const double num[6] = {sh, 1.0 - cf, th - sf, 0.0, 0.0, 0.0};
+        const double den[6] = {th, th2, th2 * th, 1.0, 1.0, 1.0};
+        double quo[6];
+        Lanes::divide6(num, den, quo);
+        imag = quo[0];
+        real = ch;
+        A = quo[1];
+        B = quo[2];
     }
     T[0] = imag * wx; T[1] = imag * wy; T[2] = imag * wz; T[3] = real;
     // V*u = u + A (w x u) + B (w x (w x u))
@@ -88,6 +110,7 @@ SAGE_HD inline void se3_exp(const double a[6], double T[7]) {
     T[5] = uy + A * cy + B * ccy;
     T[6] = uz + A * cz + B * ccz;
 }
+SAGE_HD inline void se3_exp(const double a[6], double T[7]) { se3_exp_t<SerialLanes>(a, T); }
 
 SAGE_HD inline void se3_log(const double T[7], double a[6]) {
     const double n2 = T[0] * T[0] + T[1] * T[1] + T[2] * T[2];
@@ -142,7 +165,8 @@ SAGE_HD inline void ldlt_sym_swap(double (&A)[6][6], const int k, const int p) {
         if (i > k && i < p) { const double s = A[i][k]; A[i][k] = A[p][i]; A[p][i] = s; }
 }
 
-SAGE_HD inline void ldlt_solve6(const double *Ain, const double *b, double *x) {
+template <class Lanes>
+SAGE_HD inline void ldlt_solve6_t(const double *Ain, const double *b, double *x) {
     double A[6][6];
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -181,9 +205,18 @@ SAGE_HD inline void ldlt_solve6(const double *Ain, const double *b, double *x) {
                 }
             const double akk = A[k][k];
             if (fabs(akk) > 0.0) {
+                if (k < 5) {                       // A[i][k] /= akk for i > k, one lane each
+                    double num[6], den[6], quo[6];
 #pragma unroll
-                for (int i = 0; i < 6; ++i)
-                    if (i > k) A[i][k] /= akk;
+                    for (int i = 0; i < 6; ++i) {
+                        num[i] = (i > k) ? A[i][k] : 0.0;
+                        den[i] = (i > k) ? akk : 1.0;
+                    }
+                    Lanes::divide6(num, den, quo);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i)
+                        if (i > k) A[i][k] = quo[i];
+                }
             } else if (k == 0) {
 #pragma unroll
                 for (int j = 0; j < 6; ++j) { tr[j] = j; A[j][j] = 0.0; }
@@ -205,9 +238,16 @@ SAGE_HD inline void ldlt_solve6(const double *Ain, const double *b, double *x) {
 #pragma unroll
         for (int j = 0; j < 6; ++j)
             if (j < i) y[i] -= A[i][j] * y[j];
+    {                                      // D^+
+        double den[6], quo[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i)            // D^+
-        y[i] = (fabs(A[i][i]) > 2.2250738585072014e-308) ? y[i] / A[i][i] : 0.0;
+        for (int i = 0; i < 6; ++i)
+            den[i] = (fabs(A[i][i]) > 2.2250738585072014e-308) ? A[i][i] : 1.0;
+        Lanes::divide6(y, den, quo);
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            y[i] = (fabs(A[i][i]) > 2.2250738585072014e-308) ? quo[i] : 0.0;
+    }
 #pragma unroll
     for (int i = 5; i >= 0; --i)           // L^-T
 #pragma unroll
@@ -221,6 +261,9 @@ SAGE_HD inline void ldlt_solve6(const double *Ain, const double *b, double *x) {
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) x[i] = y[i];
+}
+SAGE_HD inline void ldlt_solve6(const double *Ain, const double *b, double *x) {
+    ldlt_solve6_t<SerialLanes>(Ain, b, x);
 }
 
 // Assemble JTJ (row-major 6x6) and JTr from the 16 closed-form sums (sageicp_types.h Sum).
