@@ -47,10 +47,15 @@ static int group_cap() {
     static int c = [] {
         int v = env_int("SAGEICP_GROUP_MAX", 4);   // measured best on c2 (profiles/sweep2.sh)
         int p = 1;
-        while (p * 2 <= v && p < 32) p *= 2;
+        while (p * 2 <= v && p < 16) p *= 2;   // three lanes per query in k_nn's prologue
         return p;
     }();
     return c;
+}
+static unsigned group_cap_log2() {
+    unsigned l = 0;
+    while ((1 << l) < group_cap()) ++l;
+    return l;
 }
 
 
@@ -84,7 +89,7 @@ struct Scratch {
     Point4 *d_sorted = nullptr; uint32_t *d_keys = nullptr; uint32_t *d_vals = nullptr;
     void *d_sort_temp = nullptr; size_t sort_cap = 0; size_t sort_temp_bytes_ = 0;
     // per-iteration work buffers: transformed queries and the group list (k_group)
-    Point4 *d_src = nullptr; int4 *d_groups = nullptr; uint2 *d_blks = nullptr;
+    Point4 *d_src = nullptr; uint2 *d_blks = nullptr;
     int4 *d_tabkey = nullptr;
     double *d_partials = nullptr;
     unsigned long long *d_cand = nullptr;      // per-chunk candidate counters of k_nn [sort_cap]
@@ -141,16 +146,14 @@ struct Scratch {
         if (d_vals) HIPCHK(hipFree(d_vals));
         if (d_sort_temp) HIPCHK(hipFree(d_sort_temp));
         if (d_src) HIPCHK(hipFree(d_src));
-        if (d_groups) HIPCHK(hipFree(d_groups));
         if (d_blks) HIPCHK(hipFree(d_blks));
         if (d_tabkey) HIPCHK(hipFree(d_tabkey));
         d_blks = nullptr; d_tabkey = nullptr;
         d_sorted = nullptr; d_keys = d_vals = nullptr; d_sort_temp = nullptr; sort_cap = 0;
-        d_src = nullptr; d_groups = nullptr;
+        d_src = nullptr;
         const size_t cap = n + n / 4 + 1024;
         HIPCHK(hipMalloc(&d_sorted, cap * sizeof(Point4)));
         HIPCHK(hipMalloc(&d_src, cap * sizeof(Point4)));
-        HIPCHK(hipMalloc(&d_groups, cap * sizeof(int4)));
         HIPCHK(hipMalloc(&d_blks, cap * 32 * sizeof(uint2)));
         HIPCHK(hipMalloc(&d_tabkey, cap * sizeof(int4)));
         if (d_cand) HIPCHK(hipFree(d_cand));
@@ -183,7 +186,6 @@ struct Scratch {
         if (d_vals) (void)hipFree(d_vals);
         if (d_sort_temp) (void)hipFree(d_sort_temp);
         if (d_src) (void)hipFree(d_src);
-        if (d_groups) (void)hipFree(d_groups);
         if (d_blks) (void)hipFree(d_blks);
         if (d_tabkey) (void)hipFree(d_tabkey);
         if (d_partials) (void)hipFree(d_partials);
@@ -530,14 +532,12 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         d_frame = sc.d_sorted;
     }
 
-    GroupParams grp{d_frame, static_cast<int>(n), sc.d_state, m->host.voxel_size, sc.d_src,
-                    sc.d_groups, group_cap() - 1, sc.d_tabkey, m->d_table, m->host.mask,
-                    m->host.cap, sc.d_blks};
     // no cached probe-table row is valid for a new call (0x7F7F7F7F is not a reachable voxel index)
     HIPCHK(hipMemsetAsync(sc.d_tabkey, 0x7F, (n + 1) * sizeof(int4), s));
-    NnParams np{sc.d_src, static_cast<int>(n), sc.d_state, 1, sc.d_groups,
-                static_cast<unsigned>(group_cap()), sc.d_blks, m->d_pts, m->host.cap,
-                nn_cand_stride(m->host.cap), sem_th, sc.d_nn, sc.d_cand};
+    NnParams np{d_frame, sc.d_src, static_cast<int>(n), sc.d_state, 1, 1, m->host.voxel_size,
+                static_cast<unsigned>(group_cap()), group_cap_log2(), sc.d_tabkey, sc.d_blks,
+                m->d_table, m->host.mask, m->d_pts, m->host.cap, nn_cand_stride(m->host.cap),
+                sem_th, sc.d_nn, sc.d_cand};
     HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * (n + 1), s));
     GnParams gp{sc.d_src, nullptr, static_cast<int>(n), sc.d_state, 1, m->d_pts, sc.d_nn, kernel,
                 max_dist, sc.d_partials, comm ? 1 : 0, sc.d_state, &sc.d_state->gn_ticket};
@@ -552,8 +552,6 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         for (int k = 0; k < todo; ++k) {
             // profiling level 1: events around k_nn only (the roofline kernel; each record costs
             // ~1 us of stream time); level 2: around every kernel
-            if (prof2) HIPCHK(hipEventRecord(sc.events[5 * k + 0], s));
-            launch_group(grp, true, s);
             if (prof) HIPCHK(hipEventRecord(sc.events[5 * k + 1], s));
             launch_nn(np, s);
             if (prof) HIPCHK(hipEventRecord(sc.events[5 * k + 2], s));
@@ -579,7 +577,6 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
                 float g = 0, a = 0, b = 0, c = 0;
                 (void)hipEventElapsedTime(&a, sc.events[5 * k + 1], sc.events[5 * k + 2]);
                 if (prof2) {
-                    (void)hipEventElapsedTime(&g, sc.events[5 * k + 0], sc.events[5 * k + 1]);
                     (void)hipEventElapsedTime(&b, sc.events[5 * k + 2], sc.events[5 * k + 3]);
                     (void)hipEventElapsedTime(&c, sc.events[5 * k + 3], sc.events[5 * k + 4]);
                 }
@@ -751,14 +748,11 @@ int sageicp_get_correspondences(const sageicp_map *m, const double *q, uint64_t 
     HIPCHK(sort_frame(sc.d_frame, sc.d_sorted, static_cast<int>(n), sc.d_state, false,
                       m->host.voxel_size, sc.d_keys, sc.d_vals, sc.d_sort_temp, sc.sort_temp_bytes_,
                       s));
-    GroupParams grp{sc.d_sorted, static_cast<int>(n), sc.d_state, m->host.voxel_size, sc.d_src,
-                    sc.d_groups, group_cap() - 1, sc.d_tabkey, m->d_table, m->host.mask,
-                    m->host.cap, sc.d_blks};
     HIPCHK(hipMemsetAsync(sc.d_tabkey, 0x7F, (n + 1) * sizeof(int4), s));
-    launch_group(grp, false, s);
-    NnParams np{sc.d_src, static_cast<int>(n), sc.d_state, 0, sc.d_groups,
-                static_cast<unsigned>(group_cap()), sc.d_blks, m->d_pts, m->host.cap,
-                nn_cand_stride(m->host.cap), sem_th, sc.d_nn, nullptr};
+    NnParams np{sc.d_sorted, sc.d_src, static_cast<int>(n), sc.d_state, 0, 0, m->host.voxel_size,
+                static_cast<unsigned>(group_cap()), group_cap_log2(), sc.d_tabkey, sc.d_blks,
+                m->d_table, m->host.mask, m->d_pts, m->host.cap, nn_cand_stride(m->host.cap),
+                sem_th, sc.d_nn, nullptr};
     launch_nn(np, s);
     HIPCHK(hipGetLastError());
     std::vector<int32_t> idx(n);

@@ -7,30 +7,21 @@
 
 namespace sageicp {
 
-struct GroupParams {
-    const Point4 *frame;      // pristine (sorted) frame, or already-transformed queries
+struct NnParams {
+    const Point4 *frame;      // pristine (sorted) frame, or ready-made queries (apply_pose == 0)
+    Point4 *src;              // out: the queries as searched (pose applied), for k_gn
     int n;
-    const IcpState *st;       // pose to apply (apply_pose) and the done flag
+    const IcpState *st;       // pose to apply and the done flag
+    int check_done;           // 1 inside the ICP loop: later launches of a finished loop are no-ops
+    int apply_pose;
     double voxel_size;
-    Point4 *src;              // out: transformed queries (x, y, z, label)
-    int4 *groups;             // out: one record per query slot: {start | len << 26, kx, ky, kz}
-                              //      at a group's head query, x = -1 elsewhere
-    int group_mask;           // group cap - 1 (cap is a power of two <= 32)
+    unsigned chunk;           // group cap: queries per wave (a power of two <= 16); a group is a
+                              // run of queries of one chunk that share a home voxel
+    unsigned chunk_log2;
     int4 *tabkey;             // [n] home voxel each cached probe-table row was built for (y, z, w)
+    uint2 *blks;              // [n][32] probe-table rows {candidate offset, first point}
     const Slot *table;        // the open-addressed voxel hash
     uint32_t mask;
-    int cap;
-    uint2 *blks;              // [n][32] probe-table rows {candidate offset, first point}
-};
-
-struct NnParams {
-    const Point4 *src;        // transformed queries
-    int n;
-    const IcpState *st;
-    int check_done;           // 1 inside the ICP loop: later launches of a finished loop are no-ops
-    const int4 *groups;
-    unsigned chunk;           // group cap: queries per chunk (a group never crosses a chunk)
-    const uint2 *blks;        // {candidate offset, first point} tables of k_probe
     const Point4 *pts;
     int cap;
     unsigned cand_stride;     // LDS words per wave (nn_cand_stride(cap))
@@ -57,9 +48,8 @@ struct GnParams {
 };
 
 constexpr int kMaxGnBlocks = 512;
-constexpr uint64_t kMaxQueries = (1ull << 26) - 1;   // group record packs start into 26 bits
+constexpr uint64_t kMaxQueries = (1ull << 26) - 1;
 
-void launch_group(const GroupParams &p, bool apply_pose, hipStream_t s);
 void launch_nn(const NnParams &p, hipStream_t s);
 int launch_gn(const GnParams &p, hipStream_t s);   // returns the number of partials written
 void launch_fin(IcpState *st, const double *partials, int nparts, int mode, int standalone,

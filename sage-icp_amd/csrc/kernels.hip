@@ -55,126 +55,56 @@ __device__ __forceinline__ uint32_t rl_u32(uint32_t v, int lane) {
     return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), lane));
 }
 
-// ---------------------------------------------------------------------------------- k_group
-// One lane per query.  Group heads: a query whose home voxel differs from its predecessor's,
-// or whose index is a multiple of the group cap (a power of two <= 32, so a group never crosses
-// a wave).
-template <bool APPLY_POSE>
-__global__ __launch_bounds__(256) void k_group(GroupParams P) {
-    if (APPLY_POSE && P.st->done) return;
-    const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    const bool valid = q < P.n;
-
-    int kx = 0, ky = 0, kz = 0;
-    if (valid) {
-        const Point4 f = P.frame[q];
-        Point4 s;
-        if (APPLY_POSE) {
-            const double *R = P.st->R;
-            const double *T = P.st->T;
-            s.x = R[0] * f.x + R[1] * f.y + R[2] * f.z + T[4];
-            s.y = R[3] * f.x + R[4] * f.y + R[5] * f.z + T[5];
-            s.z = R[6] * f.x + R[7] * f.y + R[8] * f.z + T[6];
-        } else {
-            s.x = f.x; s.y = f.y; s.z = f.z;
+// -------------------------------------------------------------------------------- probe_row
+// Probe-table row of one home voxel (hx, hy, hz), built by one wave:
+//   row[v] = {exclusive candidate offset, index of the voxel block's first point}
+// for neighbour voxel v = 0..26 (x outer, y, z inner — the reference's enumeration order,
+// core/VoxelHashMap.cpp:66-78: 27 x map_.find).  27 lanes probe the GPU-resident open-addressed
+// hash (linear probing, 16-B slots, load factor <= 0.25, one 16-B load per step), a 32-lane
+// prefix sum turns the counts into offsets; entry 27 carries the total and 28..31 a sentinel, so
+// any flat candidate index is located by a fixed 5-step binary search over 32 entries.  The row
+// is also stored in `blks` (with the voxel it describes in `tabkey`) for the next iterations.
+__device__ __forceinline__ uint2 probe_row(const NnParams &P, int lane, const int *skey, int h,
+                                           unsigned slot) {
+    // rare path (stale rows only): keep its lane-derived constants from being hoisted into the
+    // registers of the caller's hot loop
+    asm volatile("" : "+v"(lane));
+    const unsigned v = static_cast<unsigned>(lane);
+    // home voxel of query h of the chunk: skey[comp * chunk + h], one component per lane 0..2
+    const unsigned kv = static_cast<unsigned>(skey[min(v, 2u) * P.chunk + static_cast<unsigned>(h)]);
+    const int hx = static_cast<int>(rl_u32(kv, 0)), hy = static_cast<int>(rl_u32(kv, 1)),
+              hz = static_cast<int>(rl_u32(kv, 2));
+    uint32_t blk = kEmptySlot;
+    if (v < 27u) {
+        const int vx = hx + static_cast<int>(v / 9u) - 1;
+        const int vy = hy + static_cast<int>((v / 3u) % 3u) - 1;
+        const int vz = hz + static_cast<int>(v % 3u) - 1;
+        uint32_t sl = voxel_hash(vx, vy, vz) & P.mask;
+        for (;;) {
+            int4 e = reinterpret_cast<const int4 *>(P.table)[sl];
+            asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(e.z), "+v"(e.w));   // one 16-B load
+            if (static_cast<uint32_t>(e.w) == kEmptySlot) break;
+            if (e.x == vx && e.y == vy && e.z == vz) { blk = static_cast<uint32_t>(e.w); break; }
+            sl = (sl + 1) & P.mask;
         }
-        s.l = f.l;
-        P.src[q] = s;
-        // static_cast<int>(p / voxel_size): exact fp64 divide, truncation toward zero
-        kx = static_cast<int>(s.x / P.voxel_size);
-        ky = static_cast<int>(s.y / P.voxel_size);
-        kz = static_cast<int>(s.z / P.voxel_size);
     }
-    const int pkx = __shfl_up(kx, 1, 64), pky = __shfl_up(ky, 1, 64), pkz = __shfl_up(kz, 1, 64);
-    const bool head = valid && ((lane & P.group_mask) == 0 || kx != pkx || ky != pky || kz != pkz);
-    const unsigned long long heads = __ballot(head);
-    const unsigned long long live = __ballot(valid);
-    if (live == 0) return;
-
-    // Slot space: the record of a group lives at its head query's own index, every other slot is
-    // marked invalid.  No atomics, no compaction: k_nn walks the slots in query order, so the
-    // work per wave is balanced by query count and each XCD's stripes of the (spatially sorted)
-    // slots are compact regions of the map.
-    if (valid) {
-        int4 rec;
-        rec.x = -1; rec.y = kx; rec.z = ky; rec.w = kz;
-        if (head) {
-            // length: distance to the next head, the end of this chunk or the end of the frame
-            const unsigned long long above = (lane == 63) ? 0ull : (heads >> (lane + 1)) << (lane + 1);
-            int end = above ? __builtin_ctzll(above) : 64;
-            end = min(end, (lane | P.group_mask) + 1);
-            end = min(end, 64 - __builtin_clzll(live));
-            rec.x = q | ((end - lane) << 26);      // start (26 bits) | length (1..32)
-        }
-        P.groups[q] = rec;
-    }
-
-    // Probe-table rows: blks[slot][v] = {exclusive candidate offset, index of the voxel block's
-    // first point} of neighbour voxel v (x outer, y, z inner) of the group's home voxel.  The map
-    // does not change during a registration and the pose moves by millimetres per iteration, so
-    // a slot's home voxel — hence its 27 neighbours and its whole row — is almost always the one
-    // of the previous iteration: rows are cached per slot together with the voxel they were built
-    // for, and only heads whose cached row is for another voxel are probed (all of them in the
-    // first iteration, a handful afterwards).  Two teams of 32 lanes, one stale head each per pass:
-    // 27 lanes probe the open-addressed hash (linear probing, 16-B slots, load factor <= 0.25,
-    // one 16-B load per step; reference core/VoxelHashMap.cpp:66-78: 27 x map_.find), then a
-    // 32-lane prefix sum turns the counts into candidate offsets; entry 27 carries the total and
-    // 28..31 a sentinel, so k_nn can locate the voxel of any flat candidate index with a fixed
-    // 5-step binary search over 32 entries.
-    int4 key0;
-    key0.x = 0; key0.y = 0x7F7F7F7F; key0.z = 0; key0.w = 0;
-    if (head) key0 = P.tabkey[q];
-    const bool stale = head && !(key0.y == kx && key0.z == ky && key0.w == kz);
-    unsigned long long todo = __ballot(stale);
-    const int team = lane >> 5;
-    const unsigned v = lane & 31u;
-    const unsigned wave_q0 = blockIdx.x * 256u + (threadIdx.x & ~63u);
-    while (todo) {
-        const int h0 = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        int h1 = -1;
-        if (todo) { h1 = __builtin_ctzll(todo); todo &= todo - 1; }
-        const int h = team ? h1 : h0;
-        const bool on = h >= 0;                       // this team has a head in this pass
-        const int hs = on ? h : h0;
-        const int hx = __shfl(kx, hs, 64), hy = __shfl(ky, hs, 64), hz = __shfl(kz, hs, 64);
-        uint32_t blk = kEmptySlot;
-        if (on && v < 27u) {
-            const int vx = hx + static_cast<int>(v / 9u) - 1;
-            const int vy = hy + static_cast<int>((v / 3u) % 3u) - 1;
-            const int vz = hz + static_cast<int>(v % 3u) - 1;
-            uint32_t sl = voxel_hash(vx, vy, vz) & P.mask;
-            for (;;) {
-                int4 e = reinterpret_cast<const int4 *>(P.table)[sl];
-                asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(e.z), "+v"(e.w));   // one 16-B load
-                if (static_cast<uint32_t>(e.w) == kEmptySlot) break;
-                if (e.x == vx && e.y == vy && e.z == vz) { blk = static_cast<uint32_t>(e.w); break; }
-                sl = (sl + 1) & P.mask;
-            }
-        }
-        const uint32_t cnt = (blk == kEmptySlot) ? 0u : (blk & 255u);
-        uint32_t incl = cnt;
+    const uint32_t cnt = (blk == kEmptySlot) ? 0u : (blk & 255u);
+    uint32_t incl = cnt;
 #pragma unroll
-        for (int d = 1; d < 32; d <<= 1) {
-            const uint32_t t = __shfl_up(incl, d, 32);
-            if (v >= static_cast<unsigned>(d)) incl += t;
-        }
-        uint32_t off = incl - cnt;
-        if (v > 27u) off = 0xFFFFFFFFu;
-        if (on) {
-            const unsigned slot = wave_q0 + static_cast<unsigned>(h);
-            uint2 row;
-            row.x = off;
-            row.y = (blk == kEmptySlot) ? 0u : (blk >> 8) * static_cast<uint32_t>(P.cap);   // first point
-            P.blks[slot * 32u + v] = row;
-            if (v == 0u) {
-                int4 k;
-                k.x = 0; k.y = hx; k.z = hy; k.w = hz;
-                P.tabkey[slot] = k;                   // the row now describes this home voxel
-            }
-        }
+    for (int d = 1; d < 32; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d, 32);
+        if ((v & 31u) >= static_cast<unsigned>(d)) incl += t;
     }
+    uint2 row;
+    row.x = (v > 27u) ? 0xFFFFFFFFu : incl - cnt;
+    row.y = (blk == kEmptySlot) ? 0u : (blk >> 8) * static_cast<uint32_t>(P.cap);   // first point
+    if (v < 32u) P.blks[slot * 32u + v] = row;
+    if (v == 0u) {
+        int4 k;
+        k.x = 0; k.y = hx; k.z = hy; k.w = hz;
+        P.tabkey[slot] = k;                   // the row now describes this home voxel
+    }
+    return row;
 }
 
 // ------------------------------------------------------------------------------------- k_nn
@@ -296,6 +226,10 @@ __global__ __launch_bounds__(64 * kNnWaves, 8) void k_nn(NnParams P) {
     const int wv = threadIdx.x >> 6;
     uint32_t *cand = smem + wv * P.cand_stride;      // this wave's candidate list (absolute indices)
     uint2 *tab = reinterpret_cast<uint2 *>(smem + kNnWaves * P.cand_stride) + wv * 32;   // {offset, base} x 32
+    double *spt = reinterpret_cast<double *>(smem + kNnWaves * (P.cand_stride + 64u)) +
+                  wv * 4u * P.chunk;                 // the chunk's transformed queries {x, y, z, label}
+    int *skey = reinterpret_cast<int *>(smem + kNnWaves * (P.cand_stride + 64u + 8u * P.chunk)) +
+                wv * 3u * P.chunk;                   // their home voxels: [comp][query]
 
     // One wave per chunk of `chunk` consecutive queries (a group never crosses a chunk), four
     // chunks per workgroup, and many more workgroups than the chip holds at once: the hardware
@@ -314,45 +248,81 @@ __global__ __launch_bounds__(64 * kNnWaves, 8) void k_nn(NnParams P) {
       const unsigned nchunks = (static_cast<unsigned>(P.n) + chunk - 1u) / chunk;
       const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
       const unsigned quad = ((j / kStripe) * 8u + xcd) * kStripe + (j % kStripe);
-      const unsigned c_hi = nchunks;
-      const unsigned waves_per_xcd = 0xFFFFFFFFu;      // one chunk per wave
-      const int4 *groups = P.groups;
-      const uint2 *blks = P.blks;
-      // Every wave walks a dependent chain of memory round trips (chunk heads -> probe table ->
-      // query -> candidates); the loads that do not depend on the current group — the next
-      // chunk's heads, the next group's probe table, this group's query — are issued one step
-      // ahead so they overlap the LDS enumeration and the pair loop.
-      auto load_heads = [&](unsigned c) -> int {
-          const unsigned q0 = c * chunk;
-          int v = -1;
-          if (c < c_hi && static_cast<unsigned>(lane) < chunk && q0 + lane < static_cast<unsigned>(P.n))
-              v = groups[q0 + lane].x;
-          return v;
-      };
+      uint2 *blks = P.blks;
       auto load_table = [&](unsigned g) -> uint2 {
           uint2 ob;
           ob.x = 0xFFFFFFFFu; ob.y = 0u;
           if (lane < 32) ob = blks[g * 32u + lane];
           return ob;
       };
-      unsigned c = __builtin_amdgcn_readfirstlane(quad * kNnWaves + wv);
+      const unsigned c = __builtin_amdgcn_readfirstlane(quad * kNnWaves + wv);
       cand_slot = c;
-      int sl = load_heads(c);
-      if (c < c_hi) {
+      if (c < nchunks) {
         const unsigned q0 = c * chunk;
-        unsigned long long heads = __ballot(sl != -1);
-        uint2 ob = load_table(q0 + (heads ? __builtin_ctzll(heads) : 0));
+        // ---- chunk prologue (was a kernel of its own: one launch + one dependent round trip per
+        // iteration).  Lane (comp, i) = (lane >> log2 chunk, lane & (chunk-1)) owns coordinate
+        // `comp` of query q0 + i: it applies the cumulative pose to the pristine frame point
+        // (TransformPoints, Registration.cpp:103-111,133 — `source` is never rewritten in place),
+        // takes the home voxel index with the reference's fp64 divide + truncation
+        // (VoxelHashMap.cpp:52-54) and parks the transformed point in LDS for the pair lanes.
+        uint2 ob = load_table(q0);                   // the first query of a chunk is always a head
+        const unsigned qi_own = static_cast<unsigned>(lane) & (chunk - 1u);
+        const unsigned comp = static_cast<unsigned>(lane) >> P.chunk_log2;
+        const unsigned q_own = q0 + qi_own;
+        const bool lv = comp < 3u && q_own < static_cast<unsigned>(P.n);
+        int key = 0, ckey = 0x7F7F7F7F;
+        if (lv) {
+            const double *f = reinterpret_cast<const double *>(P.frame + q_own);
+            ckey = reinterpret_cast<const int *>(P.tabkey + q_own)[1 + comp];
+            const double fx = f[0], fy = f[1], fz = f[2], fl = f[3];
+            double sv;
+            if (P.apply_pose) {
+                const double *R = P.st->R + 3u * comp;
+                sv = R[0] * fx + R[1] * fy + R[2] * fz + P.st->T[4u + comp];
+            } else {
+                sv = comp == 0u ? fx : (comp == 1u ? fy : fz);
+            }
+            // static_cast<int>(p / voxel_size): exact fp64 divide, truncation toward zero
+            key = static_cast<int>(sv / P.voxel_size);
+            double *o = reinterpret_cast<double *>(P.src + q_own);
+            spt[4u * qi_own + comp] = sv;
+            skey[lane] = key;
+            o[comp] = sv;
+            if (comp == 0u) {
+                spt[4u * qi_own + 3u] = fl;
+                o[3] = fl;
+            }
+        }
+        // Group heads: a query whose home voxel differs from its predecessor's (chunks are
+        // aligned to rows of 16 lanes, so the predecessor is one DPP row-shift away), and the
+        // first query of the chunk.  Stale rows: heads whose cached probe-table row was built
+        // for another voxel (all of them in the first iteration, a handful afterwards: the pose
+        // moves by millimetres per iteration and the map does not change during a call).
+        const int prev = static_cast<int>(dpp_u32<0x111>(static_cast<unsigned>(key)));   // row_shr:1
+        const unsigned long long ne = __ballot(lv && qi_own > 0u && key != prev);
+        const unsigned long long mm = __ballot(lv && key != ckey);
+        const unsigned nvalid = min(chunk, static_cast<unsigned>(P.n) - q0);
+        const unsigned vmask = (nvalid >= 32u) ? 0xFFFFFFFFu : ((1u << nvalid) - 1u);
+        unsigned heads = (static_cast<unsigned>(ne | (ne >> chunk) | (ne >> (2u * chunk))) | 1u) & vmask;
+        const unsigned stale = static_cast<unsigned>(mm | (mm >> chunk) | (mm >> (2u * chunk))) & heads;
         while (heads) {
-        const int h = __builtin_ctzll(heads);
-        heads &= heads - 1;
-        const uint2 ob_next = load_table(q0 + (heads ? __builtin_ctzll(heads) : h));   // prefetch
-        const int startlen = __builtin_amdgcn_readlane(sl, h);
-        const int start = startlen & 0x03FFFFFF;
-        const int len = static_cast<unsigned>(startlen) >> 26;
+        const int h = __builtin_ctz(heads);
+        heads &= heads - 1u;
+        const int hn = heads ? __builtin_ctz(heads) : static_cast<int>(nvalid);   // end of the group
+        const uint2 ob_next = load_table(q0 + static_cast<unsigned>(heads ? hn : h));   // prefetch
+        const int start = static_cast<int>(q0) + h;
+        const int len = hn - h;
+        if ((stale >> h) & 1u) {
+            ob = probe_row(P, lane, skey, h, static_cast<unsigned>(start));
+        }
         // (query x candidate) pairs over the lanes: W = 64 / pow2ceil(len) lanes per query
         const int lgq = (len <= 1) ? 0 : (32 - __builtin_clz(static_cast<unsigned>(len - 1)));
         const int lw = 6 - lgq;
-        const Point4 p = P.src[start + min(lane >> lw, len - 1)];   // this lane's query, early
+        Point4 p;                                     // this lane's query
+        {
+            const double4 t = *reinterpret_cast<const double4 *>(spt + 4 * (h + min(lane >> lw, len - 1)));
+            p.x = t.x; p.y = t.y; p.z = t.z; p.l = t.w;
+        }
         NN_T(0);
 
         // Enumerate the candidates once, in reference order (x outer, y, z inner, then insertion
@@ -388,7 +358,6 @@ __global__ __launch_bounds__(64 * kNnWaves, 8) void k_nn(NnParams P) {
         ob = ob_next;
         }
       }
-      (void)waves_per_xcd;
     }
 #ifdef SAGE_NN_TIMING
     if (lane == 0) {
@@ -777,19 +746,11 @@ unsigned nn_cand_stride(int cap) {
     return (27u * static_cast<unsigned>(cap) + 3u) & ~3u;
 }
 
-void launch_group(const GroupParams &p, bool apply_pose, hipStream_t s) {
-    if (p.n <= 0) return;
-    const int grid = (p.n + 255) / 256;
-    if (apply_pose)
-        hipLaunchKernelGGL(k_group<true>, dim3(grid), dim3(256), 0, s, p);
-    else
-        hipLaunchKernelGGL(k_group<false>, dim3(grid), dim3(256), 0, s, p);
-}
-
 void launch_nn(const NnParams &p, hipStream_t s) {
     if (p.n <= 0) return;
     const int grid = nn_grid_for(p.n, static_cast<int>(p.chunk));
-    const size_t lds = kNnWaves * (p.cand_stride * sizeof(uint32_t) + 32u * sizeof(uint2));
+    const size_t lds = kNnWaves * (p.cand_stride * sizeof(uint32_t) + 32u * sizeof(uint2) +
+                                   4u * p.chunk * sizeof(double) + 3u * p.chunk * sizeof(int));
     hipLaunchKernelGGL(k_nn, dim3(grid), dim3(64 * kNnWaves), lds, s, p);
 }
 
