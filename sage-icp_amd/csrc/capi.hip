@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cfloat>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -52,10 +53,25 @@ static int group_cap() {
     }();
     return c;
 }
-static unsigned group_cap_log2() {
+// queries per k_nn wave: a power of two, group_cap() <= chunk <= 16
+static int nn_chunk() {
+    static int c = [] {
+        int v = env_int("SAGEICP_NN_CHUNK", group_cap());
+        int p = group_cap();
+        while (p * 2 <= v && p < 16) p *= 2;
+        return p;
+    }();
+    return c;
+}
+static unsigned nn_chunk_log2() {
     unsigned l = 0;
-    while ((1 << l) < group_cap()) ++l;
+    while ((1 << l) < nn_chunk()) ++l;
     return l;
+}
+static unsigned nn_cap_heads() {
+    unsigned m = 0;
+    for (int i = 0; i < nn_chunk(); i += group_cap()) m |= 1u << i;
+    return m;
 }
 
 
@@ -535,9 +551,9 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     // no cached probe-table row is valid for a new call (0x7F7F7F7F is not a reachable voxel index)
     HIPCHK(hipMemsetAsync(sc.d_tabkey, 0x7F, (n + 1) * sizeof(int4), s));
     NnParams np{d_frame, sc.d_src, static_cast<int>(n), sc.d_state, 1, 1, m->host.voxel_size,
-                static_cast<unsigned>(group_cap()), group_cap_log2(), sc.d_tabkey, sc.d_blks,
-                m->d_table, m->host.mask, m->d_pts, m->host.cap, nn_cand_stride(m->host.cap),
-                sem_th, sc.d_nn, sc.d_cand};
+                static_cast<unsigned>(nn_chunk()), nn_chunk_log2(), nn_cap_heads(), sc.d_tabkey, sc.d_blks,
+                m->d_table, m->host.mask, m->d_pts, m->host.cap,
+                sem_th, DBL_MAX, sc.d_nn, sc.d_cand};
     HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * (n + 1), s));
     GnParams gp{sc.d_src, nullptr, static_cast<int>(n), sc.d_state, 1, m->d_pts, sc.d_nn, kernel,
                 max_dist, sc.d_partials, comm ? 1 : 0, sc.d_state, &sc.d_state->gn_ticket};
@@ -750,9 +766,9 @@ int sageicp_get_correspondences(const sageicp_map *m, const double *q, uint64_t 
                       s));
     HIPCHK(hipMemsetAsync(sc.d_tabkey, 0x7F, (n + 1) * sizeof(int4), s));
     NnParams np{sc.d_sorted, sc.d_src, static_cast<int>(n), sc.d_state, 0, 0, m->host.voxel_size,
-                static_cast<unsigned>(group_cap()), group_cap_log2(), sc.d_tabkey, sc.d_blks,
-                m->d_table, m->host.mask, m->d_pts, m->host.cap, nn_cand_stride(m->host.cap),
-                sem_th, sc.d_nn, nullptr};
+                static_cast<unsigned>(nn_chunk()), nn_chunk_log2(), nn_cap_heads(), sc.d_tabkey, sc.d_blks,
+                m->d_table, m->host.mask, m->d_pts, m->host.cap,
+                sem_th, DBL_MAX, sc.d_nn, nullptr};
     launch_nn(np, s);
     HIPCHK(hipGetLastError());
     std::vector<int32_t> idx(n);

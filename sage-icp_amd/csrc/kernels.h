@@ -18,18 +18,40 @@ struct NnParams {
     unsigned chunk;           // group cap: queries per wave (a power of two <= 16); a group is a
                               // run of queries of one chunk that share a home voxel
     unsigned chunk_log2;
+    unsigned cap_heads;       // forced heads inside a chunk: bit i set for every i that is a multiple
+                              // of the group cap (1 when the cap equals the chunk)
     int4 *tabkey;             // [n] home voxel each cached probe-table row was built for (y, z, w)
     uint2 *blks;              // [n][32] probe-table rows {candidate offset, first point}
     const Slot *table;        // the open-addressed voxel hash
     uint32_t mask;
     const Point4 *pts;
     int cap;
-    unsigned cand_stride;     // LDS words per wave (nn_cand_stride(cap))
     double sem_th;
+    double dist_init;         // DBL_MAX
     int32_t *nn_idx;          // out: block*cap+slot of the semantic nearest neighbour, -1 if the
                               //      27-voxel neighbourhood is empty (acceptance is applied later)
     unsigned long long *cand_counter;  // optional: [>= n] per-chunk running sums of C_q
 };
+
+// k_nn's per-wave LDS layout, in 32-bit words from the wave's base (host and device agree on it)
+struct NnLds {
+    unsigned marks;           // 64-bit start-mark bitmap over the flat candidate indices
+    unsigned delta;           // 32 x (first point - candidate offset) of the occupied voxels
+    unsigned spt;             // chunk x {x, y, z, label} fp64
+    unsigned skey;            // 3 x chunk home voxel indices
+    unsigned wave_words;
+};
+__host__ __device__ inline NnLds nn_lds_layout(int cap, unsigned chunk) {
+    NnLds l;
+    const unsigned ncand = 27u * static_cast<unsigned>(cap);
+    l.marks = (ncand + 3u) & ~3u;                                  // after the candidate list
+    const unsigned mark_words = (((ncand + 63u) >> 6) + 1u) & ~1u;   // 64-bit words, even count
+    l.delta = l.marks + 2u * mark_words;
+    l.spt = l.delta + 32u;
+    l.skey = l.spt + 8u * chunk;
+    l.wave_words = (l.skey + 3u * chunk + 3u) & ~3u;
+    return l;
+}
 
 struct GnParams {
     const Point4 *src;        // transformed queries (or the explicit sources of align_clouds)
@@ -60,7 +82,6 @@ void launch_scatter_points(const uint32_t *idx, const Point4 *vals, uint32_t n, 
 void launch_scatter_slots(const uint32_t *idx, const Slot *vals, uint32_t n, Slot *table,
                           hipStream_t s);
 int gn_grid_for(int n);
-unsigned nn_cand_stride(int cap);
 
 // preprocess.hip: one level of per-label-group voxel down-sampling (optionally with the range crop)
 struct VdsParams {

@@ -64,11 +64,14 @@ __device__ __forceinline__ uint32_t rl_u32(uint32_t v, int lane) {
 // prefix sum turns the counts into offsets; entry 27 carries the total and 28..31 a sentinel, so
 // any flat candidate index is located by a fixed 5-step binary search over 32 entries.  The row
 // is also stored in `blks` (with the voxel it describes in `tabkey`) for the next iterations.
-__device__ __forceinline__ uint2 probe_row(const NnParams &P, int lane, const int *skey, int h,
-                                           unsigned slot) {
-    // rare path (stale rows only): keep its lane-derived constants from being hoisted into the
-    // registers of the caller's hot loop
+__device__ __forceinline__ uint2 probe_row(const NnParams &P, int lane, const uint32_t *lds,
+                                           unsigned skey_word, int h, unsigned slot) {
+    // rare path (stale rows only): keep its lane-derived constants and LDS addresses from being
+    // hoisted into the registers of the caller's hot loop
     asm volatile("" : "+v"(lane));
+    skey_word = __builtin_amdgcn_readfirstlane(skey_word);
+    asm volatile("" : "+s"(skey_word));
+    const int *skey = reinterpret_cast<const int *>(lds + skey_word);
     const unsigned v = static_cast<unsigned>(lane);
     // home voxel of query h of the chunk: skey[comp * chunk + h], one component per lane 0..2
     const unsigned kv = static_cast<unsigned>(skey[min(v, 2u) * P.chunk + static_cast<unsigned>(h)]);
@@ -128,11 +131,29 @@ constexpr int kDppXor2 = 0x4E;          // quad_perm [2,3,0,1]
 constexpr int kDppHalfMirror = 0x141;   // lane i <-> 7 - i   within each 8
 constexpr int kDppMirror = 0x140;       // lane i <-> 15 - i  within each 16
 
-__device__ __forceinline__ void argmin_merge(double &b, unsigned &k, double ob, unsigned ok) {
-    const bool take = ob < b || (ob == b && ok < k);   // lexicographic (distance, enumeration index)
-    b = take ? ob : b;
-    k = take ? ok : k;
+// v_min_f64 without the quieting v_max_f64 x, x pairs the compiler puts around fmin(): the
+// operands here are never NaN.
+__device__ __forceinline__ double min_f64(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
+// min(v, v of the partner lane) in one VOP2-DPP instruction.  The s_nop covers the two wait
+// states a DPP read needs after a VALU write of the same register (the compiler's hazard
+// recogniser does not look into inline assembly).
+#define SAGE_MIN_U32_DPP(name, ctrl)                                                          \
+    __device__ __forceinline__ unsigned name(unsigned v) {                                    \
+        unsigned r;                                                                           \
+        asm("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf"         \
+            : "=v"(r)                                                                         \
+            : "v"(v));                                                                        \
+        return r;                                                                             \
+    }
+SAGE_MIN_U32_DPP(min_u32_xor1, "quad_perm:[1,0,3,2]")
+SAGE_MIN_U32_DPP(min_u32_xor2, "quad_perm:[2,3,0,1]")
+SAGE_MIN_U32_DPP(min_u32_half_mirror, "row_half_mirror")
+SAGE_MIN_U32_DPP(min_u32_mirror, "row_mirror")
+#undef SAGE_MIN_U32_DPP
 
 // One group: `len` (1..32) consecutive queries that share a home voxel, C candidates enumerated
 // in LDS.  W = 2^LW lanes serve each query, lane ci of them visiting candidates ci, ci+W, ...
@@ -149,7 +170,9 @@ __device__ __forceinline__ void nn_group(const NnParams &P, const uint32_t *cand
     const int pli = static_cast<int>(p.l);
     const double th = P.sem_th;
 
-    double best = DBL_MAX;            // scaled squared distance (closest_distance2)
+    // closest_distance2 starts at numeric_limits<double>::max() (VoxelHashMap.cpp:80); the value
+    // travels as a kernel argument so that it sits in scalar registers
+    double best = P.dist_init;        // scaled squared distance
     unsigned best_f = 0xFFFFFFFFu;    // flat candidate index == enumeration order: the tie-break
 
     auto eval = [&](unsigned f, const Point4 &nb) {
@@ -189,13 +212,23 @@ __device__ __forceinline__ void nn_group(const NnParams &P, const uint32_t *cand
 #endif
     }
 
-    // argmin over the W lanes of each query
-    if (W >= 2) argmin_merge(best, best_f, dpp_f64<kDppXor1>(best), dpp_u32<kDppXor1>(best_f));
-    if (W >= 4) argmin_merge(best, best_f, dpp_f64<kDppXor2>(best), dpp_u32<kDppXor2>(best_f));
-    if (W >= 8) argmin_merge(best, best_f, dpp_f64<kDppHalfMirror>(best), dpp_u32<kDppHalfMirror>(best_f));
-    if (W >= 16) argmin_merge(best, best_f, dpp_f64<kDppMirror>(best), dpp_u32<kDppMirror>(best_f));
-    if (W >= 32) argmin_merge(best, best_f, __shfl_xor(best, 16, 64), __shfl_xor(best_f, 16, 64));
-    if (W >= 64) argmin_merge(best, best_f, __shfl_xor(best, 32, 64), __shfl_xor(best_f, 32, 64));
+    // argmin over the W lanes of each query, lexicographic in (distance, enumeration index) like
+    // the sequential strict-< scan it replaces: first the minimum distance (never NaN: a NaN
+    // distance fails d < best), then the smallest index among the lanes that hold it.
+    double m = best;
+    if (W >= 2) m = min_f64(m, dpp_f64<kDppXor1>(m));
+    if (W >= 4) m = min_f64(m, dpp_f64<kDppXor2>(m));
+    if (W >= 8) m = min_f64(m, dpp_f64<kDppHalfMirror>(m));
+    if (W >= 16) m = min_f64(m, dpp_f64<kDppMirror>(m));
+    if (W >= 32) m = min_f64(m, __shfl_xor(m, 16, 64));
+    if (W >= 64) m = min_f64(m, __shfl_xor(m, 32, 64));
+    best_f = (best == m) ? best_f : 0xFFFFFFFFu;
+    if (W >= 2) best_f = min_u32_xor1(best_f);
+    if (W >= 4) best_f = min_u32_xor2(best_f);
+    if (W >= 8) best_f = min_u32_half_mirror(best_f);
+    if (W >= 16) best_f = min_u32_mirror(best_f);
+    if (W >= 32) best_f = min(best_f, static_cast<unsigned>(__shfl_xor(static_cast<int>(best_f), 16, 64)));
+    if (W >= 64) best_f = min(best_f, static_cast<unsigned>(__shfl_xor(static_cast<int>(best_f), 32, 64)));
 
     // The argmin is stored unconditionally; the acceptance test on the unscaled distance
     // (VoxelHashMap.cpp:111) is applied where the pair is consumed (k_gn / the host join).
@@ -224,12 +257,14 @@ __global__ __launch_bounds__(64 * kNnWaves, 8) void k_nn(NnParams P) {
 
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    uint32_t *cand = smem + wv * P.cand_stride;      // this wave's candidate list (absolute indices)
-    uint2 *tab = reinterpret_cast<uint2 *>(smem + kNnWaves * P.cand_stride) + wv * 32;   // {offset, base} x 32
-    double *spt = reinterpret_cast<double *>(smem + kNnWaves * (P.cand_stride + 64u)) +
-                  wv * 4u * P.chunk;                 // the chunk's transformed queries {x, y, z, label}
-    int *skey = reinterpret_cast<int *>(smem + kNnWaves * (P.cand_stride + 64u + 8u * P.chunk)) +
-                wv * 3u * P.chunk;                   // their home voxels: [comp][query]
+    // per-wave LDS (words): candidate list | start-mark bitmap | compacted voxel deltas |
+    // the chunk's transformed queries {x, y, z, label} | their home voxels [comp][query]
+    const NnLds L = nn_lds_layout(P.cap, P.chunk);
+    uint32_t *cand = smem + wv * L.wave_words;       // absolute point indices, enumeration order
+    unsigned long long *marks = reinterpret_cast<unsigned long long *>(cand + L.marks);
+    uint32_t *delta = cand + L.delta;
+    double *spt = reinterpret_cast<double *>(cand + L.spt);
+    int *skey = reinterpret_cast<int *>(cand + L.skey);
 
     // One wave per chunk of `chunk` consecutive queries (a group never crosses a chunk), four
     // chunks per workgroup, and many more workgroups than the chip holds at once: the hardware
@@ -303,7 +338,7 @@ __global__ __launch_bounds__(64 * kNnWaves, 8) void k_nn(NnParams P) {
         const unsigned long long mm = __ballot(lv && key != ckey);
         const unsigned nvalid = min(chunk, static_cast<unsigned>(P.n) - q0);
         const unsigned vmask = (nvalid >= 32u) ? 0xFFFFFFFFu : ((1u << nvalid) - 1u);
-        unsigned heads = (static_cast<unsigned>(ne | (ne >> chunk) | (ne >> (2u * chunk))) | 1u) & vmask;
+        unsigned heads = (static_cast<unsigned>(ne | (ne >> chunk) | (ne >> (2u * chunk))) | P.cap_heads) & vmask;
         const unsigned stale = static_cast<unsigned>(mm | (mm >> chunk) | (mm >> (2u * chunk))) & heads;
         while (heads) {
         const int h = __builtin_ctz(heads);
@@ -313,7 +348,7 @@ __global__ __launch_bounds__(64 * kNnWaves, 8) void k_nn(NnParams P) {
         const int start = static_cast<int>(q0) + h;
         const int len = hn - h;
         if ((stale >> h) & 1u) {
-            ob = probe_row(P, lane, skey, h, static_cast<unsigned>(start));
+            ob = probe_row(P, lane, smem, wv * L.wave_words + L.skey, h, static_cast<unsigned>(start));
         }
         // (query x candidate) pairs over the lanes: W = 64 / pow2ceil(len) lanes per query
         const int lgq = (len <= 1) ? 0 : (32 - __builtin_clz(static_cast<unsigned>(len - 1)));
@@ -326,22 +361,43 @@ __global__ __launch_bounds__(64 * kNnWaves, 8) void k_nn(NnParams P) {
         NN_T(0);
 
         // Enumerate the candidates once, in reference order (x outer, y, z inner, then insertion
-        // order), into LDS.  No scalar loop over voxels: every lane finds the voxel of its flat
-        // candidate index by a fixed 5-step binary search over the 32 offsets (the scalar unit is
-        // shared by the CU's four SIMDs and was the bottleneck of a per-voxel readlane loop).
-        if (lane < 32) tab[lane] = ob;
+        // order), into LDS: cand[f] = first point of f's voxel + (f - offset of that voxel).
+        // No scalar loop over voxels and no per-candidate search: the occupied voxels are
+        // compacted (ballot + mbcnt) into delta[r] = first point - offset, the position before
+        // each occupied voxel's first candidate is marked in a bitmap (LDS atomic OR), and the
+        // compacted voxel of flat index f is the number of marks below f — a running count of the
+        // earlier 64-bit words (scalar) plus v_mbcnt of f's own word.
         const unsigned C = rl_u32(ob.x, 27);
-        for (unsigned f = lane; f < C; f += 64) {
-            unsigned pos = 0, o = 0, base = rl_u32(ob.y, 0);
-#pragma unroll
-            for (int stp = 16; stp >= 1; stp >>= 1) {
-                const uint2 t = tab[pos + stp];
-                const bool take = t.x <= f;
-                pos = take ? pos + stp : pos;
-                o = take ? t.x : o;
-                base = take ? t.y : base;
+        {
+            const unsigned nxt = dpp_u32<0x130>(ob.x);            // wave_shl:1: offset of voxel v+1
+            const bool occupied = lane < 27 && nxt != ob.x;
+            const unsigned long long occ = __ballot(occupied);
+            const unsigned r = __builtin_amdgcn_mbcnt_hi(
+                static_cast<unsigned>(occ >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(occ), 0u));
+            const unsigned nwords = (C + 63u) >> 6;
+            unsigned ln = static_cast<unsigned>(lane);
+            asm volatile("" : "+v"(ln));   // bitmap addresses are cheaper to form than to keep live
+            for (unsigned w = ln; w < nwords; w += 64u) marks[w] = 0ull;
+            if (occupied) {
+                delta[r] = ob.y - ob.x;
+                if (ob.x) {
+                    const unsigned bpos = ob.x - 1u;
+                    atomicOr(&marks[bpos >> 6], 1ull << (bpos & 63u));
+                }
             }
-            cand[f] = base + (f - o);
+            unsigned below = 0;                                   // marks in the earlier words
+            for (unsigned wb = 0; wb < nwords; wb += 64u) {
+                const unsigned long long mine = (wb + ln < nwords) ? marks[wb + ln] : 0ull;
+                const unsigned nw = min(64u, nwords - wb);
+                for (unsigned i = 0; i < nw; ++i) {
+                    const unsigned lo = rl_u32(static_cast<unsigned>(mine), static_cast<int>(i));
+                    const unsigned hi = rl_u32(static_cast<unsigned>(mine >> 32), static_cast<int>(i));
+                    const unsigned rr = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, below));
+                    const unsigned f = ((wb + i) << 6) + lane;
+                    if (f < C) cand[f] = delta[rr] + f;
+                    below += __builtin_popcount(lo) + __builtin_popcount(hi);
+                }
+            }
         }
         wave_candidates += static_cast<unsigned long long>(C) * static_cast<unsigned>(len);
         NN_T(1);
@@ -741,16 +797,11 @@ int gn_grid_for(int n) {
     return static_cast<int>(blocks);
 }
 
-unsigned nn_cand_stride(int cap) {
-    // LDS words per wave: 27 voxels x cap candidates, rounded to a multiple of 4 words
-    return (27u * static_cast<unsigned>(cap) + 3u) & ~3u;
-}
 
 void launch_nn(const NnParams &p, hipStream_t s) {
     if (p.n <= 0) return;
     const int grid = nn_grid_for(p.n, static_cast<int>(p.chunk));
-    const size_t lds = kNnWaves * (p.cand_stride * sizeof(uint32_t) + 32u * sizeof(uint2) +
-                                   4u * p.chunk * sizeof(double) + 3u * p.chunk * sizeof(int));
+    const size_t lds = kNnWaves * nn_lds_layout(p.cap, p.chunk).wave_words * sizeof(uint32_t);
     hipLaunchKernelGGL(k_nn, dim3(grid), dim3(64 * kNnWaves), lds, s, p);
 }
 
