@@ -463,6 +463,8 @@ int sync_mirror(const sageicp_map *m) {
     }
     const size_t blocks_cap = h.cnt.size();
     const size_t block_bytes = static_cast<size_t>(h.cap) * sizeof(Point4);
+    if (static_cast<uint64_t>(blocks_cap) * h.cap > kMaxMapPoints)
+        return fail(SAGEICP_ERR_CAPACITY, "voxel blocks x capacity beyond 2^27 points");
     bool points_full = h.points_all_dirty || m->mirror_stale_all;
     if (blocks_cap > m->d_blocks_cap) {
         if (m->d_pts) HIPCHK(hipFree(m->d_pts));
@@ -552,7 +554,8 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     HIPCHK(hipMemsetAsync(sc.d_tabkey, 0x7F, (n + 1) * sizeof(int4), s));
     NnParams np{d_frame, sc.d_src, static_cast<int>(n), sc.d_state, 1, 1, m->host.voxel_size,
                 static_cast<unsigned>(nn_chunk()), nn_chunk_log2(), nn_cap_heads(), sc.d_tabkey, sc.d_blks,
-                m->d_table, m->host.mask, m->d_pts, m->host.cap,
+                m->d_table, m->host.mask, m->d_pts,
+                static_cast<uint32_t>(m->d_blocks_cap * m->host.cap * sizeof(Point4)), m->host.cap,
                 sem_th, DBL_MAX, sc.d_nn, sc.d_cand};
     HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * (n + 1), s));
     GnParams gp{sc.d_src, nullptr, static_cast<int>(n), sc.d_state, 1, m->d_pts, sc.d_nn, kernel,
@@ -700,6 +703,8 @@ int sageicp_map_add_points(sageicp_map *m, const double *xyzl, uint64_t n) {
     m->host.add_points(xyzl, n);
     if (m->host.blocks_hi >= (1u << kMaxBlockBits))
         return fail(SAGEICP_ERR_CAPACITY, "more than 2^23 voxels");
+    if (static_cast<uint64_t>(m->host.cnt.size()) * m->host.cap > kMaxMapPoints)
+        return fail(SAGEICP_ERR_CAPACITY, "voxel blocks x capacity beyond 2^27 points");
     return SAGEICP_OK;
 }
 
@@ -767,7 +772,8 @@ int sageicp_get_correspondences(const sageicp_map *m, const double *q, uint64_t 
     HIPCHK(hipMemsetAsync(sc.d_tabkey, 0x7F, (n + 1) * sizeof(int4), s));
     NnParams np{sc.d_sorted, sc.d_src, static_cast<int>(n), sc.d_state, 0, 0, m->host.voxel_size,
                 static_cast<unsigned>(nn_chunk()), nn_chunk_log2(), nn_cap_heads(), sc.d_tabkey, sc.d_blks,
-                m->d_table, m->host.mask, m->d_pts, m->host.cap,
+                m->d_table, m->host.mask, m->d_pts,
+                static_cast<uint32_t>(m->d_blocks_cap * m->host.cap * sizeof(Point4)), m->host.cap,
                 sem_th, DBL_MAX, sc.d_nn, nullptr};
     launch_nn(np, s);
     HIPCHK(hipGetLastError());

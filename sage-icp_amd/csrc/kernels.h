@@ -25,6 +25,7 @@ struct NnParams {
     const Slot *table;        // the open-addressed voxel hash
     uint32_t mask;
     const Point4 *pts;
+    uint32_t pts_bytes;       // size of the point array (< 4 GiB: k_nn addresses it by byte offset)
     int cap;
     double sem_th;
     double dist_init;         // DBL_MAX
@@ -71,6 +72,7 @@ struct GnParams {
 
 constexpr int kMaxGnBlocks = 512;
 constexpr uint64_t kMaxQueries = (1ull << 26) - 1;
+constexpr uint64_t kMaxMapPoints = (1ull << 27) - 1;   // blocks x capacity: 32-B points under 4 GiB
 
 void launch_nn(const NnParams &p, hipStream_t s);
 int launch_gn(const GnParams &p, hipStream_t s);   // returns the number of partials written

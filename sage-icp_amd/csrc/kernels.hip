@@ -160,9 +160,26 @@ SAGE_MIN_U32_DPP(min_u32_mirror, "row_mirror")
 // Control flow is wave-uniform and branch-free inside the loop (indices are clamped, invalid
 // pairs are masked by select), which keeps the scalar unit — one per CU, shared by the four
 // SIMDs — out of the critical path.
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+// One map point through the buffer path: `off` is its byte offset in the point array (what the
+// LDS candidate list holds), the resource carries the 64-bit base, so a load costs no address
+// arithmetic (a flat 64-bit address took three VALU instructions per candidate).
+__device__ __forceinline__ Point4 load_point(__amdgpu_buffer_rsrc_t pts, uint32_t off) {
+    const v4u a = __builtin_amdgcn_raw_buffer_load_b128(pts, off, 0, 0);
+    const v4u b = __builtin_amdgcn_raw_buffer_load_b128(pts, off + 16u, 0, 0);
+    Point4 q;
+    q.x = __hiloint2double(static_cast<int>(a.y), static_cast<int>(a.x));
+    q.y = __hiloint2double(static_cast<int>(a.w), static_cast<int>(a.z));
+    q.z = __hiloint2double(static_cast<int>(b.y), static_cast<int>(b.x));
+    q.l = __hiloint2double(static_cast<int>(b.w), static_cast<int>(b.z));
+    return q;
+}
+
 template <int LW>
-__device__ __forceinline__ void nn_group(const NnParams &P, const uint32_t *cand, int lane,
-                                         int start, int len, unsigned C, const Point4 &p) {
+__device__ __forceinline__ void nn_group(const NnParams &P, __amdgpu_buffer_rsrc_t pts,
+                                         const uint32_t *cand, int lane, int start, int len,
+                                         unsigned C, const Point4 &p) {
     constexpr int W = 1 << LW;
     const int qi = lane >> LW;                  // query of this lane within the group
     const unsigned ci = lane & (W - 1);
@@ -179,7 +196,8 @@ __device__ __forceinline__ void nn_group(const NnParams &P, const uint32_t *cand
         const double dx = nb.x - p.x, dy = nb.y - p.y, dz = nb.z - p.z;
         double d = dx * dx + (dy * dy + dz * dz);
         // same label, or either side unlabelled (VoxelHashMap.cpp:87-88)
-        const bool same = static_cast<int>(nb.l) == pli || static_cast<int>(nb.l * p.l) == 0;
+        // ((int)(a * b) == 0  <=>  |a * b| < 1 under truncation toward zero)
+        const bool same = static_cast<int>(nb.l) == pli || fabs(nb.l * p.l) < 1.0;
         const double ds = d * th;
         d = same ? ds : d;
         const bool take = (f < C) && (d < best);      // strict <: first minimum wins in a lane
@@ -198,7 +216,8 @@ __device__ __forceinline__ void nn_group(const NnParams &P, const uint32_t *cand
         n1 = n0; n1.x = __uint_as_float(i1); n2 = n0; n2.x = __uint_as_float(i2);
         n3 = n0; n3.x = __uint_as_float(i3);
 #else
-        const Point4 n0 = P.pts[i0], n1 = P.pts[i1], n2 = P.pts[i2], n3 = P.pts[i3];
+        const Point4 n0 = load_point(pts, i0), n1 = load_point(pts, i1), n2 = load_point(pts, i2),
+                     n3 = load_point(pts, i3);
 #endif
 #if defined(SAGE_ABLATE_NOEVAL)      // ablation: loads only, values kept live
         asm volatile("" ::"v"(n0.x), "v"(n0.l), "v"(n1.x), "v"(n1.l), "v"(n2.x), "v"(n2.l),
@@ -234,7 +253,7 @@ __device__ __forceinline__ void nn_group(const NnParams &P, const uint32_t *cand
     // (VoxelHashMap.cpp:111) is applied where the pair is consumed (k_gn / the host join).
     const uint32_t widx = cand[min(best_f, last)];
     if (active && ci == 0)
-        P.nn_idx[start + qi] = (best_f == 0xFFFFFFFFu) ? -1 : static_cast<int>(widx);
+        P.nn_idx[start + qi] = (best_f == 0xFFFFFFFFu) ? -1 : static_cast<int>(widx >> 5);
 }
 
 #ifdef SAGE_NN_TIMING
@@ -256,11 +275,14 @@ __global__ __launch_bounds__(64 * kNnWaves, 8) void k_nn(NnParams P) {
 #endif
 
     const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));   // wave-uniform
     // per-wave LDS (words): candidate list | start-mark bitmap | compacted voxel deltas |
     // the chunk's transformed queries {x, y, z, label} | their home voxels [comp][query]
     const NnLds L = nn_lds_layout(P.cap, P.chunk);
-    uint32_t *cand = smem + wv * L.wave_words;       // absolute point indices, enumeration order
+    uint32_t *cand = smem + wv * L.wave_words;       // byte offsets of the candidates, enumeration order
+    // raw buffer resource over the point array (bounds-checked, 32-bit byte offsets)
+    const __amdgpu_buffer_rsrc_t pts = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<Point4 *>(P.pts), 0, static_cast<int>(P.pts_bytes), 0x00020000);
     unsigned long long *marks = reinterpret_cast<unsigned long long *>(cand + L.marks);
     uint32_t *delta = cand + L.delta;
     double *spt = reinterpret_cast<double *>(cand + L.spt);
@@ -379,7 +401,7 @@ __global__ __launch_bounds__(64 * kNnWaves, 8) void k_nn(NnParams P) {
             asm volatile("" : "+v"(ln));   // bitmap addresses are cheaper to form than to keep live
             for (unsigned w = ln; w < nwords; w += 64u) marks[w] = 0ull;
             if (occupied) {
-                delta[r] = ob.y - ob.x;
+                delta[r] = (ob.y - ob.x) << 5;                    // byte offsets of 32-B points
                 if (ob.x) {
                     const unsigned bpos = ob.x - 1u;
                     atomicOr(&marks[bpos >> 6], 1ull << (bpos & 63u));
@@ -393,8 +415,8 @@ __global__ __launch_bounds__(64 * kNnWaves, 8) void k_nn(NnParams P) {
                     const unsigned lo = rl_u32(static_cast<unsigned>(mine), static_cast<int>(i));
                     const unsigned hi = rl_u32(static_cast<unsigned>(mine >> 32), static_cast<int>(i));
                     const unsigned rr = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, below));
-                    const unsigned f = ((wb + i) << 6) + lane;
-                    if (f < C) cand[f] = delta[rr] + f;
+                    const unsigned f = ((wb + i) << 6) + ln;
+                    if (f < C) cand[f] = delta[rr] + (f << 5);
                     below += __builtin_popcount(lo) + __builtin_popcount(hi);
                 }
             }
@@ -403,12 +425,12 @@ __global__ __launch_bounds__(64 * kNnWaves, 8) void k_nn(NnParams P) {
         NN_T(1);
 
         switch (lw) {
-            case 6: nn_group<6>(P, cand, lane, start, len, C, p); break;
-            case 5: nn_group<5>(P, cand, lane, start, len, C, p); break;
-            case 4: nn_group<4>(P, cand, lane, start, len, C, p); break;
-            case 3: nn_group<3>(P, cand, lane, start, len, C, p); break;
-            case 2: nn_group<2>(P, cand, lane, start, len, C, p); break;
-            default: nn_group<1>(P, cand, lane, start, len, C, p); break;
+            case 6: nn_group<6>(P, pts, cand, lane, start, len, C, p); break;
+            case 5: nn_group<5>(P, pts, cand, lane, start, len, C, p); break;
+            case 4: nn_group<4>(P, pts, cand, lane, start, len, C, p); break;
+            case 3: nn_group<3>(P, pts, cand, lane, start, len, C, p); break;
+            case 2: nn_group<2>(P, pts, cand, lane, start, len, C, p); break;
+            default: nn_group<1>(P, pts, cand, lane, start, len, C, p); break;
         }
         NN_T(2);
         ob = ob_next;
