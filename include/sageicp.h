@@ -51,12 +51,12 @@ typedef struct sageicp_stats {
     double us_upload;           /* frame H2D + lazy map-mirror refresh inside the call */
     /* device time per kernel summed over the executed iterations (HIP events on the launch
      * stream); filled only when profiling is enabled with sageicp_set_profiling(). */
-    double us_group;            /* k_group: pose apply + home voxel + grouping */
-    double us_nn;               /* k_nn: the correspondence search */
+    double us_group;            /* always 0 (the grouping pass is part of k_nn) */
+    double us_nn;               /* k_nn: pose apply + grouping + the correspondence search */
     double us_gn;
     double us_fin;
     uint32_t nn_launches;
-    uint32_t reserved;
+    uint32_t resorts;           /* re-sorts of the frame after the pose drifted (first sort excluded) */
     uint64_t sum_candidates;    /* sum over iterations and queries of C_q: map points stored in the
                                  * <=27 existing neighbour voxels of each query (this rank) */
     uint32_t n_corr_hist[64];   /* accepted correspondences of the first 64 iterations */

@@ -54,7 +54,7 @@ class Stats(C.Structure):
         ("us_gn", C.c_double),
         ("us_fin", C.c_double),
         ("nn_launches", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("resorts", C.c_uint32),
         ("sum_candidates", C.c_uint64),
         ("n_corr_hist", C.c_uint32 * 64),
     ]
