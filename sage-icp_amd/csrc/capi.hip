@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cfloat>
+#include <limits>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -469,7 +470,13 @@ int sync_mirror(const sageicp_map *m) {
     if (blocks_cap > m->d_blocks_cap) {
         if (m->d_pts) HIPCHK(hipFree(m->d_pts));
         m->d_pts = nullptr; m->d_blocks_cap = 0;
-        HIPCHK(hipMalloc(&m->d_pts, std::max<size_t>(blocks_cap, 1) * block_bytes));
+        // one extra point after the blocks: NaN coordinates, the target of the padding entries of
+        // k_nn's candidate lists (its distance to anything fails every comparison)
+        HIPCHK(hipMalloc(&m->d_pts, blocks_cap * block_bytes + sizeof(Point4)));
+        const double qnan = std::numeric_limits<double>::quiet_NaN();
+        const Point4 pad{qnan, qnan, qnan, qnan};
+        HIPCHK(hipMemcpy(reinterpret_cast<char *>(m->d_pts) + blocks_cap * block_bytes, &pad,
+                         sizeof(Point4), hipMemcpyHostToDevice));
         m->d_blocks_cap = blocks_cap;
         points_full = true;
     }
@@ -575,7 +582,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     NnParams np{d_frame, sc.d_src, static_cast<int>(n), sc.d_state, 1, 1, m->host.voxel_size,
                 static_cast<unsigned>(nn_chunk()), nn_chunk_log2(), nn_cap_heads(), sc.d_tabkey, sc.d_blks,
                 m->d_table, m->host.mask, m->d_pts,
-                static_cast<uint32_t>(m->d_blocks_cap * m->host.cap * sizeof(Point4)), m->host.cap,
+                static_cast<uint32_t>((m->d_blocks_cap * m->host.cap + 1) * sizeof(Point4)), m->host.cap,
                 sem_th, DBL_MAX, sc.d_nn, sc.d_cand};
     HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * (n + 1), s));
     GnParams gp{sc.d_src, nullptr, static_cast<int>(n), sc.d_state, 1, m->d_pts, sc.d_nn, kernel,
@@ -800,7 +807,7 @@ int sageicp_get_correspondences(const sageicp_map *m, const double *q, uint64_t 
     NnParams np{sc.d_sorted, sc.d_src, static_cast<int>(n), sc.d_state, 0, 0, m->host.voxel_size,
                 static_cast<unsigned>(nn_chunk()), nn_chunk_log2(), nn_cap_heads(), sc.d_tabkey, sc.d_blks,
                 m->d_table, m->host.mask, m->d_pts,
-                static_cast<uint32_t>(m->d_blocks_cap * m->host.cap * sizeof(Point4)), m->host.cap,
+                static_cast<uint32_t>((m->d_blocks_cap * m->host.cap + 1) * sizeof(Point4)), m->host.cap,
                 sem_th, DBL_MAX, sc.d_nn, nullptr};
     launch_nn(np, s);
     HIPCHK(hipGetLastError());

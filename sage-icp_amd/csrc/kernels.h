@@ -25,7 +25,8 @@ struct NnParams {
     const Slot *table;        // the open-addressed voxel hash
     uint32_t mask;
     const Point4 *pts;
-    uint32_t pts_bytes;       // size of the point array (< 4 GiB: k_nn addresses it by byte offset)
+    uint32_t pts_bytes;       // size of the point array (< 4 GiB: k_nn addresses it by byte offset);
+                              // its last 32 B hold a NaN point, the padding of candidate lists
     int cap;
     double sem_th;
     double dist_init;         // DBL_MAX
@@ -45,7 +46,7 @@ struct NnLds {
 __host__ __device__ inline NnLds nn_lds_layout(int cap, unsigned chunk) {
     NnLds l;
     const unsigned ncand = 27u * static_cast<unsigned>(cap);
-    l.marks = (ncand + 3u) & ~3u;                                  // after the candidate list
+    l.marks = (ncand + 127u) & ~127u;          // after the candidate list, padded to its widest stride
     const unsigned mark_words = (((ncand + 63u) >> 6) + 1u) & ~1u;   // 64-bit words, even count
     l.delta = l.marks + 2u * mark_words;
     l.spt = l.delta + 32u;
@@ -72,7 +73,7 @@ struct GnParams {
 
 constexpr int kMaxGnBlocks = 512;
 constexpr uint64_t kMaxQueries = (1ull << 26) - 1;
-constexpr uint64_t kMaxMapPoints = (1ull << 27) - 1;   // blocks x capacity: 32-B points under 4 GiB
+constexpr uint64_t kMaxMapPoints = (1ull << 27) - 2;   // blocks x capacity: 32-B points under 4 GiB
 
 void launch_nn(const NnParams &p, hipStream_t s);
 int launch_gn(const GnParams &p, hipStream_t s);   // returns the number of partials written

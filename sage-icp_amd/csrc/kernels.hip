@@ -190,9 +190,12 @@ __device__ __forceinline__ void nn_group(const NnParams &P, __amdgpu_buffer_rsrc
     // closest_distance2 starts at numeric_limits<double>::max() (VoxelHashMap.cpp:80); the value
     // travels as a kernel argument so that it sits in scalar registers
     double best = P.dist_init;        // scaled squared distance
-    unsigned best_f = 0xFFFFFFFFu;    // flat candidate index == enumeration order: the tie-break
+    // Lane ci visits the flat candidate indices ci, ci + W, ci + 2W, ...; it remembers the STEP
+    // (a wave-uniform counter) of its best one, the flat index — the enumeration order the
+    // tie-break needs — is rebuilt once after the loop.
+    unsigned best_step = 0xFFFFFFFFu;
 
-    auto eval = [&](unsigned f, const Point4 &nb) {
+    auto eval = [&](unsigned step, const Point4 &nb) {
         const double dx = nb.x - p.x, dy = nb.y - p.y, dz = nb.z - p.z;
         double d = dx * dx + (dy * dy + dz * dz);
         // same label, or either side unlabelled (VoxelHashMap.cpp:87-88)
@@ -200,36 +203,29 @@ __device__ __forceinline__ void nn_group(const NnParams &P, __amdgpu_buffer_rsrc
         const bool same = static_cast<int>(nb.l) == pli || fabs(nb.l * p.l) < 1.0;
         const double ds = d * th;
         d = same ? ds : d;
-        const bool take = (f < C) && (d < best);      // strict <: first minimum wins in a lane
-        best = take ? d : best;
-        best_f = take ? f : best_f;
+        const bool take = d < best;       // strict <: first minimum wins in a lane; NaN never wins
+        best = min_f64(best, d);
+        best_step = take ? step : best_step;
     };
 
-    const unsigned last = C ? C - 1 : 0;
-    for (unsigned f0 = 0; f0 < C; f0 += 4 * W) {       // uniform trip count, 4 loads in flight
-        const unsigned f = f0 + ci, f1 = f + W, f2 = f + 2 * W, f3 = f + 3 * W;
-        const uint32_t i0 = cand[min(f, last)], i1 = cand[min(f1, last)],
-                       i2 = cand[min(f2, last)], i3 = cand[min(f3, last)];
-#if defined(SAGE_ABLATE_NOLOAD)      // ablation: no global candidate loads (compute + LDS only)
-        Point4 n0, n1, n2, n3;
-        n0.x = __uint_as_float(i0); n0.y = 1.0; n0.z = 2.0; n0.l = 3.0;
-        n1 = n0; n1.x = __uint_as_float(i1); n2 = n0; n2.x = __uint_as_float(i2);
-        n3 = n0; n3.x = __uint_as_float(i3);
-#else
-        const Point4 n0 = load_point(pts, i0), n1 = load_point(pts, i1), n2 = load_point(pts, i2),
-                     n3 = load_point(pts, i3);
-#endif
-#if defined(SAGE_ABLATE_NOEVAL)      // ablation: loads only, values kept live
-        asm volatile("" ::"v"(n0.x), "v"(n0.l), "v"(n1.x), "v"(n1.l), "v"(n2.x), "v"(n2.l),
-                     "v"(n3.x), "v"(n3.l));
-        best_f = f;
-#else
-        eval(f, n0);
-        eval(f1, n1);
-        eval(f2, n2);
-        eval(f3, n3);
-#endif
+    // The list is padded up to a multiple of U * W entries with the offset of a NaN point (its
+    // distance fails d < best and leaves v_min_f64 unchanged), so the loop needs no index clamp,
+    // no bounds test, and its LDS reads sit at immediate offsets from one per-lane address.
+    constexpr int U = (LW >= 5) ? 2 : 4;               // loads in flight per lane
+    const uint32_t *cp = cand + ci;
+    unsigned step = 0;
+    for (unsigned f0 = 0; f0 < C; f0 += U * W, step += U, cp += U * W) {   // uniform trip count
+        uint32_t off[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) off[u] = cp[u * W];
+        Point4 nb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) nb[u] = load_point(pts, off[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) eval(step + static_cast<unsigned>(u), nb[u]);
     }
+    unsigned best_f = (best_step == 0xFFFFFFFFu) ? 0xFFFFFFFFu : (best_step << LW) + ci;
+    const unsigned last = C ? C - 1 : 0;
 
     // argmin over the W lanes of each query, lexicographic in (distance, enumeration index) like
     // the sequential strict-< scan it replaces: first the minimum distance (never NaN: a NaN
@@ -397,6 +393,10 @@ __global__ __launch_bounds__(64 * kNnWaves, 8) void k_nn(NnParams P) {
             const unsigned r = __builtin_amdgcn_mbcnt_hi(
                 static_cast<unsigned>(occ >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(occ), 0u));
             const unsigned nwords = (C + 63u) >> 6;
+            // entries filled: whole 64-entry words, an even number of them when the pair loop
+            // strides 128 (one query on all 64 lanes); the tail beyond C points at the NaN point
+            const unsigned nfill = (lw == 6) ? ((nwords + 1u) & ~1u) : nwords;
+            const uint32_t pad_off = P.pts_bytes - static_cast<uint32_t>(sizeof(Point4));
             unsigned ln = static_cast<unsigned>(lane);
             asm volatile("" : "+v"(ln));   // bitmap addresses are cheaper to form than to keep live
             for (unsigned w = ln; w < nwords; w += 64u) marks[w] = 0ull;
@@ -408,15 +408,15 @@ __global__ __launch_bounds__(64 * kNnWaves, 8) void k_nn(NnParams P) {
                 }
             }
             unsigned below = 0;                                   // marks in the earlier words
-            for (unsigned wb = 0; wb < nwords; wb += 64u) {
+            for (unsigned wb = 0; wb < nfill; wb += 64u) {
                 const unsigned long long mine = (wb + ln < nwords) ? marks[wb + ln] : 0ull;
-                const unsigned nw = min(64u, nwords - wb);
+                const unsigned nw = min(64u, nfill - wb);
                 for (unsigned i = 0; i < nw; ++i) {
                     const unsigned lo = rl_u32(static_cast<unsigned>(mine), static_cast<int>(i));
                     const unsigned hi = rl_u32(static_cast<unsigned>(mine >> 32), static_cast<int>(i));
                     const unsigned rr = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, below));
                     const unsigned f = ((wb + i) << 6) + ln;
-                    if (f < C) cand[f] = delta[rr] + (f << 5);
+                    cand[f] = (f < C) ? delta[rr] + (f << 5) : pad_off;
                     below += __builtin_popcount(lo) + __builtin_popcount(hi);
                 }
             }
