@@ -573,7 +573,10 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         if (dot > 1.0) dot = 1.0;
         return dt + 2.0 * std::acos(dot) * m->host.max_distance;
     };
-    const double resort_drift = 0.01 * env_int("SAGEICP_RESORT_PCT", 10) * m->host.voxel_size;
+    // (a sort costs about as much as one iteration of a 40k-point frame saves over the rest of
+    // the loop: small frames keep their first order)
+    const double resort_drift = 0.01 * env_int("SAGEICP_RESORT_PCT", 25) * m->host.voxel_size;
+    const bool resort_on = n >= static_cast<uint64_t>(env_int("SAGEICP_RESORT_MIN_N", 40000));
     if (n > 0) {
         if ((rc = sort_now())) return rc;
         d_frame = sc.d_sorted;
@@ -633,7 +636,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         }
         launched += todo;
         if (sc.h_state->done || launched >= kMaxIterations) break;
-        if (n > 0 && drift(sc.h_state->T, T_sorted) > resort_drift) {
+        if (resort_on && drift(sc.h_state->T, T_sorted) > resort_drift) {
             if ((rc = sort_now())) return rc;
             for (int i = 0; i < 7; ++i) T_sorted[i] = sc.h_state->T[i];
             ++resorts;
