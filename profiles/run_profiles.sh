@@ -17,6 +17,7 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-include
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --kernel-include-regex "$K" --output-format csv -d $OUT/pmc_sq -o pmc -- $BENCH --steps 1 --warmup 0 > /dev/null 2> $OUT/pmc_sq.err
 timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_LDS TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE --kernel-include-regex "$K" --output-format csv -d $OUT/pmc_mem -o pmc -- $BENCH --steps 1 --warmup 0 > /dev/null 2> $OUT/pmc_mem.err
 cd $R
+timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 find $OUT -name "*.db" -delete
 python profiles/summarize.py $OUT > $OUT/summary.md 2>&1
 cat $OUT/summary.md
