@@ -89,6 +89,13 @@ int sageicp_map_update(sageicp_map *map, const double *xyzl, uint64_t n, const d
 /* Update(points, pose), VoxelHashMap.cpp:149-160 */
 int sageicp_map_update_pose(sageicp_map *map, const double *xyzl, uint64_t n,
                             const double pose[7]);
+/* The same Update(points, pose) executed on the GPU against the HBM-resident map (stable sort by
+ * voxel, one lane per voxel run applying VoxelBlock::AddPoint's policy in arrival order, eviction
+ * by first-point distance).  Same result as the host entry: identical voxel blocks, free list and
+ * counts.  Afterwards the HBM copy is the authority; host-side entries (AddPoints, Pointcloud,
+ * clone ...) download it first.  SAGEICP_ERR_CAPACITY if a voxel index exceeds +-2^20. */
+int sageicp_map_update_pose_device(sageicp_map *map, const double *xyzl, uint64_t n,
+                                   const double pose[7]);
 /* Pointcloud(), VoxelHashMap.cpp:132-142.  Returns the number of points the map holds; writes
  * at most `cap` of them. */
 uint64_t sageicp_map_pointcloud(const sageicp_map *map, double *out_xyzl, uint64_t cap);
@@ -171,6 +178,8 @@ typedef struct sageicp_pipeline_config {   /* sageConfig, pipeline/sageICP.hpp:3
     const int *group_labels;          /* concatenated label lists of the groups */
     const double *group_voxel_size;   /* [n_groups] */
     int device;
+    int map_update_on_device;         /* 1: the per-frame map update runs on the GPU
+                                       * (sageicp_map_update_pose_device); 0: on the host */
 } sageicp_pipeline_config;
 
 sageicp_pipeline *sageicp_pipeline_create(const sageicp_pipeline_config *config);

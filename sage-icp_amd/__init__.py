@@ -72,6 +72,7 @@ class PipelineConfig(C.Structure):
         ("group_label_counts", C.POINTER(C.c_int)), ("group_labels", C.POINTER(C.c_int)),
         ("group_voxel_size", C.POINTER(C.c_double)),
         ("device", C.c_int),
+        ("map_update_on_device", C.c_int),
     ]
 
 
@@ -85,7 +86,7 @@ def make_pipeline_config(voxel_size_map=0.8, max_range=100.0, min_range=5.0, lab
                          local_map_range=100.0, basic=20, critical=20,
                          basic_parts_labels=(40, 44, 48, 49, 50, 70, 72), min_motion_th=0.1,
                          initial_threshold=2.0, sem_th=0.05, voxel_labels=None, voxel_size=None,
-                         device=0):
+                         device=0, map_update_on_device=True):
     """defaults: ros/launch/odometry_gt.launch.py (pre-labelled scans, dynamic filter off)"""
     voxel_labels = KITTI_VOXEL_LABELS if voxel_labels is None else voxel_labels
     voxel_size = KITTI_VOXEL_SIZE if voxel_size is None else voxel_size
@@ -99,7 +100,7 @@ def make_pipeline_config(voxel_size_map=0.8, max_range=100.0, min_range=5.0, lab
     cfg = PipelineConfig(voxel_size_map, max_range, min_range, label_max_range, local_map_range,
                          basic, critical, keep["basic"], len(basic_parts_labels), min_motion_th,
                          initial_threshold, sem_th, len(voxel_labels), keep["counts"],
-                         keep["labels"], keep["sizes"], device)
+                         keep["labels"], keep["sizes"], device, 1 if map_update_on_device else 0)
     cfg._keep = keep          # the arrays must outlive the struct
     return cfg
 
@@ -122,6 +123,7 @@ _SIGNATURES = [
     ("sageicp_map_remove_far", C.c_int, [C.c_void_p, _dp]),
     ("sageicp_map_update", C.c_int, [C.c_void_p, _dp, C.c_uint64, _dp]),
     ("sageicp_map_update_pose", C.c_int, [C.c_void_p, _dp, C.c_uint64, _dp]),
+    ("sageicp_map_update_pose_device", C.c_int, [C.c_void_p, _dp, C.c_uint64, _dp]),
     ("sageicp_map_pointcloud", C.c_uint64, [C.c_void_p, _dp, C.c_uint64]),
     ("sageicp_map_sync", C.c_int, [C.c_void_p]),
     ("sageicp_get_correspondences", C.c_int,
@@ -286,6 +288,13 @@ class VoxelHashMap:
     def RemovePointsFarFromLocation(self, origin):
         o, op = _d(origin)
         _check(lib().sageicp_map_remove_far(self._h, op))
+
+    def UpdateOnDevice(self, pts, pose):
+        """Update(points, pose) executed on the GPU against the HBM-resident map (row f-2)."""
+        pts, pp = _d(pts)
+        x, xp = _d(pose)
+        assert x.size == 7
+        _check(lib().sageicp_map_update_pose_device(self._h, pp, pts.reshape(-1, 4).shape[0], xp))
 
     def Update(self, pts, pose_or_origin):
         pts, pp = _d(pts)

@@ -3,7 +3,8 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["csrc/kernels.hip", "csrc/sort.hip", "csrc/preprocess.hip", "csrc/capi.hip"]
+SOURCES = ["csrc/kernels.hip", "csrc/sort.hip", "csrc/preprocess.hip", "csrc/map_update.hip",
+           "csrc/capi.hip"]
 HEADERS = ["csrc/kernels.h", "csrc/sageicp_types.h", "csrc/se3_math.h", "csrc/host_map.hpp", "csrc/pipeline.hpp",
            "../include/sageicp.h"]
 OUT = os.path.join(HERE, "libsageicp_hip.so")

@@ -29,6 +29,7 @@
 #include "../../include/sageicp.h"
 #include "host_map.hpp"
 #include "kernels.h"
+#include "map_update.h"
 #include "pipeline.hpp"
 #include "se3_math.h"
 #include "sageicp_types.h"
@@ -381,6 +382,22 @@ struct sageicp_map {
     mutable void *h_stage = nullptr;
     mutable void *d_stage = nullptr;
     mutable size_t stage_bytes = 0;
+    // Device-side Update() (map_update.hip).  After one the HBM copy is the authority
+    // (`on_device`) and `host` is stale until ensure_host() downloads it; `ctr` is the host's
+    // shadow of the device counters.  The auxiliary arrays are valid for the host generation
+    // they were uploaded at.
+    mutable bool on_device = false;
+    mutable uint8_t *d_zeros = nullptr;
+    mutable uint32_t *d_slot_of = nullptr;
+    mutable uint32_t *d_free = nullptr;
+    mutable MapCounters *d_ctr = nullptr;
+    mutable MapCounters *h_ctr = nullptr;       // pinned
+    mutable size_t d_aux_cap = 0;               // blocks the auxiliary arrays hold
+    mutable bool aux_valid = false;
+    mutable uint64_t aux_generation = 0;
+    mutable MapCounters ctr{};
+    mutable UpdateScratch up{};
+    mutable size_t up_n = 0, up_nb = 0;
 };
 
 struct sageicp_frame {
@@ -451,6 +468,7 @@ int sync_mirror(const sageicp_map *m) {
     int rc = m->sc.init(m->device);
     if (rc) return rc;
     HIPCHK(hipSetDevice(m->device));
+    if (m->on_device) return SAGEICP_OK;      // the HBM copy is the map
     const HostMap &h = m->host;
     hipStream_t s = m->sc.stream;
     bool any = false;
@@ -521,6 +539,223 @@ int sync_mirror(const sageicp_map *m) {
     return SAGEICP_OK;
 }
 
+// ---- device-side Update() (row f-2) -----------------------------------------------------------
+bool map_is_empty(const sageicp_map *m) {
+    return m->on_device ? m->ctr.num_voxels == 0 : m->host.empty();
+}
+
+// Bring `host` up to date after device-side updates: download table, blocks, counts and free list
+// and let HostMap rebuild itself from them.  The host table is rebuilt without tombstones, so the
+// device table (and the block -> slot map) is stale afterwards and is re-uploaded on next use.
+int ensure_host(const sageicp_map *m) {
+    if (!m->on_device) return SAGEICP_OK;
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t s = m->sc.stream;
+    HostMap &h = const_cast<HostMap &>(m->host);
+    const MapCounters c = m->ctr;
+    std::vector<Slot> tab(m->d_table_cap);
+    std::vector<uint8_t> zeros(std::max<uint32_t>(c.blocks_hi, 1));
+    std::vector<uint32_t> fl(std::max<uint32_t>(c.free_count, 1));
+    HIPCHK(hipMemcpyAsync(tab.data(), m->d_table, tab.size() * sizeof(Slot), hipMemcpyDeviceToHost, s));
+    if (c.blocks_hi)
+        HIPCHK(hipMemcpyAsync(zeros.data(), m->d_zeros, c.blocks_hi, hipMemcpyDeviceToHost, s));
+    if (c.free_count)
+        HIPCHK(hipMemcpyAsync(fl.data(), m->d_free, c.free_count * sizeof(uint32_t),
+                              hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    h.adopt(tab, m->d_blocks_cap, c.blocks_hi, zeros.data(), fl.data(), c.free_count, c.num_voxels,
+            c.total_points);
+    if (c.blocks_hi) {
+        HIPCHK(hipMemcpyAsync(h.pts.data(), m->d_pts,
+                              static_cast<size_t>(c.blocks_hi) * h.cap * sizeof(Point4),
+                              hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    m->on_device = false;
+    m->aux_valid = false;
+    return SAGEICP_OK;
+}
+
+static int reserve_update_scratch(const sageicp_map *m, size_t n, size_t nb) {
+    UpdateScratch &u = m->up;
+    if (n > m->up_n) {
+        const size_t c = n + n / 2 + 1024;
+        void *olds[] = {u.raw, u.w, u.keys, u.keys_alt, u.idx, u.idx_alt, u.head_slot, u.flag, u.rank};
+        for (void *q : olds)
+            if (q) HIPCHK(hipFree(q));
+        u = UpdateScratch{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                          u.far_flag, u.far_sel, u.n_sel, u.temp, u.temp_bytes};
+        m->up_n = 0;
+        HIPCHK(hipMalloc(&u.raw, c * sizeof(Point4)));
+        HIPCHK(hipMalloc(&u.w, c * sizeof(Point4)));
+        HIPCHK(hipMalloc(&u.keys, c * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc(&u.keys_alt, c * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc(&u.idx, c * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&u.idx_alt, c * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&u.head_slot, c * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&u.flag, (c + 1) * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&u.rank, (c + 1) * sizeof(uint32_t)));
+        m->up_n = c;
+    }
+    if (nb > m->up_nb) {
+        const size_t c = nb + nb / 2 + 1024;
+        if (u.far_flag) HIPCHK(hipFree(u.far_flag));
+        if (u.far_sel) HIPCHK(hipFree(u.far_sel));
+        u.far_flag = u.far_sel = nullptr;
+        m->up_nb = 0;
+        HIPCHK(hipMalloc(&u.far_flag, c * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&u.far_sel, c * sizeof(uint32_t)));
+        m->up_nb = c;
+    }
+    if (!u.n_sel) HIPCHK(hipMalloc(&u.n_sel, sizeof(uint32_t)));
+    const size_t tb = map_update_temp_bytes(static_cast<int>(m->up_n), static_cast<int>(m->up_nb));
+    if (tb > u.temp_bytes) {
+        if (u.temp) HIPCHK(hipFree(u.temp));
+        u.temp = nullptr; u.temp_bytes = 0;
+        HIPCHK(hipMalloc(&u.temp, tb));
+        u.temp_bytes = tb;
+    }
+    return SAGEICP_OK;
+}
+
+// (re)allocate the per-block device arrays for `blocks` blocks, keeping the first `keep` blocks
+static int grow_device_blocks(const sageicp_map *m, size_t blocks, size_t keep) {
+    hipStream_t s = m->sc.stream;
+    const size_t block_bytes = static_cast<size_t>(m->host.cap) * sizeof(Point4);
+    if (blocks > m->d_blocks_cap) {
+        Point4 *np_ = nullptr;
+        HIPCHK(hipMalloc(&np_, blocks * block_bytes + sizeof(Point4)));
+        if (keep && m->d_pts)
+            HIPCHK(hipMemcpyAsync(np_, m->d_pts, keep * block_bytes, hipMemcpyDeviceToDevice, s));
+        const double qnan = std::numeric_limits<double>::quiet_NaN();
+        const Point4 pad{qnan, qnan, qnan, qnan};
+        HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(np_) + blocks * block_bytes, &pad, sizeof(Point4),
+                              hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (m->d_pts) HIPCHK(hipFree(m->d_pts));
+        m->d_pts = np_;
+        m->d_blocks_cap = blocks;
+    }
+    if (m->d_blocks_cap > m->d_aux_cap) {
+        const size_t nb = m->d_blocks_cap;
+        uint8_t *z = nullptr;
+        uint32_t *so = nullptr, *fl = nullptr;
+        HIPCHK(hipMalloc(&z, nb));
+        HIPCHK(hipMalloc(&so, nb * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&fl, nb * sizeof(uint32_t)));
+        HIPCHK(hipMemsetAsync(z, 0, nb, s));
+        HIPCHK(hipMemsetAsync(so, 0xFF, nb * sizeof(uint32_t), s));        // kNoSlot
+        if (keep && m->d_zeros) {
+            HIPCHK(hipMemcpyAsync(z, m->d_zeros, keep, hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemcpyAsync(so, m->d_slot_of, keep * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemcpyAsync(fl, m->d_free, std::min(keep, m->d_aux_cap) * sizeof(uint32_t),
+                                  hipMemcpyDeviceToDevice, s));
+        }
+        HIPCHK(hipStreamSynchronize(s));
+        if (m->d_zeros) HIPCHK(hipFree(m->d_zeros));
+        if (m->d_slot_of) HIPCHK(hipFree(m->d_slot_of));
+        if (m->d_free) HIPCHK(hipFree(m->d_free));
+        m->d_zeros = z; m->d_slot_of = so; m->d_free = fl;
+        m->d_aux_cap = nb;
+    }
+    if (!m->d_ctr) {
+        HIPCHK(hipMalloc(&m->d_ctr, sizeof(MapCounters)));
+        HIPCHK(hipHostMalloc(&m->h_ctr, sizeof(MapCounters), hipHostMallocDefault));
+    }
+    return SAGEICP_OK;
+}
+
+// VoxelHashMap::Update(points, pose) on the device.
+int device_update(sageicp_map *m, const double *xyzl, uint64_t n, const double pose[7]) {
+    if (m->host.basic_labels.size() > static_cast<size_t>(kMaxBasicLabels))
+        return fail(SAGEICP_ERR_INVALID, "device map update supports at most 32 basic_parts_labels");
+    if (n > 0x3FFFFFFFull) return fail(SAGEICP_ERR_INVALID, "too many points");
+    int rc = m->sc.init(m->device);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t s = m->sc.stream;
+    const HostMap &h = m->host;
+    if (!m->on_device) {
+        if ((rc = sync_mirror(m))) return rc;       // table + points as the host has them
+        m->ctr = MapCounters{};
+        m->ctr.blocks_hi = h.blocks_hi;
+        m->ctr.free_count = static_cast<uint32_t>(h.free_blocks.size());
+        m->ctr.num_voxels = h.num_voxels;
+        m->ctr.used_slots = h.num_voxels;
+        m->ctr.total_points = h.total_points;
+    }
+    // capacity for the worst case (every point opens a voxel); the host rule is load <= 1/4
+    const uint64_t need_blocks = static_cast<uint64_t>(m->ctr.blocks_hi) + n;
+    if (need_blocks >= (1ull << kMaxBlockBits)) return fail(SAGEICP_ERR_CAPACITY, "more than 2^23 voxels");
+    size_t blocks = m->d_blocks_cap;
+    if (need_blocks > blocks) blocks = std::max<size_t>(need_blocks, std::max<size_t>(1024, 2 * blocks));
+    if (static_cast<uint64_t>(blocks) * h.cap > kMaxMapPoints) {
+        blocks = need_blocks;
+        if (static_cast<uint64_t>(blocks) * h.cap > kMaxMapPoints)
+            return fail(SAGEICP_ERR_CAPACITY, "voxel blocks x capacity beyond 2^27 points");
+    }
+    if ((rc = grow_device_blocks(m, blocks, m->ctr.blocks_hi))) return rc;
+    if (!m->on_device && !(m->aux_valid && m->aux_generation == h.generation)) {
+        // auxiliary arrays from the host's view of the map
+        const std::vector<uint32_t> so = h.slot_of_blocks();
+        if (h.blocks_hi) {
+            HIPCHK(hipMemcpyAsync(m->d_zeros, h.zeros.data(), h.blocks_hi, hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(m->d_slot_of, so.data(), h.blocks_hi * sizeof(uint32_t),
+                                  hipMemcpyHostToDevice, s));
+        }
+        if (!h.free_blocks.empty())
+            HIPCHK(hipMemcpyAsync(m->d_free, h.free_blocks.data(), h.free_blocks.size() * sizeof(uint32_t),
+                                  hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        m->aux_valid = true;
+        m->aux_generation = h.generation;
+    }
+    *m->h_ctr = m->ctr;
+    m->h_ctr->n_new = m->h_ctr->n_far = m->h_ctr->overflow = 0;
+    HIPCHK(hipMemcpyAsync(m->d_ctr, m->h_ctr, sizeof(MapCounters), hipMemcpyHostToDevice, s));
+
+    DevMap dm{m->d_table, static_cast<uint32_t>(m->d_table_cap - 1), m->d_pts, h.cap, m->d_zeros,
+              m->d_slot_of, m->d_free, m->d_ctr};
+    // table: (live + tombstoned + incoming) slots must stay within a quarter of the capacity
+    if ((static_cast<uint64_t>(m->ctr.used_slots) + n) * 4 > m->d_table_cap) {
+        size_t cap = 1024;
+        while ((static_cast<uint64_t>(m->ctr.num_voxels) + n) * 4 > cap) cap *= 2;
+        cap = std::max(cap, m->d_table_cap);
+        Slot *nt = nullptr;
+        HIPCHK(hipMalloc(&nt, cap * sizeof(Slot)));
+        HIPCHK(map_rebuild_table(dm, nt, static_cast<uint32_t>(cap - 1), m->ctr.blocks_hi, s));
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipFree(m->d_table));
+        m->d_table = nt;
+        m->d_table_cap = cap;
+        m->ctr.used_slots = m->ctr.num_voxels;
+        dm.table = nt;
+        dm.mask = static_cast<uint32_t>(cap - 1);
+    }
+    const uint32_t bound = static_cast<uint32_t>(need_blocks);
+    if ((rc = reserve_update_scratch(m, n, bound))) return rc;
+    if (n) HIPCHK(hipMemcpyAsync(m->up.raw, xyzl, n * sizeof(Point4), hipMemcpyHostToDevice, s));
+    UpdatePolicy pol{};
+    pol.voxel_size = h.voxel_size;
+    pol.max_dist2 = h.max_distance * h.max_distance;
+    pol.basic = h.basic;
+    pol.critical = h.critical;
+    pol.n_labels = static_cast<int>(h.basic_labels.size());
+    for (int i = 0; i < pol.n_labels; ++i) pol.labels[i] = h.basic_labels[i];
+    HIPCHK(map_update_device(dm, pol, m->up, static_cast<int>(n), pose, bound, s));
+    HIPCHK(hipMemcpyAsync(m->h_ctr, m->d_ctr, sizeof(MapCounters), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (m->h_ctr->overflow) {
+        // nothing was inserted or evicted (every kernel checks the flag first)
+        return fail(SAGEICP_ERR_CAPACITY, "voxel index beyond +-2^20 in the device map update");
+    }
+    m->ctr = *m->h_ctr;
+    m->on_device = true;
+    const_cast<HostMap &>(h).clear_dirty();
+    m->mirror_stale_all = false;
+    return SAGEICP_OK;
+}
+
 void identity_pose(double T[7]) {
     T[0] = T[1] = T[2] = 0.0; T[3] = 1.0; T[4] = T[5] = T[6] = 0.0;
 }
@@ -584,7 +819,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
 
     NnParams np{d_frame, sc.d_src, static_cast<int>(n), sc.d_state, 1, 1, m->host.voxel_size,
                 static_cast<unsigned>(nn_chunk()), nn_chunk_log2(), nn_cap_heads(), sc.d_tabkey, sc.d_blks,
-                m->d_table, m->host.mask, m->d_pts,
+                m->d_table, static_cast<uint32_t>(m->d_table_cap - 1), m->d_pts,
                 static_cast<uint32_t>((m->d_blocks_cap * m->host.cap + 1) * sizeof(Point4)), m->host.cap,
                 sem_th, DBL_MAX, sc.d_nn, sc.d_cand};
     HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * (n + 1), s));
@@ -711,6 +946,12 @@ void sageicp_map_destroy(sageicp_map *m) {
         if (m->d_pts) (void)hipFree(m->d_pts);
         if (m->d_stage) (void)hipFree(m->d_stage);
         if (m->h_stage) (void)hipHostFree(m->h_stage);
+        void *aux[] = {m->d_zeros, m->d_slot_of, m->d_free, m->d_ctr, m->up.raw, m->up.w, m->up.keys,
+                       m->up.keys_alt, m->up.idx, m->up.idx_alt, m->up.head_slot, m->up.flag, m->up.rank,
+                       m->up.far_flag, m->up.far_sel, m->up.n_sel, m->up.temp};
+        for (void *q : aux)
+            if (q) (void)hipFree(q);
+        if (m->h_ctr) (void)hipHostFree(m->h_ctr);
     }
     m->sc.destroy();
     delete m;
@@ -718,6 +959,7 @@ void sageicp_map_destroy(sageicp_map *m) {
 
 sageicp_map *sageicp_map_clone(const sageicp_map *src) {
     if (!src) return nullptr;
+    if (ensure_host(src)) return nullptr;
     sageicp_map *m = new sageicp_map;
     m->host = src->host;
     m->device = src->device;
@@ -727,16 +969,25 @@ sageicp_map *sageicp_map_clone(const sageicp_map *src) {
 
 int sageicp_map_clear(sageicp_map *m) {
     if (!m) return fail(SAGEICP_ERR_INVALID, "null map");
+    m->on_device = false;     // whatever the device holds is dropped with the rest
+    m->aux_valid = false;
     m->host.clear();
     m->mirror_stale_all = true;
     return SAGEICP_OK;
 }
-int sageicp_map_empty(const sageicp_map *m) { return (!m || m->host.empty()) ? 1 : 0; }
-uint64_t sageicp_map_size(const sageicp_map *m) { return m ? m->host.total_points : 0; }
-uint64_t sageicp_map_num_voxels(const sageicp_map *m) { return m ? m->host.num_voxels : 0; }
+int sageicp_map_empty(const sageicp_map *m) { return (!m || map_is_empty(m)) ? 1 : 0; }
+uint64_t sageicp_map_size(const sageicp_map *m) {
+    if (!m) return 0;
+    return m->on_device ? m->ctr.total_points : m->host.total_points;
+}
+uint64_t sageicp_map_num_voxels(const sageicp_map *m) {
+    if (!m) return 0;
+    return m->on_device ? m->ctr.num_voxels : m->host.num_voxels;
+}
 
 int sageicp_map_add_points(sageicp_map *m, const double *xyzl, uint64_t n) {
     if (!m || (n && !xyzl)) return fail(SAGEICP_ERR_INVALID, "null argument");
+    if (int rc = ensure_host(m)) return rc;
     m->host.add_points(xyzl, n);
     if (m->host.blocks_hi >= (1u << kMaxBlockBits))
         return fail(SAGEICP_ERR_CAPACITY, "more than 2^23 voxels");
@@ -747,6 +998,7 @@ int sageicp_map_add_points(sageicp_map *m, const double *xyzl, uint64_t n) {
 
 int sageicp_map_remove_far(sageicp_map *m, const double origin[3]) {
     if (!m || !origin) return fail(SAGEICP_ERR_INVALID, "null argument");
+    if (int rc = ensure_host(m)) return rc;
     m->host.remove_far(origin);
     return SAGEICP_OK;
 }
@@ -770,8 +1022,14 @@ int sageicp_map_update_pose(sageicp_map *m, const double *xyzl, uint64_t n, cons
     return sageicp_map_update(m, w.data(), n, pose + 4);
 }
 
+int sageicp_map_update_pose_device(sageicp_map *m, const double *xyzl, uint64_t n, const double pose[7]) {
+    if (!m || (n && !xyzl) || !pose) return fail(SAGEICP_ERR_INVALID, "null argument");
+    return device_update(m, xyzl, n, pose);
+}
+
 uint64_t sageicp_map_pointcloud(const sageicp_map *m, double *out, uint64_t cap) {
     if (!m) return 0;
+    if (ensure_host(m)) return 0;
     return m->host.pointcloud(out, out ? cap : 0);
 }
 
@@ -788,9 +1046,10 @@ int sageicp_get_correspondences(const sageicp_map *m, const double *q, uint64_t 
         return fail(SAGEICP_ERR_INVALID, "null argument");
     if (n > kMaxQueries) return fail(SAGEICP_ERR_INVALID, "too many queries (2^26 max)");
     *n_out = 0;
-    int rc = sync_mirror(m);
+    int rc = ensure_host(m);      // the returned target points are read from the host copy
     if (rc) return rc;
-    if (n == 0 || m->host.empty()) return SAGEICP_OK;
+    if ((rc = sync_mirror(m))) return rc;
+    if (n == 0 || map_is_empty(m)) return SAGEICP_OK;
     Scratch &sc = m->sc;
     if ((rc = sc.reserve_frame(n))) return rc;
     if ((rc = sc.reserve_nn(n))) return rc;
@@ -809,7 +1068,7 @@ int sageicp_get_correspondences(const sageicp_map *m, const double *q, uint64_t 
     HIPCHK(hipMemsetAsync(sc.d_tabkey, 0x7F, (n + 1) * sizeof(int4), s));
     NnParams np{sc.d_sorted, sc.d_src, static_cast<int>(n), sc.d_state, 0, 0, m->host.voxel_size,
                 static_cast<unsigned>(nn_chunk()), nn_chunk_log2(), nn_cap_heads(), sc.d_tabkey, sc.d_blks,
-                m->d_table, m->host.mask, m->d_pts,
+                m->d_table, static_cast<uint32_t>(m->d_table_cap - 1), m->d_pts,
                 static_cast<uint32_t>((m->d_blocks_cap * m->host.cap + 1) * sizeof(Point4)), m->host.cap,
                 sem_th, DBL_MAX, sc.d_nn, nullptr};
     launch_nn(np, s);
@@ -915,7 +1174,7 @@ int sageicp_register_frame(const sageicp_map *m, const double *frame, uint64_t n
                            double pose_out[7], sageicp_stats *stats) {
     if (!m || !init || !pose_out || (n && !frame)) return fail(SAGEICP_ERR_INVALID, "null argument");
     const double t0 = now_us();
-    if (m->host.empty()) {   // Registration.cpp:119
+    if (map_is_empty(m)) {   // Registration.cpp:119
         std::memcpy(pose_out, init, 56);
         if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->n_queries = n; }
         return SAGEICP_OK;
@@ -967,7 +1226,7 @@ int sageicp_register_frame_resident(const sageicp_map *m, const sageicp_frame *f
     if (f->device != m->device) return fail(SAGEICP_ERR_INVALID, "frame and map live on different devices");
     if (comm && comm->device != m->device) return fail(SAGEICP_ERR_INVALID, "comm and map live on different devices");
     const double t0 = now_us();
-    if (m->host.empty()) {
+    if (map_is_empty(m)) {
         std::memcpy(pose_out, init, 56);
         if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->n_queries = f->n; }
         return SAGEICP_OK;

@@ -137,6 +137,44 @@ public:
         return k;
     }
 
+    // Take over the state a device-side update left in HBM (capi.hip ensure_host): the device
+    // table (any slot layout, tombstones allowed), the first `bhi` point blocks, the per-block
+    // unlabelled counts, the free-list stack and the counters.  The host table is rebuilt
+    // tombstone-free at the same capacity, so afterwards it must be uploaded as a whole.
+    void adopt(const std::vector<Slot> &dtab, size_t blocks_cap, uint32_t bhi, const uint8_t *dzeros,
+               const uint32_t *dfree, uint32_t nfree, uint32_t nvox, uint64_t total) {
+        reset_table(static_cast<uint32_t>(dtab.size()));
+        cnt.assign(blocks_cap, 0);
+        zeros.assign(blocks_cap, 0);
+        keys.assign(3 * blocks_cap, 0);
+        pts.resize(blocks_cap * cap, Point4{0, 0, 0, 0});     // blocks [0, bhi) filled by the caller
+        for (const Slot &e : dtab) {
+            if (e.blk == kEmptySlot || e.blk == kTombstone) continue;
+            table[probe(e.x, e.y, e.z)] = e;
+            const uint32_t b = e.blk >> 8;
+            cnt[b] = static_cast<uint8_t>(e.blk & 255u);
+            keys[3 * b] = e.x; keys[3 * b + 1] = e.y; keys[3 * b + 2] = e.z;
+        }
+        if (bhi) std::memcpy(zeros.data(), dzeros, bhi);
+        free_blocks.assign(dfree, dfree + nfree);
+        blocks_hi = bhi;
+        num_voxels = nvox;
+        total_points = total;
+        dirty_pts.clear();
+        dirty_slots.clear();
+        table_all_dirty = true;
+        points_all_dirty = false;
+        ++generation;
+    }
+
+    // block -> slot map of the current table (kNoSlot for free blocks), for the device-side update
+    std::vector<uint32_t> slot_of_blocks() const {
+        std::vector<uint32_t> so(cnt.size(), kNoSlot);
+        for (uint32_t s = 0; s <= mask; ++s)
+            if (table[s].blk != kEmptySlot) so[table[s].blk >> 8] = s;
+        return so;
+    }
+
     void clear_dirty() {
         dirty_pts.clear();
         dirty_slots.clear();

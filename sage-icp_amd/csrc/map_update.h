@@ -1,0 +1,77 @@
+// Device-side map maintenance: VoxelHashMap::Update(points, pose)
+// = AddPoints + RemovePointsFarFromLocation (reference core/VoxelHashMap.cpp:149-184, retention
+// policy core/VoxelHashMap.hpp:45-70) applied directly to the HBM-resident map.
+//
+// The result is bit-identical to HostMap (host_map.hpp) in everything that is observable: the
+// point blocks (which voxel owns which block, which points it keeps, in which order), the free
+// list and the counters.  Only the position of a voxel's slot inside the open-addressed table may
+// differ (concurrent claims; evicted voxels leave tombstones instead of a backward shift), which
+// no search result depends on.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "sageicp_types.h"
+
+namespace sageicp {
+
+constexpr int kMaxBasicLabels = 32;
+
+struct MapCounters {
+    uint32_t blocks_hi;      // high-water mark of block indices
+    uint32_t free_count;     // entries of the free list (a stack: the last one is handed out first)
+    uint32_t num_voxels;
+    uint32_t used_slots;     // live + tombstoned slots (what the load factor is computed from)
+    uint64_t total_points;
+    uint32_t n_new;          // voxels created by the last update
+    uint32_t n_far;          // voxels evicted by the last update
+    uint32_t overflow;       // a voxel index beyond +-2^20 was seen (update rejected)
+    uint32_t pad;
+};
+
+struct DevMap {
+    Slot *table;
+    uint32_t mask;
+    Point4 *pts;
+    int cap;
+    uint8_t *zeros;          // unlabelled points per block
+    uint32_t *slot_of;       // block -> its slot (kNoSlot for a free block)
+    uint32_t *free_list;
+    MapCounters *ctr;
+};
+
+struct UpdatePolicy {
+    double voxel_size;
+    double max_dist2;
+    int basic, critical;
+    int n_labels;
+    int labels[kMaxBasicLabels];
+};
+
+struct UpdateScratch {       // device buffers sized for n points / nb blocks (capi.hip reserves them)
+    Point4 *raw;             // [n] the caller's points
+    Point4 *w;               // [n] transformed into the map frame
+    unsigned long long *keys, *keys_alt;   // [n]
+    uint32_t *idx, *idx_alt;               // [n]
+    uint32_t *head_slot;     // [n]
+    uint32_t *flag;          // [n + 1]
+    uint32_t *rank;          // [n + 1]
+    uint32_t *far_flag;      // [nb]
+    uint32_t *far_sel;       // [nb]
+    uint32_t *n_sel;         // [1]
+    void *temp;
+    size_t temp_bytes;
+};
+
+size_t map_update_temp_bytes(int n, int nb);
+
+// Update(points, pose): w = pose * raw, insert in order, evict voxels far from pose.translation.
+// `blocks_hi_bound` >= the map's block high-water mark after the insert (grid size only).
+hipError_t map_update_device(const DevMap &M, const UpdatePolicy &P, const UpdateScratch &S, int n,
+                             const double pose[7], uint32_t blocks_hi_bound, hipStream_t s);
+
+// Re-insert every live voxel into a fresh (larger or tombstone-free) table.
+hipError_t map_rebuild_table(const DevMap &M, Slot *new_table, uint32_t new_mask,
+                             uint32_t blocks_hi_bound, hipStream_t s);
+
+}  // namespace sageicp

@@ -36,7 +36,8 @@ class Pipeline {
 public:
     explicit Pipeline(const sageicp_pipeline_config &c)
         : max_range(c.max_range), min_range(c.min_range), label_max_range(c.label_max_range),
-          min_motion_th(c.min_motion_th), initial_threshold(c.initial_threshold), sem_th(c.sem_th) {
+          min_motion_th(c.min_motion_th), initial_threshold(c.initial_threshold), sem_th(c.sem_th),
+          map_update_on_device(c.map_update_on_device != 0) {
         const int *gl = c.group_labels;
         for (int g = 0; g < c.n_groups; ++g) {
             groups.emplace_back(gl, gl + c.group_label_counts[g]);
@@ -96,8 +97,11 @@ public:
         Pose7 ginv;
         se3_inv(guess.v, ginv.v);
         se3_mul(ginv.v, new_pose.v, model_deviation.v);       // UpdateModelDeviation
-        rc = sageicp_map_update_pose(map, frame_downsample.data(), frame_downsample.size() / 4,
-                                     new_pose.v);
+        rc = map_update_on_device
+                 ? sageicp_map_update_pose_device(map, frame_downsample.data(),
+                                                  frame_downsample.size() / 4, new_pose.v)
+                 : sageicp_map_update_pose(map, frame_downsample.data(), frame_downsample.size() / 4,
+                                           new_pose.v);
         if (rc) return rc;
         poses.push_back(new_pose);
         for (int i = 0; i < 7; ++i) pose_out[i] = new_pose.v[i];
@@ -151,6 +155,7 @@ private:
 
     double max_range, min_range, label_max_range;
     double min_motion_th, initial_threshold, sem_th;
+    bool map_update_on_device;
     std::vector<std::vector<int>> groups;
     std::vector<double> group_voxel;
     double model_error_sse2 = 0.0;

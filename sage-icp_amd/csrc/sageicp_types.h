@@ -21,6 +21,11 @@ struct alignas(16) Slot {
     uint32_t blk;
 };
 constexpr uint32_t kEmptySlot = 0xFFFFFFFFu;
+// device-side map update (map_update.hip): an evicted voxel's slot keeps the probe chain intact
+// as a tombstone — a non-empty blk word and a key no stored voxel can have (|index| < 2^20)
+constexpr uint32_t kTombstone = 0xFFFFFFFEu;
+constexpr int32_t kTombKey = 0x7F7F7F7F;
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 constexpr int kMaxBlockBits = 23;   // block_index < 2^23
 constexpr int kMaxCap = 255;        // basic + critical points per voxel
 

@@ -1,0 +1,123 @@
+"""Device-side VoxelHashMap::Update (map_update.hip) against the host map of the
+product (bit-identical block contents and order expected) and against the CPU oracle (same set
+of points per voxel, same search results).  Needs the MI355X."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LABELS = (0, 0, 40, 44, 50, 70, 71, 80, 99)       # 0 twice: plenty of unlabelled points
+
+
+def _sorted(a):
+    return a[np.lexsort(a.T)]
+
+
+def _frames(seed, n_frames, n_pts, box, step, labels=LABELS):
+    """points in the SENSOR frame + the poses that carry them along a curved path"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(n_frames):
+        p = rng.uniform(-box, box, size=(n_pts, 4))
+        p[:, 2] = rng.uniform(-1.5, 2.5, n_pts)
+        p[:, 3] = rng.choice(labels, size=n_pts)
+        yaw = 0.05 * k
+        pose = np.array([0.0, 0.0, np.sin(yaw / 2), np.cos(yaw / 2), step * k, 0.3 * step * k, 0.0])
+        out.append((p, pose))
+    return out
+
+
+def _maps(sage, oracle, vs, md, basic, critical):
+    kw = dict(basic_points_per_voxel=basic, critical_points_per_voxel=critical)
+    return (sage.VoxelHashMap(vs, md, **kw), sage.VoxelHashMap(vs, md, **kw),
+            oracle.Map(vs, md, basic, critical))
+
+
+@pytest.mark.parametrize("vs,md,basic,critical,n_pts,box,step", [
+    (1.0, 25.0, 3, 2, 6000, 9.0, 4.0),       # small capacities: every branch of the policy, evictions
+    (0.5, 40.0, 20, 20, 20000, 30.0, 6.0),   # reference capacities, table growth on the device
+    (1.0, 12.0, 1, 0, 3000, 10.0, 7.0),      # one point per voxel, heavy eviction / block reuse
+    (2.0, 1000.0, 0, 4, 4000, 40.0, 5.0),    # basic = 0: only the first point and critical labels
+])
+def test_device_update_equals_host_update(gpu_sage, oracle, vs, md, basic, critical, n_pts, box, step):
+    sage = gpu_sage
+    dev, host, orc = _maps(sage, oracle, vs, md, basic, critical)
+    for k, (p, pose) in enumerate(_frames(5, 9, n_pts, box, step)):
+        dev.UpdateOnDevice(p, pose)
+        host.Update(p, pose)
+        w = sage.transform_points(pose, p)
+        orc.add_points(w)
+        orc.remove_far(pose[4:])
+        assert dev.size() == host.size() == orc.size(), "frame %d" % k
+        assert dev.num_voxels() == host.num_voxels(), "frame %d" % k
+    a, b = dev.Pointcloud(), host.Pointcloud()
+    assert np.array_equal(a, b), "blocks differ from the host map (content or order)"
+    assert np.array_equal(_sorted(a), _sorted(orc.pointcloud()))
+
+
+def test_device_update_interleaved_with_host_entries(gpu_sage, oracle):
+    """authority moves device -> host -> device; searches in between stay index-exact"""
+    sage = gpu_sage
+    dev, host, orc = _maps(sage, oracle, 1.0, 30.0, 4, 3)
+    rng = np.random.default_rng(3)
+    for k, (p, pose) in enumerate(_frames(11, 8, 5000, 10.0, 5.0)):
+        if k % 3 == 2:                       # a host-side entry between device updates
+            extra = rng.uniform(-8, 8, size=(700, 4)) + np.append(pose[4:], 0)
+            extra[:, 3] = rng.choice(LABELS, size=len(extra))
+            dev.AddPoints(extra)
+            host.AddPoints(extra)
+            orc.add_points(extra)
+        dev.UpdateOnDevice(p, pose)
+        host.Update(p, pose)
+        orc.add_points(sage.transform_points(pose, p))
+        orc.remove_far(pose[4:])
+        q = rng.uniform(-9, 9, size=(1500, 4)) + np.append(pose[4:], 0)
+        q[:, 3] = rng.choice(LABELS, size=len(q))
+        if k % 2 == 0:                       # GetCorrespondences downloads; RegisterFrame does not
+            _, tgt, idx = dev.GetCorrespondences(q, 3.0, 0.4, with_index=True)
+            _, otgt, oidx = orc.get_correspondences(q, 3.0, 0.4, with_index=True)
+            assert np.array_equal(idx, oidx) and np.array_equal(tgt, otgt), "frame %d" % k
+    assert np.array_equal(dev.Pointcloud(), host.Pointcloud())
+    c = dev.clone()
+    assert np.array_equal(c.Pointcloud(), host.Pointcloud())
+    dev.Clear()
+    assert dev.size() == 0 and dev.Empty()
+
+
+def test_register_frame_on_a_device_updated_map(gpu_sage, oracle):
+    """the search runs on the HBM copy a device update left behind (tombstones, claimed slots)"""
+    sage = gpu_sage
+    dev, host, _ = _maps(sage, oracle, 1.0, 40.0, 20, 20)
+    fr = _frames(21, 6, 15000, 25.0, 3.0)
+    for p, pose in fr:
+        dev.UpdateOnDevice(p, pose)
+        host.Update(p, pose)
+    scan, pose = fr[-1]
+    guess = pose.copy()
+    guess[4:] += [0.3, -0.2, 0.05]
+    Ta, sa = sage.register_frame(scan[:8000], dev, guess, 3.0, 0.5, 0.4, return_stats=True)
+    Tb, sb = sage.register_frame(scan[:8000], host, guess, 3.0, 0.5, 0.4, return_stats=True)
+    assert sa.iterations == sb.iterations and sa.n_corr_last == sb.n_corr_last
+    assert np.array_equal(Ta, Tb), "same blocks => the same candidates in the same order"
+
+
+def test_pipeline_with_device_map_update_matches_host_map_update(gpu_sage, oracle):
+    sage = gpu_sage
+    from sage_icp_amd import synthetic as syn
+    frames, _ = syn.make_stream(9, 6, points_per_frame=30000)
+    a = sage.SageICP(sage.make_pipeline_config(map_update_on_device=True))
+    b = sage.SageICP(sage.make_pipeline_config(map_update_on_device=False))
+    for f in frames:
+        pa = a.RegisterFrame(f)[0]
+        pb = b.RegisterFrame(f)[0]
+        assert np.array_equal(pa, pb)
+    assert np.array_equal(a.LocalMap(), b.LocalMap())
+
+
+def test_device_update_rejects_far_voxel_indices(gpu_sage):
+    sage = gpu_sage
+    m = sage.VoxelHashMap(0.001, 1e9)
+    p = np.array([[0.5, 0.5, 0.5, 40.0], [2000.0, 0.0, 0.0, 40.0]])     # 2e6 voxels away
+    with pytest.raises(sage.SageIcpError):
+        m.UpdateOnDevice(p, sage.IDENTITY)
+    assert m.size() == 0
