@@ -5,7 +5,9 @@ import numpy as np
 import sage_icp_amd as sage
 from sage_icp_amd import synthetic as syn
 frames, truth = syn.make_stream(21, 40, points_per_frame=120000)
-p = sage.SageICP(sage.make_pipeline_config())
+dev_update = os.environ.get("STREAM_HOST_MAP_UPDATE", "0") != "1"
+p = sage.SageICP(sage.make_pipeline_config(map_update_on_device=dev_update))
+print("map update on", "device" if dev_update else "host")
 sage.set_profiling(2 if len(sys.argv) > 1 else 0)
 kt = []
 rows = []
@@ -20,7 +22,7 @@ print("frames %d  source pts %.0f  iterations %.1f" % (len(r), r[:, 3].mean(), r
 print("per frame ms: wall %.2f  (preprocess+voxelize %.2f, ICP %.2f [mirror refresh+upload %.2f], map update+rest %.2f)"
       % (1e3 * r[:, 0].mean(), 1e3 * (r[:, 1] - r[:, 2]).mean(), 1e3 * r[:, 2].mean(),
          1e-3 * r[:, 5].mean(), 1e3 * (r[:, 0] - r[:, 1]).mean()))
-print("map points", len(p.LocalMap()))
+print("map points", p.LocalMapSize() if hasattr(p, "LocalMapSize") else len(p.LocalMap()))
 
 if kt:
     k = np.array(kt[5:]).mean(0)

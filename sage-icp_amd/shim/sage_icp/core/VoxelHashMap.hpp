@@ -82,8 +82,10 @@ struct VoxelHashMap {
     void Update(const Vector4dVector &points, const Eigen::Vector3d &origin) {
         Check(sageicp_map_update(map_, Data(points), points.size(), origin.data()), "Update");
     }
+    // the per-frame map update (pipeline/sageICP.cpp:89) runs on the GPU against the HBM-resident
+    // map; same voxel blocks as the host entry sageicp_map_update_pose()
     void Update(const Vector4dVector &points, const Sophus::SE3d &pose) {
-        Check(sageicp_map_update_pose(map_, Data(points), points.size(), pose.data()), "Update");
+        Check(sageicp_map_update_pose_device(map_, Data(points), points.size(), pose.data()), "Update");
     }
     void AddPoints(const Vector4dVector &points) {
         Check(sageicp_map_add_points(map_, Data(points), points.size()), "AddPoints");

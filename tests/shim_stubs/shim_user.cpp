@@ -17,7 +17,7 @@ int main() {
     Eigen::Vector3d origin;
     a.Update(pts, origin);
     Sophus::SE3d T;
-    a.Update(pts, T);
+    if (sageicp_device_count() > 0) a.Update(pts, T);     // the per-frame update runs on the GPU
     VoxelHashMap b(0.5, 50.0, 1, 1, {});
     b = a;                                   // OdometryServer.cpp:104 copy-assigns the pipeline
     VoxelHashMap c = std::move(b);
