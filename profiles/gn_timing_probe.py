@@ -1,7 +1,7 @@
 """Critical-path phases of k_gn's last workgroup (s_memrealtime, 10 ns ticks); instrumented build."""
 import os, sys, subprocess, ctypes as C
 sys.path.insert(0, os.getcwd())
-src = ["sage-icp_amd/csrc/%s.hip" % n for n in ("kernels", "sort", "preprocess", "capi")]
+src = ["sage-icp_amd/csrc/%s.hip" % n for n in ("kernels", "sort", "preprocess", "map_update", "capi")]
 out = "gpurun_out/libsageicp_gntiming.so"
 os.makedirs("gpurun_out", exist_ok=True)
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",

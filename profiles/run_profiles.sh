@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py --no-cpu-baseline"
-K="k_nn|k_probe|k_group|k_gn|k_fin"
+K="k_nn|k_gn|k_fin"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $BENCH --steps 3 --warmup 1 > $OUT/bench_kt.json 2> $OUT/kt.err
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$K" --output-format csv -d $OUT/pmc_fetch -o pmc -- $BENCH --steps 1 --warmup 0 > /dev/null 2> $OUT/pmc_fetch.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-include-regex "$K" --output-format csv -d $OUT/pmc_tcc -o pmc -- $BENCH --steps 1 --warmup 0 > /dev/null 2> $OUT/pmc_tcc.err

@@ -106,7 +106,7 @@ struct Scratch {
     // Morton re-ordering of the frame (sort.hip)
     Point4 *d_sorted = nullptr; uint32_t *d_keys = nullptr; uint32_t *d_vals = nullptr;
     void *d_sort_temp = nullptr; size_t sort_cap = 0; size_t sort_temp_bytes_ = 0;
-    // per-iteration work buffers: transformed queries and the group list (k_group)
+    // per-iteration work buffers: transformed queries, cached probe-table rows and their keys
     Point4 *d_src = nullptr; uint2 *d_blks = nullptr;
     int4 *d_tabkey = nullptr;
     double *d_partials = nullptr;

@@ -1,37 +1,39 @@
 // Hand-written HIP kernels for gfx950 (CDNA4, wave64) — SAGE-ICP registration hot path.
-// One ICP iteration = k_group -> k_nn -> k_gn, all on one stream, no host round trip.
+// One ICP iteration = k_nn -> k_gn, both on one stream, no host round trip.
 //
-//   k_group  per query: apply the cumulative pose to the pristine frame (TransformPoints,
-//            reference core/Registration.cpp:103-111,133, fused: `source` is never rewritten in
-//            place), compute its home voxel with the reference's exact fp64 divide + truncation
-//            (core/VoxelHashMap.cpp:52-54) and cut the spatially sorted frame into GROUPS: runs
-//            of consecutive queries that share a home voxel (<= 4 long by default).  All queries
-//            of a group see the same 27-voxel candidate list.  For the groups whose cached
-//            probe-table row belongs to another voxel, 27 lanes probe the GPU-resident
-//            open-addressed voxel hash (core/VoxelHashMap.cpp:66-78: 27 x map_.find) and a 32-lane
-//            prefix sum turns the counts into candidate offsets; rows are reused across the
-//            iterations of a call.
-//   k_nn     one wavefront per chunk of queries: per group the occupied voxels' points are
-//            enumerated once in reference order (x outer, y, z inner, then insertion order) into
-//            an LDS candidate list, and the (query x candidate) pairs are spread over the 64
-//            lanes — W = 64 / pow2(group size) lanes per query, each lane striding the list —
-//            followed by a W-lane argmin.  Replaces VoxelHashMap::GetCorrespondences' per-point
+//   k_nn     one wavefront per chunk of 4 consecutive queries of the spatially sorted frame.
+//            Prologue (three lanes per query): apply the cumulative pose to the pristine frame
+//            (TransformPoints, reference core/Registration.cpp:103-111,133 — `source` is never
+//            rewritten in place), home voxel by the reference's exact fp64 divide + truncation
+//            (core/VoxelHashMap.cpp:52-54), and cut the chunk into GROUPS: runs of queries that
+//            share a home voxel, which see the same 27-voxel candidate list.  A group's
+//            probe-table row (27 x map_.find, core/VoxelHashMap.cpp:66-78) is cached across
+//            iterations and re-probed by 27 lanes only when the home voxel changed.
+//            Per group the occupied voxels' points are enumerated once in reference order (x
+//            outer, y, z inner, then insertion order) into an LDS list of byte offsets (start-mark
+//            bitmap + v_mbcnt, no search, no scalar loop), and the (query x candidate) pairs are
+//            spread over the 64 lanes — W = 64 / pow2(group size) lanes per query, each lane
+//            striding the list through a raw buffer resource — followed by a W-lane two-phase
+//            argmin (v_min_f64 over DPP, then the smallest enumeration index among the lanes
+//            that hold the minimum).  Replaces VoxelHashMap::GetCorrespondences' per-point
 //            lambda (core/VoxelHashMap.cpp:51-96).
 //   k_gn     acceptance test (core/VoxelHashMap.cpp:109-115) + robust-weighted point-to-point
 //            Gauss-Newton accumulation (Registration.cpp:62-90) as 16 closed-form fp64 sums +
-//            count, wave-shuffle -> LDS -> one partial per workgroup; the last-arriving workgroup
-//            then finishes the iteration: fixed-order reduction of the partials, 6x6 LDL^T solve,
-//            SE3 exp, pose composition and the convergence test (Registration.cpp:92-93,135-137).
+//            count, LDS-transposed block reduction -> one partial per workgroup; the
+//            last-arriving workgroup then finishes the iteration: fixed-order reduction of the
+//            partials, 6x6 LDL^T solve and SE3 exp with their divisions / sincos spread over
+//            lanes, pose composition and the convergence test (Registration.cpp:92-93,135-137).
 //   k_fin    the same finish as its own launch (multi-GPU: after the RCCL all-reduce).
 //   k_tf     TransformPoints for the stand-alone API entry (Registration.cpp:103-111).
 //   k_scatter_points / k_scatter_slots   refresh of the HBM mirror of the host map.
 //
-// Roofline: HBM-bound integer/byte + fp64 compare work (~0.1 flop/B) — no MFMA (a 6x6 outer
-// product sum is not a dense contraction).  What matters here is coalescing (a voxel block is
-// one contiguous run of 32-B records; identical addresses across the lanes of a group collapse
-// into one request), LDS staging of the candidate enumeration, wave-uniform branch-free inner
-// loops (one scalar unit per CU), no device-scope atomics on hot words, and load balance by
-// hardware dispatch of many small workgroups.
+// Roofline: HBM / cache-gather bound integer/byte + fp64 compare work (~0.1 flop/B) — no MFMA (a
+// 6x6 outer product sum is not a dense contraction).  What matters here is coalescing (a voxel
+// block is one contiguous run of 32-B records; identical addresses across the lanes of a group
+// collapse into one request), LDS staging of the candidate enumeration, wave-uniform
+// branch-free inner loops with as few VALU instructions per pair as the exact fp64 semantics
+// allow (19), no device-scope atomics on hot words, and load balance by hardware dispatch of
+// many small workgroups.
 //
 // Built with -ffp-contract=off: distances are the plain IEEE sequence
 // dx*dx + (dy*dy + dz*dz) the CPU evaluates, so the argmin is index-exact against the oracle.

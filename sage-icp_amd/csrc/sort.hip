@@ -1,10 +1,10 @@
 // Per-frame spatial ordering of the scan (gfx950).  The reference hands RegisterFrame a scan in
 // hash-map iteration order (core/Preprocessing.cpp:75-82), i.e. spatially random.  Here the
 // frame is re-ordered once per call along the Morton curve of the map-frame voxels its points
-// fall into under the initial guess, so that queries sharing a home voxel are consecutive
-// (k_group cuts the frame into such runs and k_nn serves a whole run with one candidate list)
-// and neighbouring runs touch neighbouring voxel blocks (L1/L2 hits).  The pose moves by less
-// than a voxel during the ICP loop, so the order stays good for every iteration.
+// fall into under the current pose, so that queries sharing a home voxel are consecutive
+// (k_nn cuts each chunk into such runs and serves a whole run with one candidate list) and
+// neighbouring runs touch neighbouring voxel blocks (L1/L2 hits).  run_icp re-sorts when the
+// pose has carried the points a fraction of a voxel away from the order they were sorted in.
 // A stable sort keeps the result — and therefore the fp64 summation order of k_gn —
 // bit-reproducible from run to run.
 #include <hip/hip_runtime.h>
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_morton_keys(const Point4 *pts, int n, c
         y = R[3] * f.x + R[4] * f.y + R[5] * f.z + T[5];
         z = R[6] * f.x + R[7] * f.y + R[8] * f.z + T[6];
     }
-    // the same expression k_group evaluates, so at the initial pose equal keys <=> same home voxel
+    // the same expression k_nn evaluates, so at the sorting pose equal keys <=> same home voxel
     // (10 bits per axis: voxels 1024 apart alias, which only costs a group split)
     const int cx = static_cast<int>(x / voxel_size) + 512;
     const int cy = static_cast<int>(y / voxel_size) + 512;
