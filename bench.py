@@ -124,7 +124,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    sage.set_profiling(0 if args.no_profile_events else 1)     # HIP events around k_nn only
+    # level 1: HIP events around k_nn in one iteration out of 8 of the timed region (bracketing
+    # every launch costs 8 % of the frame rate this line reports)
+    sage.set_profiling(0 if args.no_profile_events else 1)
     fence()
     t0 = time.perf_counter()
     stats = []
@@ -149,14 +151,16 @@ def main():
 
     iters = stats[-1][0]
     n_local = hi - lo
-    us_nn = sum(s[1] for s in stats)
+    us_nn = sum(s[1] for s in stats)          # the timed sample of k_nn launches
     launches = sum(s[2] for s in stats)
-    cands = sum(s[3] for s in stats)
+    all_launches = sum(s[0] for s in stats)   # every k_nn launch of the timed region
+    cands = sum(s[3] for s in stats)          # sum of C_q over ALL launches (counted by the kernel)
     roofline = None
     if launches:
-        bytes_nn = 456.0 * n_local * launches + 16.0 * cands     # B_nn summed over the launches
+        bytes_per_launch = 456.0 * n_local + 16.0 * cands / all_launches   # B_nn, mean per launch
         avg_us = us_nn / launches
-        achieved = bytes_nn / (us_nn * 1e-6) / 1e9                # GB/s
+        achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9       # GB/s
+        bytes_nn = bytes_per_launch * launches
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "nn_traffic.json")
         if os.path.exists(tpath) and args.workload == "c2" and world == 1 and args.scale == 1.0:
@@ -168,9 +172,15 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic,
                     "algorithmic_bytes_per_launch": round(bytes_nn / launches),
-                    "avg_launch_us": round(avg_us, 2), "launches": launches,
+                    "avg_launch_us": round(avg_us, 2), "launches_timed": launches,
+                    "launches": all_launches,
                     "queries_per_launch": n_local,
-                    "candidates_per_query": round(cands / launches / max(n_local, 1), 1),
+                    "candidates_per_query": round(cands / all_launches / max(n_local, 1), 1),
+                    "note": "achieved = algorithmic bytes (SURVEY 8d: 456 B/query + 16 B/candidate) / "
+                            "mean k_nn duration (HIP events on the launch stream, 1 launch in 8 of "
+                            "the timed region); queries of a group share one candidate list and "
+                            "the map stays in L2 / Infinity Cache, so `traffic` (HBM bytes, "
+                            "rocprofv3 FETCH_SIZE) is several times smaller and frac can exceed 1",
                     }
 
     fps = args.steps / elapsed

@@ -55,7 +55,7 @@ typedef struct sageicp_stats {
     double us_nn;               /* k_nn: pose apply + grouping + the correspondence search */
     double us_gn;
     double us_fin;
-    uint32_t nn_launches;
+    uint32_t nn_launches;       /* k_nn launches that were timed (us_nn / nn_launches = mean duration) */
     uint32_t resorts;           /* re-sorts of the frame after the pose drifted (first sort excluded) */
     uint64_t sum_candidates;    /* sum over iterations and queries of C_q: map points stored in the
                                  * <=27 existing neighbour voxels of each query (this rank) */
@@ -66,7 +66,8 @@ typedef struct sageicp_stats {
 int sageicp_abi_version(void);
 const char *sageicp_last_error(void);
 int sageicp_device_count(void);               /* number of visible HIP devices (0: none) */
-void sageicp_set_profiling(int level);        /* 0 off; 1 HIP events around k_nn; 2 around every kernel */
+void sageicp_set_profiling(int level);        /* 0 off; 1 HIP events around k_nn in one iteration
+                                               * out of 8; 2 around every kernel of every iteration */
 
 /* ---- map: sage_icp::VoxelHashMap (core/VoxelHashMap.hpp:35-107) ------------------------ */
 /* ctor, VoxelHashMap.hpp:79-88.  device: HIP device ordinal that will hold the mirror. */

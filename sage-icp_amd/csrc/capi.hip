@@ -113,7 +113,9 @@ struct Scratch {
     unsigned long long *d_cand = nullptr;      // per-chunk candidate counters of k_nn [sort_cap]
     IcpState *d_state = nullptr;
     IcpState *h_state = nullptr;   // pinned
-    std::vector<hipEvent_t> events;  // 5 per iteration of a chunk
+    IcpProgress *h_prog = nullptr; // pinned + host-mapped: written by the device every iteration
+    IcpProgress *d_prog = nullptr; // its device address
+    std::vector<hipEvent_t> events;  // 5 per profiled iteration
 
     int init(int dev) {
         if (stream) return SAGEICP_OK;
@@ -128,6 +130,8 @@ struct Scratch {
         HIPCHK(hipMalloc(&d_state, sizeof(IcpState)));
 
         HIPCHK(hipHostMalloc(&h_state, sizeof(IcpState), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&h_prog, sizeof(IcpProgress), hipHostMallocMapped | hipHostMallocCoherent));
+        HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&d_prog), h_prog, 0));
         return SAGEICP_OK;
     }
     int reserve_frame(size_t n) {
@@ -184,10 +188,12 @@ struct Scratch {
         sort_cap = cap;
         return SAGEICP_OK;
     }
-    int reserve_events() {
-        if (!events.empty()) return SAGEICP_OK;
-        events.resize(5 * kChunkMax);
-        for (auto &e : events) HIPCHK(hipEventCreate(&e));
+    int reserve_events(size_t iterations) {
+        while (events.size() < 5 * iterations) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreate(&e));
+            events.push_back(e);
+        }
         return SAGEICP_OK;
     }
     void destroy() {
@@ -210,6 +216,7 @@ struct Scratch {
         if (d_state) (void)hipFree(d_state);
         if (d_cand) (void)hipFree(d_cand);
         if (h_state) (void)hipHostFree(h_state);
+        if (h_prog) (void)hipHostFree(h_prog);
         (void)hipStreamDestroy(stream);
         *this = Scratch();
     }
@@ -778,9 +785,18 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     if (rc) return rc;
     const bool prof = g_profiling != 0;
     const bool prof2 = g_profiling >= 2;
-    if (prof && (rc = sc.reserve_events())) return rc;
+    // Single GPU: iterations are enqueued a few ahead of the GPU, which reports its progress
+    // through a host-mapped word (no stream synchronisation inside the loop).  With a
+    // communicator every rank must enqueue the same number of all-reduces, so the loop advances
+    // in fixed chunks (4, 8, 16, 16, ...) with one synchronisation per chunk instead.
+    const bool polled = !comm && env_int("SAGEICP_CHUNKED", 0) == 0;
+    if (prof && (rc = sc.reserve_events(polled ? kMaxIterations : kChunkMax))) return rc;
 
     fill_state(sc.h_state, init);
+    if (polled) {
+        sc.h_prog->word = 0;
+        sc.h_state->progress = sc.d_prog;
+    }
     HIPCHK(hipMemcpyAsync(sc.d_state, sc.h_state, sizeof(IcpState), hipMemcpyHostToDevice, s));
 
     // Spatial re-ordering of the frame: the loop runs on a copy sorted by map-frame voxel under
@@ -810,7 +826,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     };
     // (a sort costs about as much as one iteration of a 40k-point frame saves over the rest of
     // the loop: small frames keep their first order)
-    const double resort_drift = 0.01 * env_int("SAGEICP_RESORT_PCT", 25) * m->host.voxel_size;
+    const double resort_drift = 0.01 * env_int("SAGEICP_RESORT_PCT", 50) * m->host.voxel_size;
     const bool resort_on = n >= static_cast<uint64_t>(env_int("SAGEICP_RESORT_MIN_N", 40000));
     if (n > 0) {
         if ((rc = sort_now())) return rc;
@@ -830,53 +846,106 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     double us_group = 0, us_nn = 0, us_gn = 0, us_fin = 0;
     uint32_t resorts = 0;
     uint32_t nn_launches = 0;
-    int launched = 0;
-    int chunk = 4;
-    for (;;) {
-        const int todo = std::min(chunk, kMaxIterations - launched);
-        for (int k = 0; k < todo; ++k) {
-            // profiling level 1: events around k_nn only (the roofline kernel; each record costs
-            // ~1 us of stream time); level 2: around every kernel
-            if (prof) HIPCHK(hipEventRecord(sc.events[5 * k + 1], s));
-            launch_nn(np, s);
-            if (prof) HIPCHK(hipEventRecord(sc.events[5 * k + 2], s));
-            launch_gn(gp, s);
-            if (prof2) HIPCHK(hipEventRecord(sc.events[5 * k + 3], s));
-            if (comm) {     // k_gn's last workgroup left the local sums in state->sums
-                ncclResult_t r = g_rccl.AllReduce(sc.d_state->sums, sc.d_state->sums, kNumSums,
-                                                  ncclDouble, ncclSum, comm->comm, s);
-                if (r != ncclSuccess)
-                    return fail(SAGEICP_ERR_RCCL, std::string("ncclAllReduce: ") +
-                                                      (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
-                launch_fin(sc.d_state, sc.d_partials, gn_blocks, 2, 0, s);
-            }               // single GPU: k_gn's last workgroup already finished the iteration
-            if (prof2) HIPCHK(hipEventRecord(sc.events[5 * k + 4], s));
+    // one iteration; `slot` indexes its 5 profiling events
+    // (profiling level 1: events around k_nn only — the roofline kernel; each record costs ~1 us
+    // of stream time; level 2: around every kernel)
+    // Level 1 brackets k_nn in one iteration out of 8 (two event records cost ~6 us of stream
+    // time, 8 % of a c2 iteration): the roofline figure is the mean over that sample.
+    auto sampled = [&](int iteration) { return prof2 || (prof && (iteration & 7) == 4); };
+    auto enqueue_iteration = [&](int slot, int iteration) -> int {
+        const bool ev = sampled(iteration);
+        if (ev) HIPCHK(hipEventRecord(sc.events[5 * slot + 1], s));
+        launch_nn(np, s);
+        if (ev) HIPCHK(hipEventRecord(sc.events[5 * slot + 2], s));
+        launch_gn(gp, s);
+        if (prof2) HIPCHK(hipEventRecord(sc.events[5 * slot + 3], s));
+        if (comm) {     // k_gn's last workgroup left the local sums in state->sums
+            ncclResult_t r = g_rccl.AllReduce(sc.d_state->sums, sc.d_state->sums, kNumSums,
+                                              ncclDouble, ncclSum, comm->comm, s);
+            if (r != ncclSuccess)
+                return fail(SAGEICP_ERR_RCCL, std::string("ncclAllReduce: ") +
+                                                  (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+            launch_fin(sc.d_state, sc.d_partials, gn_blocks, 2, 0, s);
+        }               // single GPU: k_gn's last workgroup already finished the iteration
+        if (prof2) HIPCHK(hipEventRecord(sc.events[5 * slot + 4], s));
+        return SAGEICP_OK;
+    };
+    auto harvest = [&](int slot) {
+        float a = 0, b = 0, c = 0;
+        (void)hipEventElapsedTime(&a, sc.events[5 * slot + 1], sc.events[5 * slot + 2]);
+        if (prof2) {
+            (void)hipEventElapsedTime(&b, sc.events[5 * slot + 2], sc.events[5 * slot + 3]);
+            (void)hipEventElapsedTime(&c, sc.events[5 * slot + 3], sc.events[5 * slot + 4]);
+        }
+        us_nn += 1e3 * a; us_gn += 1e3 * b; us_fin += 1e3 * c;
+        ++nn_launches;
+    };
+    if (polled) {
+        const int depth = std::max(1, env_int("SAGEICP_DEPTH", 4));
+        volatile unsigned long long *word = &sc.h_prog->word;
+        int enq = 0, seen = 0;
+        unsigned spins = 0;
+        for (;;) {
+            const unsigned long long w = *word;
+            const int comp = static_cast<int>(w & 0xFFFFFFFFull);
+            if (w >> 32) break;                                  // converged or out of iterations
+            if (enq < kMaxIterations && enq - comp < depth) {
+                if ((rc = enqueue_iteration(enq, enq))) return rc;
+                ++enq;
+                spins = 0;
+                continue;
+            }
+            if (resort_on && comp != seen) {                     // the pose moved: still sorted?
+                seen = comp;
+                double Tc[7];
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                for (int i = 0; i < 7; ++i) Tc[i] = sc.h_prog->T[i];
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                if (*word == w && drift(Tc, T_sorted) > resort_drift) {   // pose read untorn
+                    if ((rc = sort_now())) return rc;
+                    for (int i = 0; i < 7; ++i) T_sorted[i] = Tc[i];
+                    ++resorts;
+                }
+            }
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFFu) == 0) {                      // every ~ms: is the stream alive?
+                const hipError_t q = hipStreamQuery(s);
+                if (q != hipSuccess && q != hipErrorNotReady)
+                    return fail(SAGEICP_ERR_HIP, std::string("ICP loop: ") + hipGetErrorString(q));
+                if (q == hipSuccess && (*word >> 32) == 0 && enq >= kMaxIterations)
+                    break;     // everything ran and nothing flagged the end: read the state below
+            }
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(sc.h_state, sc.d_state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        const int iters = sc.h_state->iter;
-        if (prof) {
-            const int executed = std::min(todo, iters - launched);   // the rest were no-ops
-            for (int k = 0; k < executed; ++k) {
-                float g = 0, a = 0, b = 0, c = 0;
-                (void)hipEventElapsedTime(&a, sc.events[5 * k + 1], sc.events[5 * k + 2]);
-                if (prof2) {
-                    (void)hipEventElapsedTime(&b, sc.events[5 * k + 2], sc.events[5 * k + 3]);
-                    (void)hipEventElapsedTime(&c, sc.events[5 * k + 3], sc.events[5 * k + 4]);
-                }
-                us_group += 1e3 * g; us_nn += 1e3 * a; us_gn += 1e3 * b; us_fin += 1e3 * c;
-                ++nn_launches;
+        if (prof)
+            for (int k = 0; k < sc.h_state->iter && k < enq; ++k)      // the rest were no-ops
+                if (sampled(k)) harvest(k);
+    } else {
+        int launched = 0;
+        int chunk = 4;
+        for (;;) {
+            const int todo = std::min(chunk, kMaxIterations - launched);
+            for (int k = 0; k < todo; ++k)
+                if ((rc = enqueue_iteration(k, launched + k))) return rc;
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(sc.h_state, sc.d_state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (prof) {
+                const int executed = std::min(todo, sc.h_state->iter - launched);   // the rest were no-ops
+                for (int k = 0; k < executed; ++k)
+                    if (sampled(launched + k)) harvest(k);
             }
+            launched += todo;
+            if (sc.h_state->done || launched >= kMaxIterations) break;
+            if (resort_on && drift(sc.h_state->T, T_sorted) > resort_drift) {
+                if ((rc = sort_now())) return rc;
+                for (int i = 0; i < 7; ++i) T_sorted[i] = sc.h_state->T[i];
+                ++resorts;
+            }
+            chunk = std::min(kChunkMax, chunk * 2);   // 4, 8, 16, 16, ... : few syncs, bounded no-op tail
         }
-        launched += todo;
-        if (sc.h_state->done || launched >= kMaxIterations) break;
-        if (resort_on && drift(sc.h_state->T, T_sorted) > resort_drift) {
-            if ((rc = sort_now())) return rc;
-            for (int i = 0; i < 7; ++i) T_sorted[i] = sc.h_state->T[i];
-            ++resorts;
-        }
-        chunk = std::min(kChunkMax, chunk * 2);   // 4, 8, 16, 16, ... : few syncs, bounded no-op tail
     }
     const IcpState &st = *sc.h_state;
     for (int i = 0; i < 7; ++i) out[i] = st.T[i];

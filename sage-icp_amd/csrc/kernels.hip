@@ -587,11 +587,25 @@ __device__ __forceinline__ void finish_iteration(IcpState *st, const double *par
     const int it = st->iter;
     if (it < kHistory) st->n_corr[it] = static_cast<uint32_t>(S[kCount]);
     st->iter = it + 1;
+    unsigned long long done = 0;
     if (nrm < kEstimationThreshold) {
         st->converged = 1;
         st->done = 1;
+        done = 1;
     } else if (it + 1 >= kMaxIterations) {
         st->done = 1;
+        done = 1;
+    }
+    if (IcpProgress *pg = st->progress) {
+        // host-mapped: the pose, then the progress word, as relaxed system-scope (write-through)
+        // stores — a release here would write back this XCD's whole L2 every iteration; the host
+        // only steers its look-ahead and its re-sort heuristic by these values and reads the
+        // final state through an ordinary copy after the loop
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+            __hip_atomic_store(&pg->T[i], Tn[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&pg->word, (done << 32) | static_cast<unsigned long long>(it + 1),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 #ifdef SAGE_GN_TIMING
     fin_t[4] = __builtin_amdgcn_s_memrealtime();

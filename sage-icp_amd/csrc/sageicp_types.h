@@ -54,6 +54,15 @@ constexpr double kEstimationThreshold = 1e-4;  // Registration.cpp:97
 constexpr int kNumSums = 20;               // 16 closed-form GN sums + count + 3 pad
 constexpr int kHistory = 512;
 
+// Loop progress as the host sees it while the loop runs: a small block of pinned, host-mapped
+// memory the finishing lane writes after every iteration (the pose and one 64-bit word
+// (done << 32) | iterations, write-through stores), polled by run_icp to keep a few
+// iterations enqueued ahead of the GPU without a stream synchronisation per check.
+struct IcpProgress {
+    unsigned long long word;   // (done << 32) | iterations completed
+    double T[7];               // cumulative pose after that many iterations
+};
+
 // Device-resident loop state, written by k_fin, read by every kernel of the next iteration.
 struct IcpState {
     double T[7];        // cumulative pose applied to the pristine frame: T_icp * initial_guess
@@ -67,6 +76,7 @@ struct IcpState {
     double sums[kNumSums];          // last reduced GN sums (diagnostics / multi-GPU exchange)
     unsigned long long sum_candidates;  // sum over launches and queries of C_q (roofline bytes)
     uint32_t n_corr[kHistory];      // accepted correspondences per iteration (all ranks)
+    IcpProgress *progress;          // host-mapped progress block (nullptr: not published)
 };
 
 // Index into the 16 closed-form sums of AlignClouds (Registration.cpp:59-94):

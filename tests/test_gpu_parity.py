@@ -346,6 +346,16 @@ def test_profiling_stats(gpu_sage, oracle):
     finally:
         gpu_sage.set_profiling(0)
     assert st.nn_launches == st.iterations and st.us_nn > 0 and st.us_gn > 0 and st.us_fin > 0
+    # level 1 (what bench.py runs with): k_nn bracketed in one iteration out of 8
+    gpu_sage.set_profiling(1)
+    try:
+        _, s1 = gpu_sage.register_frame(w["scan"], w["map"], gpu_sage.IDENTITY, 6.0, 2 / 3, 0.4,
+                                        return_stats=True)
+    finally:
+        gpu_sage.set_profiling(0)
+    assert s1.iterations == st.iterations and s1.sum_candidates == st.sum_candidates
+    assert s1.nn_launches == len([k for k in range(s1.iterations) if k % 8 == 4])
+    assert s1.us_nn > 0 and s1.us_gn == 0
 
 
 # ------------------------------------------------------------------ full-size properties
