@@ -46,34 +46,27 @@ static int env_int(const char *name, int dflt) {
     const char *v = std::getenv(name);
     return v ? std::atoi(v) : dflt;
 }
-static int group_cap() {
-    static int c = [] {
-        int v = env_int("SAGEICP_GROUP_MAX", 4);   // measured best on c2 (profiles/sweep2.sh)
-        int p = 1;
-        while (p * 2 <= v && p < 16) p *= 2;   // three lanes per query in k_nn's prologue
-        return p;
-    }();
-    return c;
-}
-// queries per k_nn wave: a power of two, group_cap() <= chunk <= 16
-static int nn_chunk() {
-    static int c = [] {
-        int v = env_int("SAGEICP_NN_CHUNK", group_cap());
-        int p = group_cap();
-        while (p * 2 <= v && p < 16) p *= 2;
-        return p;
-    }();
-    return c;
-}
-static unsigned nn_chunk_log2() {
-    unsigned l = 0;
-    while ((1 << l) < nn_chunk()) ++l;
-    return l;
-}
-static unsigned nn_cap_heads() {
-    unsigned m = 0;
-    for (int i = 0; i < nn_chunk(); i += group_cap()) m |= 1u << i;
-    return m;
+// Queries per k_nn wave (= the cap on a group of same-voxel queries), a power of two <= 16.
+// Measured on MI355X: 4 is best once the frame fills the chip several times over (c2: 80 us
+// against 83 / 99 us for 2 / 1); smaller frames are bound by the dependent chain of a single
+// wave, and shorter chunks mean more, shorter waves (c1 and 24k-point stream frames: 4-7 % faster
+// with 1).  SAGEICP_GROUP_MAX / SAGEICP_NN_CHUNK override both for experiments.
+struct NnShape {
+    unsigned chunk, chunk_log2, cap_heads;
+};
+static NnShape nn_shape(uint64_t n) {
+    int cap = env_int("SAGEICP_GROUP_MAX", 0);
+    if (cap <= 0) cap = n <= 32768 ? 1 : (n <= 65536 ? 2 : 4);
+    int c = 1;
+    while (c * 2 <= cap && c < 16) c *= 2;      // three lanes per query in k_nn's prologue
+    cap = c;
+    int chunk = cap;
+    const int want = env_int("SAGEICP_NN_CHUNK", cap);
+    while (chunk * 2 <= want && chunk < 16) chunk *= 2;
+    NnShape s{static_cast<unsigned>(chunk), 0u, 0u};
+    while ((1u << s.chunk_log2) < s.chunk) ++s.chunk_log2;
+    for (int i = 0; i < chunk; i += cap) s.cap_heads |= 1u << i;
+    return s;
 }
 
 
@@ -833,8 +826,9 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         d_frame = sc.d_sorted;
     }
 
+    const NnShape shape = nn_shape(n);
     NnParams np{d_frame, sc.d_src, static_cast<int>(n), sc.d_state, 1, 1, m->host.voxel_size,
-                static_cast<unsigned>(nn_chunk()), nn_chunk_log2(), nn_cap_heads(), sc.d_tabkey, sc.d_blks,
+                shape.chunk, shape.chunk_log2, shape.cap_heads, sc.d_tabkey, sc.d_blks,
                 m->d_table, static_cast<uint32_t>(m->d_table_cap - 1), m->d_pts,
                 static_cast<uint32_t>((m->d_blocks_cap * m->host.cap + 1) * sizeof(Point4)), m->host.cap,
                 sem_th, DBL_MAX, sc.d_nn, sc.d_cand};
@@ -1135,8 +1129,9 @@ int sageicp_get_correspondences(const sageicp_map *m, const double *q, uint64_t 
                       m->host.voxel_size, sc.d_keys, sc.d_vals, sc.d_sort_temp, sc.sort_temp_bytes_,
                       s));
     HIPCHK(hipMemsetAsync(sc.d_tabkey, 0x7F, (n + 1) * sizeof(int4), s));
+    const NnShape shape = nn_shape(n);
     NnParams np{sc.d_sorted, sc.d_src, static_cast<int>(n), sc.d_state, 0, 0, m->host.voxel_size,
-                static_cast<unsigned>(nn_chunk()), nn_chunk_log2(), nn_cap_heads(), sc.d_tabkey, sc.d_blks,
+                shape.chunk, shape.chunk_log2, shape.cap_heads, sc.d_tabkey, sc.d_blks,
                 m->d_table, static_cast<uint32_t>(m->d_table_cap - 1), m->d_pts,
                 static_cast<uint32_t>((m->d_blocks_cap * m->host.cap + 1) * sizeof(Point4)), m->host.cap,
                 sem_th, DBL_MAX, sc.d_nn, nullptr};
