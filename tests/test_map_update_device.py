@@ -3,6 +3,7 @@ product (bit-identical block contents and order expected) and against the CPU or
 of points per voxel, same search results).  Needs the MI355X."""
 import numpy as np
 import pytest
+from hypothesis import given, settings, strategies as st
 
 pytestmark = pytest.mark.gpu
 
@@ -121,3 +122,27 @@ def test_device_update_rejects_far_voxel_indices(gpu_sage):
     with pytest.raises(sage.SageIcpError):
         m.UpdateOnDevice(p, sage.IDENTITY)
     assert m.size() == 0
+
+
+@settings(max_examples=12, deadline=None)
+@given(seed=st.integers(0, 2**31 - 1), vs=st.sampled_from([0.3, 1.0, 2.5]),
+       basic=st.integers(0, 6), critical=st.integers(1, 5), md=st.sampled_from([6.0, 15.0, 400.0]),
+       n_pts=st.sampled_from([1, 37, 900, 4000]), frames=st.integers(1, 6))
+def test_device_update_property(gpu_sage, vs, basic, critical, md, n_pts, frames, seed):
+    """random capacities, voxel sizes, eviction radii and batch sizes: device == host, block for block"""
+    sage = gpu_sage
+    kw = dict(basic_points_per_voxel=basic, critical_points_per_voxel=critical,
+              basic_parts_labels=(40, 44, 50))
+    dev, host = sage.VoxelHashMap(vs, md, **kw), sage.VoxelHashMap(vs, md, **kw)
+    rng = np.random.default_rng(seed)
+    for k, (p, pose) in enumerate(_frames(seed % 1000, frames, n_pts, 6.0 * vs, 2.0 * vs)):
+        if seed % 2 and k:
+            p[: len(p) // 2, :3] = np.round(p[: len(p) // 2, :3] / vs) * vs     # points on voxel faces
+        if (seed >> 1) % 3 == 0 and k == 1:
+            extra = rng.uniform(-3 * vs, 3 * vs, size=(50, 4))
+            dev.AddPoints(extra)            # a host-side entry in between (download + re-upload)
+            host.AddPoints(extra)
+        dev.UpdateOnDevice(p, pose)
+        host.Update(p, pose)
+        assert dev.size() == host.size() and dev.num_voxels() == host.num_voxels()
+    assert np.array_equal(dev.Pointcloud(), host.Pointcloud())
