@@ -208,6 +208,36 @@ def test_mirror_refresh_after_updates(gpu_sage, oracle):
     assert len(c2.GetCorrespondences(q, 3.0, 0.4)[0]) == len(oidx)
 
 
+def test_maximum_voxel_capacity(gpu_sage, oracle):
+    """255 points per voxel (the ABI's limit): 27 x 255 candidates per query, LDS list of 6.9k
+    entries, multi-word start-mark bitmap; search and device-side update stay exact"""
+    rng = np.random.default_rng(77)
+    mp = rng.uniform(-2.4, 2.4, size=(60000, 4))
+    mp[:, 3] = rng.choice([0, 40, 50, 71], size=len(mp))
+    a = gpu_sage.VoxelHashMap(1.0, 100.0, 200, 55)
+    h = gpu_sage.VoxelHashMap(1.0, 100.0, 200, 55)
+    b = oracle.Map(1.0, 100.0, 200, 55)
+    a.AddPoints(mp)
+    h.AddPoints(mp)
+    b.add_points(mp)
+    assert a.size() == b.size() and a.size() > 100 * 200
+    q = rng.uniform(-2.6, 2.6, size=(900, 4))
+    q[:, 3] = rng.choice([0, 40, 50, 71], size=len(q))
+    _, tgt, idx = a.GetCorrespondences(q, 1.0, 0.4, with_index=True)
+    _, otgt, oidx = b.get_correspondences(q, 1.0, 0.4, with_index=True)
+    assert np.array_equal(idx, oidx) and np.array_equal(tgt, otgt)
+    more = rng.uniform(-3.0, 3.0, size=(20000, 4))
+    more[:, 3] = rng.choice([0, 40, 50, 71, 80], size=len(more))
+    a.UpdateOnDevice(more, gpu_sage.IDENTITY)
+    h.Update(more, gpu_sage.IDENTITY)
+    assert np.array_equal(a.Pointcloud(), h.Pointcloud())
+    pose, st = gpu_sage.register_frame(q, a, gpu_sage.IDENTITY, 1.0, 0.3, 0.4, return_stats=True)
+    b.add_points(more)
+    opose, ost = b.register_frame(q, oracle.IDENTITY, 1.0, 0.3, 0.4)
+    dt, dr = pose_error(oracle, opose, pose)
+    assert st.iterations == ost.iterations and dt < 1e-9 and dr < 1e-9
+
+
 # ------------------------------------------------------------------ AlignClouds / TransformPoints
 @pytest.mark.parametrize("n", [0, 1, 63, 64, 1000, 70001])
 def test_align_clouds_matches_oracle(gpu_sage, oracle, n):
