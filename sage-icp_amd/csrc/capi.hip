@@ -1020,12 +1020,51 @@ void sageicp_map_destroy(sageicp_map *m) {
     delete m;
 }
 
+// copy of a map whose authority is the HBM copy: device-to-device, the (stale) host side is not
+// touched on either map
+static int clone_on_device(const sageicp_map *src, sageicp_map *m) {
+    const HostMap &h = src->host;
+    m->host.configure(h.voxel_size, h.max_distance, h.basic, h.critical, h.basic_labels.data(),
+                      static_cast<int>(h.basic_labels.size()));
+    int rc = m->sc.init(m->device);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t s = m->sc.stream;
+    HIPCHK(hipStreamSynchronize(src->sc.stream));
+    const size_t block_bytes = static_cast<size_t>(h.cap) * sizeof(Point4);
+    HIPCHK(hipMalloc(&m->d_table, src->d_table_cap * sizeof(Slot)));
+    m->d_table_cap = src->d_table_cap;
+    HIPCHK(hipMemcpyAsync(m->d_table, src->d_table, src->d_table_cap * sizeof(Slot),
+                          hipMemcpyDeviceToDevice, s));
+    m->ctr = src->ctr;
+    if ((rc = grow_device_blocks(m, src->d_blocks_cap, 0))) return rc;
+    HIPCHK(hipMemcpyAsync(m->d_pts, src->d_pts, m->ctr.blocks_hi * block_bytes, hipMemcpyDeviceToDevice, s));
+    if (m->ctr.blocks_hi) {
+        HIPCHK(hipMemcpyAsync(m->d_zeros, src->d_zeros, m->ctr.blocks_hi, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(m->d_slot_of, src->d_slot_of, m->ctr.blocks_hi * sizeof(uint32_t),
+                              hipMemcpyDeviceToDevice, s));
+    }
+    if (m->ctr.free_count)
+        HIPCHK(hipMemcpyAsync(m->d_free, src->d_free, m->ctr.free_count * sizeof(uint32_t),
+                              hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    m->on_device = true;
+    m->mirror_stale_all = false;
+    return SAGEICP_OK;
+}
+
 sageicp_map *sageicp_map_clone(const sageicp_map *src) {
     if (!src) return nullptr;
-    if (ensure_host(src)) return nullptr;
     sageicp_map *m = new sageicp_map;
-    m->host = src->host;
     m->device = src->device;
+    if (src->on_device) {
+        if (clone_on_device(src, m)) {
+            sageicp_map_destroy(m);
+            return nullptr;
+        }
+        return m;
+    }
+    m->host = src->host;
     m->mirror_stale_all = true;   // the clone builds its own mirror on first use
     return m;
 }

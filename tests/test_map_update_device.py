@@ -78,11 +78,21 @@ def test_device_update_interleaved_with_host_entries(gpu_sage, oracle):
             _, tgt, idx = dev.GetCorrespondences(q, 3.0, 0.4, with_index=True)
             _, otgt, oidx = orc.get_correspondences(q, 3.0, 0.4, with_index=True)
             assert np.array_equal(idx, oidx) and np.array_equal(tgt, otgt), "frame %d" % k
+    before = host.Pointcloud()
+    p, pose = _frames(12, 1, 4000, 10.0, 5.0)[0]
+    dev.UpdateOnDevice(p, pose)             # leaves the HBM copy as the authority ...
+    c = dev.clone()                         # ... so this is a device-to-device copy
+    host.Update(p, pose)
+    assert c.size() == host.size() == dev.size()
+    c.UpdateOnDevice(p[:1000], pose)        # the clone lives on its own
+    h2 = host.clone()
+    h2.Update(p[:1000], pose)
+    assert np.array_equal(c.Pointcloud(), h2.Pointcloud())
     assert np.array_equal(dev.Pointcloud(), host.Pointcloud())
-    c = dev.clone()
-    assert np.array_equal(c.Pointcloud(), host.Pointcloud())
+    assert not np.array_equal(before, host.Pointcloud())
     dev.Clear()
     assert dev.size() == 0 and dev.Empty()
+    assert c.size() == h2.size() > 0
 
 
 def test_register_frame_on_a_device_updated_map(gpu_sage, oracle):
