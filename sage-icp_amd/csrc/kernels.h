@@ -46,7 +46,12 @@ struct NnLds {
 __host__ __device__ inline NnLds nn_lds_layout(int cap, unsigned chunk) {
     NnLds l;
     const unsigned ncand = 27u * static_cast<unsigned>(cap);
-    l.marks = (ncand + 127u) & ~127u;          // after the candidate list, padded to its widest stride
+#ifdef SAGE_NN_U_BIG
+    constexpr unsigned pad = (SAGE_NN_U_BIG * 64u > 128u) ? SAGE_NN_U_BIG * 64u : 128u;
+#else
+    constexpr unsigned pad = 128u;
+#endif
+    l.marks = (ncand + pad - 1u) & ~(pad - 1u);   // after the candidate list, padded to its widest stride
     const unsigned mark_words = (((ncand + 63u) >> 6) + 1u) & ~1u;   // 64-bit words, even count
     l.delta = l.marks + 2u * mark_words;
     l.spt = l.delta + 32u;

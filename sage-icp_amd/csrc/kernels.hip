@@ -46,6 +46,17 @@
 #ifndef SAGE_NN_WAVES
 #define SAGE_NN_WAVES 1
 #endif
+// k_nn tuning (measured on MI355X, c2): candidate loads in flight per lane when a query has 32-64
+// lanes / 2-16 lanes, and the occupancy the register allocation aims for
+#ifndef SAGE_NN_U_BIG
+#define SAGE_NN_U_BIG 2
+#endif
+#ifndef SAGE_NN_U_SMALL
+#define SAGE_NN_U_SMALL 4
+#endif
+#ifndef SAGE_NN_OCC
+#define SAGE_NN_OCC 8
+#endif
 
 #include "kernels.h"
 #include "se3_math.h"
@@ -178,7 +189,7 @@ __device__ __forceinline__ Point4 load_point(__amdgpu_buffer_rsrc_t pts, uint32_
     return q;
 }
 
-template <int LW>
+template <int LW, int U>      // W = 2^LW lanes per query, U candidate loads in flight per lane
 __device__ __forceinline__ void nn_group(const NnParams &P, __amdgpu_buffer_rsrc_t pts,
                                          const uint32_t *cand, int lane, int start, int len,
                                          unsigned C, const Point4 &p) {
@@ -213,7 +224,6 @@ __device__ __forceinline__ void nn_group(const NnParams &P, __amdgpu_buffer_rsrc
     // The list is padded up to a multiple of U * W entries with the offset of a NaN point (its
     // distance fails d < best and leaves v_min_f64 unchanged), so the loop needs no index clamp,
     // no bounds test, and its LDS reads sit at immediate offsets from one per-lane address.
-    constexpr int U = (LW >= 5) ? 2 : 4;               // loads in flight per lane
     const uint32_t *cp = cand + ci;
     unsigned step = 0;
     for (unsigned f0 = 0; f0 < C; f0 += U * W, step += U, cp += U * W) {   // uniform trip count
@@ -263,7 +273,7 @@ __device__ unsigned long long g_nn_phase[8];
 
 constexpr int kNnWaves = SAGE_NN_WAVES;     // waves per k_nn workgroup
 
-__global__ __launch_bounds__(64 * kNnWaves, 8) void k_nn(NnParams P) {
+__global__ __launch_bounds__(64 * kNnWaves, SAGE_NN_OCC) void k_nn(NnParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     if (P.check_done && P.st->done) return;
 #ifdef SAGE_NN_TIMING
@@ -300,6 +310,9 @@ __global__ __launch_bounds__(64 * kNnWaves, 8) void k_nn(NnParams P) {
     unsigned cand_slot = 0;
     {
       const unsigned chunk = P.chunk;
+      // one query per wave (small frames): a single load in flight per lane and a list padded to
+      // 64 is faster there (c1: 6 %); with several queries per wave two in flight win (c2: 3 %)
+      const unsigned u6 = (chunk == 1u) ? 1u : static_cast<unsigned>(SAGE_NN_U_BIG);
       const unsigned nchunks = (static_cast<unsigned>(P.n) + chunk - 1u) / chunk;
       const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
       const unsigned quad = ((j / kStripe) * 8u + xcd) * kStripe + (j % kStripe);
@@ -397,7 +410,8 @@ __global__ __launch_bounds__(64 * kNnWaves, 8) void k_nn(NnParams P) {
             const unsigned nwords = (C + 63u) >> 6;
             // entries filled: whole 64-entry words, an even number of them when the pair loop
             // strides 128 (one query on all 64 lanes); the tail beyond C points at the NaN point
-            const unsigned nfill = (lw == 6) ? ((nwords + 1u) & ~1u) : nwords;
+            const unsigned stepw = max(1u, ((lw == 6 ? u6 : static_cast<unsigned>(lw == 5 ? SAGE_NN_U_BIG : SAGE_NN_U_SMALL)) << lw) >> 6);
+            const unsigned nfill = ((nwords + stepw - 1u) / stepw) * stepw;
             const uint32_t pad_off = P.pts_bytes - static_cast<uint32_t>(sizeof(Point4));
             unsigned ln = static_cast<unsigned>(lane);
             asm volatile("" : "+v"(ln));   // bitmap addresses are cheaper to form than to keep live
@@ -427,12 +441,15 @@ __global__ __launch_bounds__(64 * kNnWaves, 8) void k_nn(NnParams P) {
         NN_T(1);
 
         switch (lw) {
-            case 6: nn_group<6>(P, pts, cand, lane, start, len, C, p); break;
-            case 5: nn_group<5>(P, pts, cand, lane, start, len, C, p); break;
-            case 4: nn_group<4>(P, pts, cand, lane, start, len, C, p); break;
-            case 3: nn_group<3>(P, pts, cand, lane, start, len, C, p); break;
-            case 2: nn_group<2>(P, pts, cand, lane, start, len, C, p); break;
-            default: nn_group<1>(P, pts, cand, lane, start, len, C, p); break;
+            case 6:
+                if (u6 == 1) nn_group<6, 1>(P, pts, cand, lane, start, len, C, p);
+                else nn_group<6, SAGE_NN_U_BIG>(P, pts, cand, lane, start, len, C, p);
+                break;
+            case 5: nn_group<5, SAGE_NN_U_BIG>(P, pts, cand, lane, start, len, C, p); break;
+            case 4: nn_group<4, SAGE_NN_U_SMALL>(P, pts, cand, lane, start, len, C, p); break;
+            case 3: nn_group<3, SAGE_NN_U_SMALL>(P, pts, cand, lane, start, len, C, p); break;
+            case 2: nn_group<2, SAGE_NN_U_SMALL>(P, pts, cand, lane, start, len, C, p); break;
+            default: nn_group<1, SAGE_NN_U_SMALL>(P, pts, cand, lane, start, len, C, p); break;
         }
         NN_T(2);
         ob = ob_next;
