@@ -57,6 +57,9 @@
 #ifndef SAGE_NN_OCC
 #define SAGE_NN_OCC 8
 #endif
+#ifndef SAGE_NN_STRIPE
+#define SAGE_NN_STRIPE 64      // chunks of the sorted frame per XCD stripe
+#endif
 
 #include "kernels.h"
 #include "se3_math.h"
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(64 * kNnWaves, SAGE_NN_OCC) void k_nn(NnParams P) {
     // workgroups' worth of the spatially sorted frame, so each private L2 sees a few compact
     // regions of the map and every XCD gets the same mix of dense and sparse regions.
     unsigned long long wave_candidates = 0;   // wave-uniform: sum over this wave's queries of C_q
-    constexpr unsigned kStripe = 64 / kNnWaves;   // workgroups per stripe (64 chunks)
+    constexpr unsigned kStripe = SAGE_NN_STRIPE / kNnWaves;   // workgroups per stripe
     unsigned cand_slot = 0;
     {
       const unsigned chunk = P.chunk;
@@ -835,7 +838,7 @@ int nn_grid_for(int n, int chunk) {
     // one wave per chunk, 4 waves per workgroup, rounded up to whole stripes on all 8 XCDs
     const long nchunks = (static_cast<long>(n) + chunk - 1) / chunk;
     const long quads = (nchunks + kNnWaves - 1) / kNnWaves;
-    const long per_round = 8L * (64 / kNnWaves);   // 8 XCDs x kStripe
+    const long per_round = 8L * (SAGE_NN_STRIPE / SAGE_NN_WAVES);   // 8 XCDs x kStripe
     const long blocks = ((quads + per_round - 1) / per_round) * per_round;
     return static_cast<int>(blocks < per_round ? per_round : blocks);
 }
