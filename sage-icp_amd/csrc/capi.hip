@@ -233,6 +233,7 @@ struct Prep {
     size_t glabels_cap = 0;
     void *h_pin = nullptr;              // pinned staging for the raw frame and the results
     size_t pin_bytes = 0;
+    uint32_t kept_levels[2] = {0, 0};   // points the last run left in d_fd / d_src
 
     int init(int dev) {
         if (stream) return SAGEICP_OK;
@@ -312,7 +313,8 @@ struct Prep {
     int run(const double *frame, uint64_t n, double max_range, double min_range,
             double label_max_range, int n_groups, const int *gcounts, const int *glabels,
             const double *gvs, const int *crop, const double *scales, int n_levels,
-            std::vector<std::vector<double>> &out) {
+            std::vector<std::vector<double>> &out, bool download = true) {
+        kept_levels[0] = kept_levels[1] = 0;
         if (n > kMaxQueries) return fail(SAGEICP_ERR_INVALID, "frame too large (2^26 points max)");
         if (n_groups > 8) return fail(SAGEICP_ERR_INVALID, "at most 8 label groups");
         size_t nlabels = 0;
@@ -348,11 +350,14 @@ struct Prep {
             uint32_t kept = 0;
             HIPCHK(hipMemcpyAsync(&kept, d_nkept + (l & 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
-            char *hp = static_cast<char *>(h_pin) + static_cast<size_t>(1 + (l & 1)) * cap * sizeof(Point4);
-            if (kept) HIPCHK(hipMemcpyAsync(hp, dst, kept * sizeof(Point4), hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipStreamSynchronize(stream));
-            out[l].resize(4 * static_cast<size_t>(kept));
-            if (kept) std::memcpy(out[l].data(), hp, kept * sizeof(Point4));
+            kept_levels[l & 1] = kept;
+            if (download) {       // otherwise the level's cloud stays in d_fd / d_src for the caller
+                char *hp = static_cast<char *>(h_pin) + static_cast<size_t>(1 + (l & 1)) * cap * sizeof(Point4);
+                if (kept) HIPCHK(hipMemcpyAsync(hp, dst, kept * sizeof(Point4), hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+                out[l].resize(4 * static_cast<size_t>(kept));
+                if (kept) std::memcpy(out[l].data(), hp, kept * sizeof(Point4));
+            }
             in = dst;
             cur = kept;
         }
@@ -666,7 +671,9 @@ static int grow_device_blocks(const sageicp_map *m, size_t blocks, size_t keep) 
 }
 
 // VoxelHashMap::Update(points, pose) on the device.
-int device_update(sageicp_map *m, const double *xyzl, uint64_t n, const double pose[7]) {
+// `d_points`: the points are already in HBM (the pipeline's down-sampled frame); else `xyzl` (host).
+int device_update(sageicp_map *m, const double *xyzl, uint64_t n, const double pose[7],
+                  const Point4 *d_points = nullptr) {
     if (m->host.basic_labels.size() > static_cast<size_t>(kMaxBasicLabels))
         return fail(SAGEICP_ERR_INVALID, "device map update supports at most 32 basic_parts_labels");
     if (n > 0x3FFFFFFFull) return fail(SAGEICP_ERR_INVALID, "too many points");
@@ -734,7 +741,9 @@ int device_update(sageicp_map *m, const double *xyzl, uint64_t n, const double p
     }
     const uint32_t bound = static_cast<uint32_t>(need_blocks);
     if ((rc = reserve_update_scratch(m, n, bound))) return rc;
-    if (n) HIPCHK(hipMemcpyAsync(m->up.raw, xyzl, n * sizeof(Point4), hipMemcpyHostToDevice, s));
+    UpdateScratch us = m->up;
+    if (d_points) us.raw = const_cast<Point4 *>(d_points);
+    else if (n) HIPCHK(hipMemcpyAsync(m->up.raw, xyzl, n * sizeof(Point4), hipMemcpyHostToDevice, s));
     UpdatePolicy pol{};
     pol.voxel_size = h.voxel_size;
     pol.max_dist2 = h.max_distance * h.max_distance;
@@ -742,7 +751,7 @@ int device_update(sageicp_map *m, const double *xyzl, uint64_t n, const double p
     pol.critical = h.critical;
     pol.n_labels = static_cast<int>(h.basic_labels.size());
     for (int i = 0; i < pol.n_labels; ++i) pol.labels[i] = h.basic_labels[i];
-    HIPCHK(map_update_device(dm, pol, m->up, static_cast<int>(n), pose, bound, s));
+    HIPCHK(map_update_device(dm, pol, us, static_cast<int>(n), pose, bound, s));
     HIPCHK(hipMemcpyAsync(m->h_ctr, m->d_ctr, sizeof(MapCounters), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (m->h_ctr->overflow) {
@@ -1453,23 +1462,47 @@ int sageicp_pipeline_register_frame(sageicp_pipeline *p, const double *frame, ui
     if (!p || !pose_out || (n && !frame)) return fail(SAGEICP_ERR_INVALID, "null argument");
     int rc = p->prep.init(p->device);
     if (rc) return rc;
-    // Preprocess + Voxelize on the device (preprocess.hip): crop + scale 0.5, then scale 1.5
-    auto voxelize = [&](const double *f, uint64_t m, std::vector<double> &fd, std::vector<double> &src) -> int {
-        std::vector<int> counts, labels;
-        std::vector<double> vs;
-        p->impl.group_tables(counts, labels, vs);
-        const int crop[2] = {1, 0};
-        const double scales[2] = {0.5, 1.5};
-        std::vector<std::vector<double>> res;
-        int r = p->prep.run(f, m, p->impl.max_range_(), p->impl.min_range_(), p->impl.label_max_range_(),
-                            static_cast<int>(counts.size()), counts.data(), labels.data(), vs.data(),
-                            crop, scales, 2, res);
-        if (r) return r;
-        fd.swap(res[0]);
-        src.swap(res[1]);
-        return SAGEICP_OK;
+    // Preprocess + Voxelize on the device (preprocess.hip): crop + scale 0.5, then scale 1.5.
+    // Neither cloud comes back to the host: the source is registered and the down-sampled frame
+    // inserted into the map from where the kernels left them (only a host-side map update
+    // downloads its points).
+    struct Backend {
+        sageicp_pipeline *p;
+        int voxelize(const double *f, uint64_t m, uint64_t &n_src) {
+            std::vector<int> counts, labels;
+            std::vector<double> vs;
+            p->impl.group_tables(counts, labels, vs);
+            const int crop[2] = {1, 0};
+            const double scales[2] = {0.5, 1.5};
+            std::vector<std::vector<double>> res;
+            int r = p->prep.run(f, m, p->impl.max_range_(), p->impl.min_range_(), p->impl.label_max_range_(),
+                                static_cast<int>(counts.size()), counts.data(), labels.data(), vs.data(),
+                                crop, scales, 2, res, false);
+            n_src = p->prep.kept_levels[1];
+            return r;
+        }
+        int register_source(const double guess[7], double max_dist, double kernel, double sem_th,
+                            double pose[7], sageicp_stats *stats) {
+            sageicp_frame view;                 // non-owning: the source cloud in the Prep buffers
+            view.device = p->device;
+            view.d = p->prep.d_src;
+            view.n = p->prep.kept_levels[1];
+            return sageicp_register_frame_resident(p->impl.map, &view, guess, max_dist, kernel, sem_th,
+                                                   nullptr, pose, stats);
+        }
+        int update_map(const double pose[7]) {
+            const uint64_t n_fd = p->prep.kept_levels[0];
+            if (p->impl.map_update_on_device_())
+                return device_update(p->impl.map, nullptr, n_fd, pose, p->prep.d_fd);
+            std::vector<double> fd(4 * n_fd);
+            if (n_fd) {
+                HIPCHK(hipSetDevice(p->device));
+                HIPCHK(hipMemcpy(fd.data(), p->prep.d_fd, n_fd * sizeof(Point4), hipMemcpyDeviceToHost));
+            }
+            return sageicp_map_update_pose(p->impl.map, fd.data(), n_fd, pose);
+        }
     };
-    return p->impl.register_frame(frame, n, pose_out, icp_s, total_s, n_source, stats, voxelize);
+    return p->impl.register_frame(frame, n, pose_out, icp_s, total_s, n_source, stats, Backend{p});
 }
 int sageicp_pipeline_reinitialize(sageicp_pipeline *p) {
     if (!p) return fail(SAGEICP_ERR_INVALID, "null pipeline");

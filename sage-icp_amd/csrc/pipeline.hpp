@@ -63,17 +63,19 @@ public:
         sageicp_map_clear(map);
     }
 
-    // pipeline/sageICP.cpp:54-95
-    // `voxelize(frame, n, frame_downsample, source)` is the device implementation of
-    // Preprocess() + Voxelize() (preprocess.hip; core/Preprocessing.cpp:173-187,44-84,
-    // pipeline/sageICP.cpp:57-67,97-101)
-    template <typename Voxelize>
+    // pipeline/sageICP.cpp:54-95.  The three device stages are supplied by the caller (capi.hip):
+    //   be.voxelize(frame, n, n_source)      Preprocess() + Voxelize() (preprocess.hip;
+    //                                        core/Preprocessing.cpp:173-187,44-84,
+    //                                        pipeline/sageICP.cpp:57-67,97-101); both clouds stay
+    //                                        on the device
+    //   be.register_source(guess, max_corr, kernel, sem_th, pose, stats)    RegisterFrame(source, ...)
+    //   be.update_map(pose)                  local_map_.Update(frame_downsample, pose)
+    template <typename Backend>
     int register_frame(const double *frame, uint64_t n, double pose_out[7], double *icp_s,
-                       double *total_s, uint64_t *n_source, sageicp_stats *stats,
-                       Voxelize &&voxelize) {
+                       double *total_s, uint64_t *n_source, sageicp_stats *stats, Backend &&be) {
         const auto t_pre = std::chrono::steady_clock::now();
-        std::vector<double> frame_downsample, source;
-        int rc = voxelize(frame, n, frame_downsample, source);
+        uint64_t n_src = 0;
+        int rc = be.voxelize(frame, n, n_src);
         if (rc) return rc;
         const double sigma = adaptive_threshold();
         Pose7 prediction;                                     // GetPredictionModel()
@@ -89,25 +91,20 @@ public:
 
         const auto t_icp = std::chrono::steady_clock::now();
         Pose7 new_pose;
-        rc = sageicp_register_frame(map, source.data(), source.size() / 4, guess.v, 3.0 * sigma,
-                                        sigma / 3.0, sem_th, new_pose.v, stats);
+        rc = be.register_source(guess.v, 3.0 * sigma, sigma / 3.0, sem_th, new_pose.v, stats);
         const auto t_end = std::chrono::steady_clock::now();
         if (rc) return rc;
 
         Pose7 ginv;
         se3_inv(guess.v, ginv.v);
         se3_mul(ginv.v, new_pose.v, model_deviation.v);       // UpdateModelDeviation
-        rc = map_update_on_device
-                 ? sageicp_map_update_pose_device(map, frame_downsample.data(),
-                                                  frame_downsample.size() / 4, new_pose.v)
-                 : sageicp_map_update_pose(map, frame_downsample.data(), frame_downsample.size() / 4,
-                                           new_pose.v);
+        rc = be.update_map(new_pose.v);
         if (rc) return rc;
         poses.push_back(new_pose);
         for (int i = 0; i < 7; ++i) pose_out[i] = new_pose.v[i];
         if (icp_s) *icp_s = std::chrono::duration<double>(t_end - t_icp).count();
         if (total_s) *total_s = std::chrono::duration<double>(t_end - t_pre).count();
-        if (n_source) *n_source = source.size() / 4;
+        if (n_source) *n_source = n_src;
         return SAGEICP_OK;
     }
 
@@ -122,6 +119,7 @@ public:
             labels.insert(labels.end(), g.begin(), g.end());
         }
     }
+    bool map_update_on_device_() const { return map_update_on_device; }
     double max_range_() const { return max_range; }
     double min_range_() const { return min_range; }
     double label_max_range_() const { return label_max_range; }
