@@ -919,6 +919,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
                     break;     // everything ran and nothing flagged the end: read the state below
             }
         }
+        if (stats) launch_sum_candidates(sc.d_cand, static_cast<int>(n + 1), sc.d_state, s);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(sc.h_state, sc.d_state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -932,6 +933,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
             const int todo = std::min(chunk, kMaxIterations - launched);
             for (int k = 0; k < todo; ++k)
                 if ((rc = enqueue_iteration(k, launched + k))) return rc;
+            if (stats) launch_sum_candidates(sc.d_cand, static_cast<int>(n + 1), sc.d_state, s);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(sc.h_state, sc.d_state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
@@ -952,14 +954,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     }
     const IcpState &st = *sc.h_state;
     for (int i = 0; i < 7; ++i) out[i] = st.T[i];
-    unsigned long long sum_candidates = 0;
-    if (stats) {
-        std::vector<unsigned long long> hc(n + 1);
-        HIPCHK(hipMemcpyAsync(hc.data(), sc.d_cand, sizeof(unsigned long long) * (n + 1),
-                              hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        for (unsigned long long v : hc) sum_candidates += v;
-    }
+    const unsigned long long sum_candidates = st.sum_candidates;   // summed on the device
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         stats->iterations = st.iter;

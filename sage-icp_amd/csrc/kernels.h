@@ -89,6 +89,7 @@ void launch_scatter_points(const uint32_t *idx, const Point4 *vals, uint32_t n, 
                            hipStream_t s);
 void launch_scatter_slots(const uint32_t *idx, const Slot *vals, uint32_t n, Slot *table,
                           hipStream_t s);
+void launch_sum_candidates(const unsigned long long *c, int n, IcpState *st, hipStream_t s);
 int gn_grid_for(int n);
 
 // preprocess.hip: one level of per-label-group voxel down-sampling (optionally with the range crop)

@@ -824,7 +824,28 @@ __global__ __launch_bounds__(256) void k_scatter_slots(const uint32_t *idx, cons
     if (i < n) table[idx[i]] = vals[i];
 }
 
+// sum of k_nn's per-chunk candidate counters into the loop state (one workgroup; it rides on the
+// state copy the host makes anyway instead of a 1-MB read-back of the counters)
+__global__ __launch_bounds__(1024) void k_sum_candidates(const unsigned long long *c, int n,
+                                                         IcpState *st) {
+    __shared__ unsigned long long part[16];
+    unsigned long long v = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) v += c[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int i = 0; i < 16; ++i) t += part[i];
+        st->sum_candidates = t;
+    }
+}
+
 // ------------------------------------------------------------------------------------ launchers
+void launch_sum_candidates(const unsigned long long *c, int n, IcpState *st, hipStream_t s) {
+    hipLaunchKernelGGL(k_sum_candidates, dim3(1), dim3(1024), 0, s, c, n, st);
+}
 void launch_scatter_points(const uint32_t *idx, const Point4 *vals, uint32_t n, Point4 *pts,
                            hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_scatter_points, dim3((n + 255) / 256), dim3(256), 0, s, idx, vals, n, pts);
