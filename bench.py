@@ -35,8 +35,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c4"])
-    ap.add_argument("--params", default="cold", choices=["cold", "steady"])
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c4", "c5"])
+    ap.add_argument("--params", default=None, choices=["cold", "steady", "dense", "dense_nosem"],
+                    help="default: cold (c1, c2, c4), dense (c5)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
@@ -96,6 +97,8 @@ def main():
         raise SystemExit("HIP device %d not visible to libsageicp_hip.so" % local_rank)
 
     wl = syn.WORKLOADS[args.workload]
+    if args.params is None:
+        args.params = "dense" if args.workload == "c5" else "cold"
     prm = syn.PARAMS[args.params]
     t_gen = time.time()
     w = syn.make_workload(args.workload,

@@ -237,12 +237,19 @@ WORKLOADS = {
     "c1": dict(half=60.0, map_stream=35_000, scan=10_000, voxel=0.8, seed=0xC1),
     "c2": dict(half=100.0, map_points=1_000_000, scan=120_000, voxel=1.0, seed=SEED_C2),
     "c4": dict(half=300.0, map_points=10_000_000, scan=500_000, voxel=1.0, seed=0xC4),
+    # c5: dense scan against a 0.1 m voxel map; the 27-voxel neighbourhood only
+    # reaches 0.1-0.2 m, so the planted offset is centimetres and sigma is small
+    "c5": dict(half=40.0, map_stream=3_000_000, scan=200_000, voxel=0.1, seed=0xC5,
+               T_gt=([0.0, 0.0, 0.03], [0.03, 0.01, 0.0])),
 }
 
 PARAMS = {
     # sigma -> (max_correspondence_distance = 3 sigma, kernel = sigma / 3), sageICP.cpp:83-84
     "cold": dict(max_dist=6.0, kernel=2.0 / 3.0, sem_th=0.4),     # sigma = 2.0 (start-up)
     "steady": dict(max_dist=0.9, kernel=0.1, sem_th=0.4),         # sigma = 0.3
+    # c5: sigma = 0.1; sem_th 0.8 as in ros/launch/odometry_360.launch.py:63, 1.0 = semantics off
+    "dense": dict(max_dist=0.3, kernel=0.1 / 3.0, sem_th=0.8),
+    "dense_nosem": dict(max_dist=0.3, kernel=0.1 / 3.0, sem_th=1.0),
 }
 
 
@@ -258,8 +265,9 @@ def make_workload(name, new_map, scale=1.0):
         m.AddPoints(stream)
     else:
         m, stream = build_map_points(new_map, rng, half, int(w["map_points"] * scale))
-    scan = make_scan(rng, int(w["scan"] * scale), half, T_GT_C2)
-    return dict(map=m, scan=scan, T_gt=T_GT_C2.copy(), stream=stream, voxel=w["voxel"])
+    T_gt = pose_from_rpy_t(*w["T_gt"]) if "T_gt" in w else T_GT_C2
+    scan = make_scan(rng, int(w["scan"] * scale), half, T_gt)
+    return dict(map=m, scan=scan, T_gt=T_gt.copy(), stream=stream, voxel=w["voxel"])
 
 
 def make_stream(seed, n_frames, points_per_frame=30000, half=120.0, step=(1.0, 0.0, 0.0),

@@ -298,6 +298,26 @@ def test_register_frame_pose_parity_c2_scaled(gpu_sage, oracle, params):
     assert np.array_equal(pose, pose2)
 
 
+@pytest.mark.parametrize("params", ["dense", "dense_nosem"])
+def test_register_frame_pose_parity_c5_scaled(gpu_sage, oracle, params):
+    """c5 (BASELINE configs[4]): dense scan vs a 0.1 m voxel map, semantic scaling on (0.8) / off (1.0)"""
+    from sage_icp_amd import synthetic as syn
+    w, om = _workload(gpu_sage, oracle, "c5", 0.1)
+    p = syn.PARAMS[params]
+    pose, st = gpu_sage.register_frame(w["scan"], w["map"], gpu_sage.IDENTITY, p["max_dist"],
+                                       p["kernel"], p["sem_th"], return_stats=True)
+    opose, ost = om.register_frame(w["scan"], oracle.IDENTITY, p["max_dist"], p["kernel"],
+                                   p["sem_th"])
+    dt, dr = pose_error(oracle, opose, pose)
+    assert dt < 1e-7 and dr < 1e-7
+    assert st.iterations == ost.iterations and st.converged == ost.converged == 1
+    assert st.n_corr_first == ost.n_corr_first and st.n_corr_last == ost.n_corr_last
+    assert 0 < st.n_corr_last < len(w["scan"])        # 0.1-0.2 m reach: part of the scan rejects
+    assert st.sum_candidates == ost.sum_candidates_total
+    gt, gr = pose_error(oracle, w["T_gt"], pose)
+    assert gt < 0.03 and gr < 1e-3                    # the planted centimetre offset is recovered
+
+
 def test_register_frame_c1_plumbing(gpu_sage, oracle):
     from sage_icp_amd import synthetic as syn
     w, om = _workload(gpu_sage, oracle, "c1", 1.0)
