@@ -3,6 +3,12 @@ import sys
 
 import pytest
 
+# The oracle (the checker) runs OpenMP over every core it sees; the tests' inputs are small, and on
+# a 256-thread host the fork/join of hundreds of tiny parallel regions dominates (a test module run
+# on its own took 4 minutes instead of seconds).  bench.py's cpu_baseline is not affected.
+os.environ.setdefault("OMP_NUM_THREADS", str(min(32, os.cpu_count() or 1)))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
