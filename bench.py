@@ -14,8 +14,9 @@ already resident in HBM when the timed region starts.
 Prints ONE JSON line on rank 0 (see the task contract), including
   roofline      NN kernel: algorithmic bytes (456 B/query + 16 B/candidate, SURVEY.md §8d, with
                 the candidate count taken exactly from the kernel) / HIP-event launch duration
-  cpu_baseline  the CPU oracle (a structure-faithful port of the reference path, OpenMP over all
-                host cores) timed on a bounded sample of the same frame, rank 0 at N = 1 only.
+  cpu_baseline  the CPU oracle (a structure-faithful port of the reference path, OpenMP at the
+                fastest thread count of a short sweep) timed on a bounded sample of the same frame,
+                rank 0 at N = 1 only.
 """
 import argparse
 import json
