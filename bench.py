@@ -70,15 +70,23 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
-    torch.cuda.set_device(local_rank)
+    # SAGEICP_BENCH_DEVICE / SAGEICP_BENCH_BACKEND=gloo: put several ranks on ONE GPU without RCCL —
+    # only to exercise the direct exchange between processes on a 1-GPU box
+    local_dev = int(os.environ.get("SAGEICP_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("SAGEICP_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(local_dev)
     # SAGEICP_FORCE_COMM=1 runs the multi-GPU code path (process group, RCCL communicator, in-stream
     # all-reduce) even with one rank, so it can be exercised on a 1-GPU box under torchrun.
     force_comm = os.environ.get("SAGEICP_FORCE_COMM", "0") == "1" and "RANK" in os.environ
     use_dist = world > 1 or force_comm
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", world_size=world, rank=rank,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", world_size=world, rank=rank,
+                                    device_id=torch.device("cuda", local_dev))
+        else:
+            dist.init_process_group(backend=backend, world_size=world, rank=rank)
+    red_dev = "cuda" if backend == "nccl" else "cpu"      # where the bench's own reductions live
 
     # the .so is a build artefact (git-ignored): build it in-tree if a fresh checkout has none
     if local_rank == 0 and not os.path.exists(os.path.join(ROOT, "sage-icp_amd", "libsageicp_hip.so")):
@@ -94,8 +102,8 @@ def main():
     from sage_icp_amd import synthetic as syn
     from sage_icp_amd.sharding import shard_bounds
 
-    if sage.device_count() <= local_rank:
-        raise SystemExit("HIP device %d not visible to libsageicp_hip.so" % local_rank)
+    if sage.device_count() <= local_dev:
+        raise SystemExit("HIP device %d not visible to libsageicp_hip.so" % local_dev)
 
     wl = syn.WORKLOADS[args.workload]
     if args.params is None:
@@ -103,7 +111,7 @@ def main():
     prm = syn.PARAMS[args.params]
     t_gen = time.time()
     w = syn.make_workload(args.workload,
-                          lambda: sage.VoxelHashMap(wl["voxel"], 100.0, device=local_rank),
+                          lambda: sage.VoxelHashMap(wl["voxel"], 100.0, device=local_dev),
                           scale=args.scale)
     vmap, scan = w["map"], w["scan"]
     vmap.sync()                                    # map mirror resident before the timed region
@@ -112,10 +120,47 @@ def main():
     t_gen = time.time() - t_gen
 
     comm = None
+    exchange = "none"
+
+    def all_agree(flag):
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
     if use_dist:
-        ids = [sage.Comm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        comm = sage.Comm(ids[0], rank, world, local_rank)
+        use_rccl = backend == "nccl" and os.environ.get("SAGEICP_NO_RCCL", "0") != "1"
+        if use_rccl:
+            ids = [sage.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = sage.Comm(ids[0], rank, world, local_dev)
+            exchange = "RCCL all-reduce of 20 fp64 sums + solve launch"
+        else:
+            comm = sage.Comm(None, rank, world, local_dev)
+        # Direct exchange over xGMI (HIP IPC): preferred when every rank can set it up, RCCL
+        # otherwise (SAGEICP_NO_P2P=1 forces RCCL).
+        p2p = False
+        if os.environ.get("SAGEICP_NO_P2P", "0") != "1" and world <= 8:
+            try:
+                mine = comm.p2p_export()
+            except Exception as e:                  # noqa
+                sys.stderr.write("rank %d: p2p export failed: %s\n" % (rank, e))
+                mine = b""
+            handles = [None] * world
+            dist.all_gather_object(handles, mine)
+            ok = all(h is not None and len(h) == sage.P2P_HANDLE_BYTES for h in handles)
+            if ok:
+                try:
+                    comm.p2p_connect(handles)
+                except Exception as e:              # noqa
+                    sys.stderr.write("rank %d: p2p connect failed: %s\n" % (rank, e))
+                    ok = False
+            p2p = all_agree(ok)
+            if not p2p and comm.p2p_enabled:
+                comm.p2p_enable(False)
+        if p2p:
+            exchange = "direct exchange of 20 fp64 sums over xGMI (HIP IPC), solved in k_gn"
+        elif not use_rccl:
+            raise SystemExit("no exchange path: RCCL disabled and the direct exchange unavailable")
 
     def step():
         return sage.register_frame(frame, vmap, sage.IDENTITY, prm["max_dist"], prm["kernel"],
@@ -126,8 +171,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    def warm():
+        try:
+            for _ in range(args.warmup):
+                step()
+            return True
+        except sage.SageIcpError as e:
+            sys.stderr.write("rank %d: warm-up failed: %s\n" % (rank, e))
+            return False
+
+    ok = warm()
+    if use_dist and comm.p2p_enabled and not all_agree(ok):
+        # the direct exchange did not work on this node: every rank falls back to RCCL together
+        if not (backend == "nccl" and os.environ.get("SAGEICP_NO_RCCL", "0") != "1"):
+            raise SystemExit("direct exchange failed and there is no RCCL side to fall back to")
+        comm.p2p_enable(False)
+        exchange = "RCCL all-reduce of 20 fp64 sums + solve launch (direct exchange failed)"
+        ok = warm()
+    if not ok:
+        raise SystemExit("warm-up failed")
     # level 1: HIP events around k_nn in one iteration out of 8 of the timed region (bracketing
     # every launch costs 8 % of the frame rate this line reports)
     sage.set_profiling(0 if args.no_profile_events else 1)
@@ -143,7 +205,7 @@ def main():
     elapsed = time.perf_counter() - t0
     sage.set_profiling(0)
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -252,8 +314,8 @@ def main():
                                "guess, full ICP loop to convergence"
                                % (args.workload, args.params, len(scan), vmap.size(), wl["voxel"],
                                   prm["max_dist"], prm["kernel"], prm["sem_th"]),
-                   "parallelism": "query-sharded x%d, map replicated, RCCL all-reduce of 17 fp64 sums"
-                                  % world if use_dist else "single GPU",
+                   "parallelism": "query-sharded x%d, map replicated, %s" % (world, exchange)
+                                  if use_dist else "single GPU",
                    "scan_points": len(scan), "map_points": vmap.size(),
                    "map_voxels": vmap.num_voxels(), "iterations_per_frame": iters,
                    "correspondences_first_last": [stats[-1][6], stats[-1][7]],

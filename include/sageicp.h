@@ -145,6 +145,19 @@ sageicp_comm *sageicp_comm_create(const uint8_t id[SAGEICP_UNIQUE_ID_BYTES], int
                                   int device);
 void sageicp_comm_destroy(sageicp_comm *comm);
 
+/* Direct exchange of the 20 Gauss-Newton sums between the GPUs of one node, without a collective
+ * launch: every rank exports a small block of fine-grained device memory through HIP IPC, maps its
+ * peers' blocks, and the workgroup that finishes an iteration stores its sums into every block
+ * over xGMI, waits for the others' and solves (replaces ncclAllReduce + a second launch; <= 8
+ * ranks).  Usage: export on every rank, all-gather the handles (rank order), connect.  A
+ * communicator made by sageicp_comm_create_local() has no RCCL side and only works connected. */
+#define SAGEICP_P2P_HANDLE_BYTES 64
+sageicp_comm *sageicp_comm_create_local(int rank, int nranks, int device);
+int sageicp_comm_p2p_export(sageicp_comm *comm, uint8_t handle_out[SAGEICP_P2P_HANDLE_BYTES]);
+int sageicp_comm_p2p_connect(sageicp_comm *comm, const uint8_t *handles /* nranks x 64 B */);
+int sageicp_comm_p2p_enable(sageicp_comm *comm, int on);   /* fall back to RCCL with on = 0 */
+int sageicp_comm_p2p_enabled(const sageicp_comm *comm);
+
 /* ---- Preprocess / VoxelDownsample (core/Preprocessing.hpp:33-45) on the device ------------------
  * sageicp_preprocess: core/Preprocessing.cpp:173-187 (dynamic_vehicle_filter == false): keep points
  * with min_range < |p| < max_range, zero the label beyond label_max_range; order preserved.

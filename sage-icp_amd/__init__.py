@@ -29,6 +29,7 @@ _u8p = C.POINTER(C.c_uint8)
 
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_RCCL, ERR_CAPACITY = -1, -2, -3, -4, -5
 UNIQUE_ID_BYTES = 128
+P2P_HANDLE_BYTES = 64
 
 IDENTITY = np.array([0, 0, 0, 1, 0, 0, 0], dtype=np.float64)
 
@@ -140,6 +141,11 @@ _SIGNATURES = [
       C.POINTER(Stats)]),
     ("sageicp_comm_unique_id", C.c_int, [_u8p]),
     ("sageicp_comm_create", C.c_void_p, [_u8p, C.c_int, C.c_int, C.c_int]),
+    ("sageicp_comm_create_local", C.c_void_p, [C.c_int, C.c_int, C.c_int]),
+    ("sageicp_comm_p2p_export", C.c_int, [C.c_void_p, C.POINTER(C.c_uint8)]),
+    ("sageicp_comm_p2p_connect", C.c_int, [C.c_void_p, C.POINTER(C.c_uint8)]),
+    ("sageicp_comm_p2p_enable", C.c_int, [C.c_void_p, C.c_int]),
+    ("sageicp_comm_p2p_enabled", C.c_int, [C.c_void_p]),
     ("sageicp_comm_destroy", None, [C.c_void_p]),
     ("sageicp_preprocess", C.c_int,
      [_dp, C.c_uint64, C.c_double, C.c_double, C.c_double, _dp, _u64p, C.c_int]),
@@ -214,14 +220,37 @@ class Frame:
 
 
 class Comm:
-    """RCCL communicator for query-sharded registration (one process per GPU)."""
+    """Communicator for query-sharded registration (one process per GPU): RCCL all-reduce, or the
+    direct exchange over xGMI once p2p_connect() has been called."""
 
     def __init__(self, unique_id, rank, nranks, device):
-        buf = (C.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(bytes(unique_id))
         self.rank, self.nranks = rank, nranks
-        self._h = lib().sageicp_comm_create(buf, rank, nranks, device)
+        if unique_id is None:                       # no RCCL side: direct exchange only
+            self._h = lib().sageicp_comm_create_local(rank, nranks, device)
+        else:
+            buf = (C.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(bytes(unique_id))
+            self._h = lib().sageicp_comm_create(buf, rank, nranks, device)
         if not self._h:
             raise SageIcpError(ERR_RCCL, (lib().sageicp_last_error() or b"").decode())
+
+    def p2p_export(self):
+        buf = (C.c_uint8 * P2P_HANDLE_BYTES)()
+        _check(lib().sageicp_comm_p2p_export(self._h, buf))
+        return bytes(buf)
+
+    def p2p_connect(self, handles):
+        """handles: the p2p_export() of every rank, in rank order"""
+        assert len(handles) == self.nranks
+        flat = b"".join(bytes(h) for h in handles)
+        buf = (C.c_uint8 * len(flat)).from_buffer_copy(flat)
+        _check(lib().sageicp_comm_p2p_connect(self._h, buf))
+
+    def p2p_enable(self, on=True):
+        _check(lib().sageicp_comm_p2p_enable(self._h, 1 if on else 0))
+
+    @property
+    def p2p_enabled(self):
+        return bool(lib().sageicp_comm_p2p_enabled(self._h))
 
     @staticmethod
     def unique_id():

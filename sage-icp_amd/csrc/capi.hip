@@ -412,8 +412,13 @@ struct sageicp_frame {
 };
 
 struct sageicp_comm {
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm = nullptr;           // RCCL (may be absent when only the direct exchange is used)
     int rank = 0, nranks = 1, device = 0;
+    // direct exchange of the sums over xGMI (P2pBlock, sageicp_types.h)
+    bool p2p = false;
+    P2pBlock *my_block = nullptr;        // fine-grained device memory, exported through HIP IPC
+    P2pBlock *blocks[kMaxRanks] = {};    // every rank's block as mapped here (blocks[rank] == my_block)
+    unsigned long long *d_exchanges = nullptr;
 };
 
 // ---- RCCL, bound at run time (only multi-GPU runs need it) ------------------------------------
@@ -791,7 +796,11 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     // through a host-mapped word (no stream synchronisation inside the loop).  With a
     // communicator every rank must enqueue the same number of all-reduces, so the loop advances
     // in fixed chunks (4, 8, 16, 16, ...) with one synchronisation per chunk instead.
-    const bool polled = !comm && env_int("SAGEICP_CHUNKED", 0) == 0;
+    const bool p2p = comm && comm->p2p;
+    if (comm && !p2p && !comm->comm)
+        return fail(SAGEICP_ERR_INVALID, "communicator without RCCL needs a connected p2p exchange");
+    // (the direct exchange enqueues no collective, so its loop can be polled like the 1-GPU one)
+    const bool polled = (!comm || p2p) && env_int("SAGEICP_CHUNKED", 0) == 0;
     if (prof && (rc = sc.reserve_events(polled ? kMaxIterations : kChunkMax))) return rc;
 
     fill_state(sc.h_state, init);
@@ -843,7 +852,16 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
                 sem_th, DBL_MAX, sc.d_nn, sc.d_cand};
     HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * (n + 1), s));
     GnParams gp{sc.d_src, nullptr, static_cast<int>(n), sc.d_state, 1, m->d_pts, sc.d_nn, kernel,
-                max_dist, sc.d_partials, comm ? 1 : 0, sc.d_state, &sc.d_state->gn_ticket};
+                max_dist, sc.d_partials, p2p ? 3 : (comm ? 1 : 0), sc.d_state, &sc.d_state->gn_ticket,
+                P2pParams{}};
+    if (p2p) {
+        gp.p2p.nranks = comm->nranks;
+        gp.p2p.rank = comm->rank;
+        for (int r = 0; r < comm->nranks; ++r) gp.p2p.block[r] = comm->blocks[r];
+        gp.p2p.exchanges = comm->d_exchanges;
+        gp.p2p.timeout_ticks = 100000000ull * static_cast<unsigned long long>(
+                                   std::max(1, env_int("SAGEICP_P2P_TIMEOUT_S", 5)));
+    }
     const int gn_blocks = gn_grid_for(static_cast<int>(n));
 
     double us_group = 0, us_nn = 0, us_gn = 0, us_fin = 0;
@@ -862,7 +880,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         if (ev) HIPCHK(hipEventRecord(sc.events[5 * slot + 2], s));
         launch_gn(gp, s);
         if (prof2) HIPCHK(hipEventRecord(sc.events[5 * slot + 3], s));
-        if (comm) {     // k_gn's last workgroup left the local sums in state->sums
+        if (comm && !p2p) {     // k_gn's last workgroup left the local sums in state->sums
             ncclResult_t r = g_rccl.AllReduce(sc.d_state->sums, sc.d_state->sums, kNumSums,
                                               ncclDouble, ncclSum, comm->comm, s);
             if (r != ncclSuccess)
@@ -953,6 +971,8 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         }
     }
     const IcpState &st = *sc.h_state;
+    if (st.exchange_failed)
+        return fail(SAGEICP_ERR_RCCL, "direct exchange: a peer's sums did not arrive in time");
     for (int i = 0; i < 7; ++i) out[i] = st.T[i];
     const unsigned long long sum_candidates = st.sum_candidates;   // summed on the device
     if (stats) {
@@ -1227,7 +1247,7 @@ int sageicp_align_clouds(const double *src, const double *tgt, uint64_t n, doubl
         fill_state(sc.h_state, I);
         HIPCHK(hipMemcpyAsync(sc.d_state, sc.h_state, sizeof(IcpState), hipMemcpyHostToDevice, s));
         GnParams gp{sc.d_frame, sc.d_tgt, static_cast<int>(n), sc.d_state, 0, nullptr, nullptr,
-                    kernel, 0.0, sc.d_partials, 0, sc.d_state, &sc.d_state->gn_ticket};
+                    kernel, 0.0, sc.d_partials, 0, sc.d_state, &sc.d_state->gn_ticket, P2pParams{}};
         launch_gn(gp, s);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(sc.h_state, sc.d_state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
@@ -1380,12 +1400,73 @@ sageicp_comm *sageicp_comm_create(const uint8_t id_in[SAGEICP_UNIQUE_ID_BYTES], 
     return c;
 }
 
+sageicp_comm *sageicp_comm_create_local(int rank, int nranks, int device) {
+    if (nranks < 1 || nranks > kMaxRanks || rank < 0 || rank >= nranks) {
+        fail(SAGEICP_ERR_INVALID, "sageicp_comm_create_local: bad rank/nranks (at most 8 ranks)");
+        return nullptr;
+    }
+    sageicp_comm *c = new sageicp_comm;
+    c->rank = rank; c->nranks = nranks; c->device = device;
+    return c;
+}
+
+int sageicp_comm_p2p_export(sageicp_comm *c, uint8_t handle_out[SAGEICP_P2P_HANDLE_BYTES]) {
+    if (!c || !handle_out) return fail(SAGEICP_ERR_INVALID, "null argument");
+    if (c->nranks > kMaxRanks) return fail(SAGEICP_ERR_INVALID, "direct exchange: at most 8 ranks");
+    static_assert(sizeof(hipIpcMemHandle_t) == SAGEICP_P2P_HANDLE_BYTES, "hipIpcMemHandle_t size");
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->my_block) {
+        // fine-grained: peers' stores and this rank's polling loads bypass the non-coherent caches
+        HIPCHK(hipExtMallocWithFlags(reinterpret_cast<void **>(&c->my_block), sizeof(P2pBlock),
+                                     hipDeviceMallocFinegrained));
+        HIPCHK(hipMemset(c->my_block, 0, sizeof(P2pBlock)));
+        HIPCHK(hipMalloc(&c->d_exchanges, sizeof(unsigned long long)));
+        HIPCHK(hipMemset(c->d_exchanges, 0, sizeof(unsigned long long)));
+        HIPCHK(hipDeviceSynchronize());
+    }
+    hipIpcMemHandle_t h;
+    HIPCHK(hipIpcGetMemHandle(&h, c->my_block));
+    std::memcpy(handle_out, &h, sizeof(h));
+    return SAGEICP_OK;
+}
+
+int sageicp_comm_p2p_connect(sageicp_comm *c, const uint8_t *handles) {
+    if (!c || !handles) return fail(SAGEICP_ERR_INVALID, "null argument");
+    if (!c->my_block) return fail(SAGEICP_ERR_INVALID, "sageicp_comm_p2p_export first");
+    HIPCHK(hipSetDevice(c->device));
+    for (int r = 0; r < c->nranks; ++r) {
+        if (r == c->rank) { c->blocks[r] = c->my_block; continue; }
+        if (c->blocks[r]) continue;
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, handles + static_cast<size_t>(r) * SAGEICP_P2P_HANDLE_BYTES, sizeof(h));
+        void *p = nullptr;
+        HIPCHK(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+        c->blocks[r] = static_cast<P2pBlock *>(p);
+    }
+    c->p2p = true;
+    return SAGEICP_OK;
+}
+
+int sageicp_comm_p2p_enable(sageicp_comm *c, int on) {
+    if (!c) return fail(SAGEICP_ERR_INVALID, "null argument");
+    if (on) {
+        for (int r = 0; r < c->nranks; ++r)
+            if (!c->blocks[r]) return fail(SAGEICP_ERR_INVALID, "direct exchange is not connected");
+    }
+    c->p2p = on != 0;
+    return SAGEICP_OK;
+}
+
+int sageicp_comm_p2p_enabled(const sageicp_comm *c) { return c && c->p2p ? 1 : 0; }
+
 void sageicp_comm_destroy(sageicp_comm *c) {
     if (!c) return;
-    if (c->comm && g_rccl.CommDestroy) {
-        (void)hipSetDevice(c->device);
-        g_rccl.CommDestroy(c->comm);
-    }
+    (void)hipSetDevice(c->device);
+    for (int r = 0; r < c->nranks && r < kMaxRanks; ++r)
+        if (r != c->rank && c->blocks[r]) (void)hipIpcCloseMemHandle(c->blocks[r]);
+    if (c->my_block) (void)hipFree(c->my_block);
+    if (c->d_exchanges) (void)hipFree(c->d_exchanges);
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     delete c;
 }
 

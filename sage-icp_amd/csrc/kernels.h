@@ -71,9 +71,11 @@ struct GnParams {
     double kernel;
     double max_dist;          // acceptance threshold on the unscaled distance
     double *partials;         // [gridDim.x][kNumSums]
-    int fuse_mode;            // -1: partials only; 0 / 1: the last workgroup runs finish_iteration
+    int fuse_mode;            // -1: partials only; 0 / 1: the last workgroup runs finish_iteration;
+                              //  3: it reduces, exchanges the sums with the peer GPUs (p2p), solves
     IcpState *st_rw;          // state written by finish_iteration
     unsigned *ticket;         // last-arriver ticket (zero before the first launch)
+    P2pParams p2p;            // fuse_mode 3 only
 };
 
 constexpr int kMaxGnBlocks = 512;

@@ -616,6 +616,7 @@ __device__ __forceinline__ void finish_iteration(IcpState *st, const double *par
         st->done = 1;
         done = 1;
     }
+    if (st->done) done = 1;                    // e.g. stopped by a failed multi-GPU exchange
     if (IcpProgress *pg = st->progress) {
         // host-mapped: the pose, then the progress word, as relaxed system-scope (write-through)
         // stores — a release here would write back this XCD's whole L2 every iteration; the host
@@ -631,6 +632,61 @@ __device__ __forceinline__ void finish_iteration(IcpState *st, const double *par
     fin_t[4] = __builtin_amdgcn_s_memrealtime();
     for (int i = 0; i < 4; ++i) atomicAdd(&g_gn_phase[8 + i], fin_t[i + 1] - fin_t[i]);
 #endif
+}
+
+// --------------------------------------------------------------------------------- exchange_sums
+// One workgroup per rank (the last arriver of k_gn), see P2pBlock.  st->sums holds this rank's
+// sums on entry and the sums over all ranks on exit.  Stores to the peers are system-scope
+// write-through atomics, completed (s_waitcnt) and fenced before the tag goes out; the tags are
+// polled with system-scope loads and an acquire fence precedes the reads of the rows.
+__device__ __forceinline__ void exchange_sums(IcpState *st, const P2pParams &X) {
+    const int t = static_cast<int>(threadIdx.x);
+    const unsigned long long g = *X.exchanges;
+    const int slot = static_cast<int>(g & 1ull);
+    const unsigned long long tag = g + 1ull;
+    if (t < kNumSums) {
+        const double v = st->sums[t];
+        for (int r = 0; r < X.nranks; ++r)
+            __hip_atomic_store(&X.block[r]->sums[slot][X.rank][t], v, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        for (int r = 0; r < X.nranks; ++r)
+            __hip_atomic_store(&X.block[r]->flag[X.rank], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    P2pBlock *mine = X.block[X.rank];
+    __shared__ int s_late;
+    if (t == 0) s_late = 0;
+    __syncthreads();
+    if (t < X.nranks) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(&mine->flag[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < tag) {
+            __builtin_amdgcn_s_sleep(4);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > X.timeout_ticks) {
+                s_late = 1;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    __syncthreads();
+    if (t < kNumSums) {
+        double s = 0.0;
+        for (int r = 0; r < X.nranks; ++r)       // rank order: the same sum on every rank
+            s += __hip_atomic_load(&mine->sums[slot][r][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        st->sums[t] = s;
+    }
+    if (t == 0) {
+        *X.exchanges = tag;
+        if (s_late) {                          // stop the loop; the host reports the failure
+            st->exchange_failed = 1;
+            st->done = 1;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------ k_gn
@@ -759,6 +815,15 @@ __global__ __launch_bounds__(256) void k_gn(GnParams P) {
     }
     __syncthreads();
     GN_STAMP(3);
+    if (P.fuse_mode == 3) {
+        // multi-GPU without a collective launch: local sums -> peers -> global sums -> solve
+        finish_iteration(P.st_rw, P.partials, static_cast<int>(gridDim.x), 1);
+        __syncthreads();
+        exchange_sums(P.st_rw, P.p2p);
+        __syncthreads();
+        finish_iteration(P.st_rw, P.partials, 0, 2);
+        return;
+    }
     finish_iteration(P.st_rw, P.partials, static_cast<int>(gridDim.x), P.fuse_mode);
 #ifdef SAGE_GN_TIMING
     if (threadIdx.x == 0) {

@@ -63,6 +63,25 @@ struct IcpProgress {
     double T[7];               // cumulative pose after that many iterations
 };
 
+// Direct exchange of the Gauss-Newton sums between the GPUs of one node (multi-GPU, no RCCL
+// launch): every rank owns one of these blocks in fine-grained device memory, exported to its
+// peers through HIP IPC.  In exchange g (a counter that only ever grows) the finishing workgroup
+// of rank r stores its 20 sums into slot g & 1, row r, of EVERY rank's block over xGMI, then the
+// tag g + 1 into flag[r] there; it waits until all flags of its own block carry that tag and adds
+// the rows in rank order, so every rank computes bit-identical sums.  A rank cannot run two
+// exchanges ahead of a peer (it needs the peer's next tag first), so two slots are enough.
+constexpr int kMaxRanks = 8;
+struct P2pBlock {
+    unsigned long long flag[kMaxRanks];            // written by rank i: the tag of its last exchange
+    double sums[2][kMaxRanks][kNumSums];
+};
+struct P2pParams {
+    int nranks, rank;
+    P2pBlock *block[kMaxRanks];                    // block[rank] is this rank's own
+    unsigned long long *exchanges;                 // device counter g (the same on every rank)
+    unsigned long long timeout_ticks;              // s_memrealtime ticks (100 MHz) before giving up
+};
+
 // Device-resident loop state, written by k_fin, read by every kernel of the next iteration.
 struct IcpState {
     double T[7];        // cumulative pose applied to the pristine frame: T_icp * initial_guess
@@ -77,6 +96,8 @@ struct IcpState {
     unsigned long long sum_candidates;  // sum over launches and queries of C_q (roofline bytes)
     uint32_t n_corr[kHistory];      // accepted correspondences per iteration (all ranks)
     IcpProgress *progress;          // host-mapped progress block (nullptr: not published)
+    int32_t exchange_failed;        // a peer's sums did not arrive in time (multi-GPU direct exchange)
+    int32_t pad_;
 };
 
 // Index into the 16 closed-form sums of AlignClouds (Registration.cpp:59-94):

@@ -387,6 +387,55 @@ def test_register_frame_through_rccl_comm_world1(gpu_sage, oracle):
     assert np.array_equal(ref, got)
 
 
+def test_register_frame_through_direct_exchange_world1(gpu_sage, oracle):
+    """the direct exchange path (reduce -> stores into the mapped blocks -> tags -> solve in k_gn)
+    with a one-rank communicator that has no RCCL side; the RCCL communicator can switch to it
+    and back"""
+    w, om = _workload(gpu_sage, oracle, "c2", 0.05)
+    f = gpu_sage.Frame(w["map"], w["scan"])
+    ref, rst = gpu_sage.register_frame(f, w["map"], gpu_sage.IDENTITY, 6.0, 2 / 3, 0.4, return_stats=True)
+    comm = gpu_sage.Comm(None, 0, 1, 0)
+    with pytest.raises(gpu_sage.SageIcpError):      # neither RCCL nor a connected exchange yet
+        gpu_sage.register_frame(f, w["map"], gpu_sage.IDENTITY, 6.0, 2 / 3, 0.4, comm=comm)
+    comm.p2p_connect([comm.p2p_export()])
+    assert comm.p2p_enabled
+    for _ in range(3):                              # the exchange counter carries over between calls
+        got, st = gpu_sage.register_frame(f, w["map"], gpu_sage.IDENTITY, 6.0, 2 / 3, 0.4, comm=comm,
+                                          return_stats=True)
+        assert np.array_equal(ref, got) and st.iterations == rst.iterations
+    both = gpu_sage.Comm(gpu_sage.Comm.unique_id(), 0, 1, 0)
+    both.p2p_connect([both.p2p_export()])
+    a = gpu_sage.register_frame(f, w["map"], gpu_sage.IDENTITY, 6.0, 2 / 3, 0.4, comm=both)
+    both.p2p_enable(False)
+    b = gpu_sage.register_frame(f, w["map"], gpu_sage.IDENTITY, 6.0, 2 / 3, 0.4, comm=both)
+    assert np.array_equal(a, ref) and np.array_equal(b, ref)
+
+
+def test_direct_exchange_between_two_processes(gpu_sage, tmp_path):
+    """bench.py with two ranks on the one GPU of the box (gloo rendezvous, no RCCL): each rank
+    registers half of the frame and the sums travel through the HIP-IPC mapped blocks"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SAGEICP_BENCH_DEVICE="0", SAGEICP_BENCH_BACKEND="gloo",
+               SAGEICP_P2P_TIMEOUT_S="3", MASTER_ADDR="127.0.0.1")
+    common = ["--steps", "2", "--warmup", "1", "--scale", "0.1", "--no-cpu-baseline"]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                          "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+                          os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    d2 = json.loads(two.stdout.strip().splitlines()[-1])
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common,
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads(one.stdout.strip().splitlines()[-1])
+    assert d2["n_gpus"] == 2 and "direct exchange" in d2["config"]["parallelism"]
+    assert d2["config"]["iterations_per_frame"] == d1["config"]["iterations_per_frame"]
+    assert d2["config"]["converged"] and d2["config"]["pose_error_vs_planted"] == d1["config"]["pose_error_vs_planted"]
+
+
 def test_profiling_stats(gpu_sage, oracle):
     w, om = _workload(gpu_sage, oracle, "c2", 0.05)
     gpu_sage.set_profiling(2)
