@@ -180,6 +180,7 @@ def main():
             sys.stderr.write("rank %d: warm-up failed: %s\n" % (rank, e))
             return False
 
+    fence()          # every rank has its map and frame in HBM before the first exchange is waited for
     ok = warm()
     if use_dist and comm.p2p_enabled and not all_agree(ok):
         # the direct exchange did not work on this node: every rank falls back to RCCL together

@@ -860,7 +860,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         for (int r = 0; r < comm->nranks; ++r) gp.p2p.block[r] = comm->blocks[r];
         gp.p2p.exchanges = comm->d_exchanges;
         gp.p2p.timeout_ticks = 100000000ull * static_cast<unsigned long long>(
-                                   std::max(1, env_int("SAGEICP_P2P_TIMEOUT_S", 5)));
+                                   std::max(1, env_int("SAGEICP_P2P_TIMEOUT_S", 10)));
     }
     const int gn_blocks = gn_grid_for(static_cast<int>(n));
 
