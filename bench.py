@@ -193,18 +193,40 @@ def main():
         raise SystemExit("warm-up failed")
     # level 1: HIP events around k_nn in one iteration out of 8 of the timed region (bracketing
     # every launch costs 8 % of the frame rate this line reports)
-    sage.set_profiling(0 if args.no_profile_events else 1)
-    fence()
-    t0 = time.perf_counter()
-    stats = []
-    pose = None
-    for _ in range(args.steps):
-        pose, st = step()
-        stats.append((st.iterations, st.us_nn, st.nn_launches, st.sum_candidates, st.us_gn,
-                      st.us_fin, st.n_corr_first, st.n_corr_last, st.converged))
-    fence()
-    elapsed = time.perf_counter() - t0
-    sage.set_profiling(0)
+    def timed():
+        """EXACTLY args.steps steps between two fences; None if a step failed on this rank"""
+        sage.set_profiling(0 if args.no_profile_events else 1)
+        fence()
+        t0 = time.perf_counter()
+        stats, pose, good = [], None, True
+        try:
+            for _ in range(args.steps):
+                pose, st = step()
+                stats.append((st.iterations, st.us_nn, st.nn_launches, st.sum_candidates, st.us_gn,
+                              st.us_fin, st.n_corr_first, st.n_corr_last, st.converged))
+        except sage.SageIcpError as e:
+            sys.stderr.write("rank %d: timed step failed: %s\n" % (rank, e))
+            good = False
+        fence()
+        elapsed = time.perf_counter() - t0
+        sage.set_profiling(0)
+        return (elapsed, stats, pose) if good else None
+
+    res = timed()
+    if use_dist and not all_agree(res is not None):
+        # an exchange failed in the timed region: every rank switches to RCCL and times again
+        if not (comm.p2p_enabled and backend == "nccl" and os.environ.get("SAGEICP_NO_RCCL", "0") != "1"):
+            raise SystemExit("a timed step failed")
+        comm.p2p_enable(False)
+        exchange = "RCCL all-reduce of 20 fp64 sums + solve launch (direct exchange failed)"
+        if not all_agree(warm()):
+            raise SystemExit("warm-up failed after the fallback to RCCL")
+        res = timed()
+        if not all_agree(res is not None):
+            raise SystemExit("a timed step failed")
+    if res is None:
+        raise SystemExit("a timed step failed")
+    elapsed, stats, pose = res
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
