@@ -861,6 +861,8 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         gp.p2p.exchanges = comm->d_exchanges;
         gp.p2p.timeout_ticks = 100000000ull * static_cast<unsigned long long>(
                                    std::max(1, env_int("SAGEICP_P2P_TIMEOUT_S", 10)));
+        if (const int ticks = env_int("SAGEICP_P2P_TIMEOUT_TICKS", 0))      // tests: provoke a timeout
+            gp.p2p.timeout_ticks = static_cast<unsigned long long>(ticks);
     }
     const int gn_blocks = gn_grid_for(static_cast<int>(n));
 

@@ -436,6 +436,22 @@ def test_direct_exchange_between_two_processes(gpu_sage, tmp_path):
     assert d2["config"]["converged"] and d2["config"]["pose_error_vs_planted"] == d1["config"]["pose_error_vs_planted"]
 
 
+def test_direct_exchange_timeout_is_reported_not_hung(gpu_sage):
+    """a peer whose sums do not arrive in time stops the loop with an error on every rank"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SAGEICP_BENCH_DEVICE="0", SAGEICP_BENCH_BACKEND="gloo",
+               SAGEICP_P2P_TIMEOUT_TICKS="1", MASTER_ADDR="127.0.0.1")
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                          "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29534",
+                          os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--scale", "0.1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert run.returncode != 0
+    assert "did not arrive in time" in run.stderr and "no RCCL side to fall back to" in run.stderr
+
+
 def test_profiling_stats(gpu_sage, oracle):
     w, om = _workload(gpu_sage, oracle, "c2", 0.05)
     gpu_sage.set_profiling(2)
