@@ -49,14 +49,15 @@ static int env_int(const char *name, int dflt) {
 // Queries per k_nn wave (= the cap on a group of same-voxel queries), a power of two <= 16.
 // Measured on MI355X: 4 is best once the frame fills the chip several times over (c2: 80 us
 // against 83 / 99 us for 2 / 1); smaller frames are bound by the dependent chain of a single
-// wave, and shorter chunks mean more, shorter waves (c1 and 24k-point stream frames: 4-7 % faster
-// with 1).  SAGEICP_GROUP_MAX / SAGEICP_NN_CHUNK override both for experiments.
+// wave, and shorter chunks mean more, shorter waves (a 30k-query shard: 36.8 us per iteration
+// with 2 against 38.4 / 40.3 with 4 / 1; 10k-24k frames: 2 and 1 within 2 %).
+// SAGEICP_GROUP_MAX / SAGEICP_NN_CHUNK override both for experiments.
 struct NnShape {
     unsigned chunk, chunk_log2, cap_heads;
 };
 static NnShape nn_shape(uint64_t n) {
     int cap = env_int("SAGEICP_GROUP_MAX", 0);
-    if (cap <= 0) cap = n <= 32768 ? 1 : (n <= 65536 ? 2 : 4);
+    if (cap <= 0) cap = n <= 65536 ? 2 : 4;
     int c = 1;
     while (c * 2 <= cap && c < 16) c *= 2;      // three lanes per query in k_nn's prologue
     cap = c;
