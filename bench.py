@@ -181,6 +181,22 @@ def main():
             return False
 
     fence()          # every rank has its map and frame in HBM before the first exchange is waited for
+    if use_dist and comm.p2p_enabled and backend == "nccl" and os.environ.get("SAGEICP_NO_RCCL", "0") != "1":
+        # cross-check before trusting the direct exchange on this node: the same frame through
+        # RCCL and through the mapped blocks must give the same pose (the summation order over
+        # the ranks differs, nothing else)
+        try:
+            comm.p2p_enable(False)
+            pose_rccl, _ = step()
+            comm.p2p_enable(True)
+            pose_p2p, _ = step()
+            same = bool(np.allclose(pose_rccl, pose_p2p, rtol=0.0, atol=1e-6))
+        except sage.SageIcpError as e:
+            sys.stderr.write("rank %d: exchange cross-check failed: %s\n" % (rank, e))
+            same = False
+        if not all_agree(same):
+            comm.p2p_enable(False)
+            exchange = "RCCL all-reduce of 20 fp64 sums + solve launch (direct exchange failed its cross-check)"
     ok = warm()
     if use_dist and comm.p2p_enabled and not all_agree(ok):
         # the direct exchange did not work on this node: every rank falls back to RCCL together
