@@ -60,6 +60,8 @@ typedef struct sageicp_stats {
     uint64_t sum_candidates;    /* sum over iterations and queries of C_q: map points stored in the
                                  * <=27 existing neighbour voxels of each query (this rank) */
     uint32_t n_corr_hist[64];   /* accepted correspondences of the first 64 iterations */
+    uint64_t pairs_evaluated;   /* (query, map point) pairs the search actually evaluated, all
+                                 * iterations: sum_candidates minus what the cell lower bound pruned */
 } sageicp_stats;
 
 /* ---- library ------------------------------------------------------------------------ */

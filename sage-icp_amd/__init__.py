@@ -58,6 +58,7 @@ class Stats(C.Structure):
         ("resorts", C.c_uint32),
         ("sum_candidates", C.c_uint64),
         ("n_corr_hist", C.c_uint32 * 64),
+        ("pairs_evaluated", C.c_uint64),
     ]
 
 

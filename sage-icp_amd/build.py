@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["csrc/kernels.hip", "csrc/sort.hip", "csrc/preprocess.hip", "csrc/map_update.hip",
            "csrc/capi.hip"]
-HEADERS = ["csrc/kernels.h", "csrc/sageicp_types.h", "csrc/se3_math.h", "csrc/host_map.hpp", "csrc/pipeline.hpp",
+HEADERS = ["csrc/kernels.h", "csrc/sageicp_types.h", "csrc/se3_math.h", "csrc/host_map.hpp", "csrc/pipeline.hpp", "csrc/map_update.h", "csrc/metrics.hpp",
            "../include/sageicp.h"]
 OUT = os.path.join(HERE, "libsageicp_hip.so")
 

@@ -104,7 +104,7 @@ struct Scratch {
     Point4 *d_src = nullptr; uint2 *d_blks = nullptr;
     int4 *d_tabkey = nullptr;
     double *d_partials = nullptr;
-    unsigned long long *d_cand = nullptr;      // per-chunk candidate counters of k_nn [sort_cap]
+    unsigned long long *d_cand = nullptr;      // per-chunk counters of k_nn [2 x sort_cap]
     IcpState *d_state = nullptr;
     IcpState *h_state = nullptr;   // pinned
     IcpProgress *h_prog = nullptr; // pinned + host-mapped: written by the device every iteration
@@ -174,7 +174,7 @@ struct Scratch {
         HIPCHK(hipMalloc(&d_tabkey, cap * sizeof(int4)));
         if (d_cand) HIPCHK(hipFree(d_cand));
         d_cand = nullptr;
-        HIPCHK(hipMalloc(&d_cand, cap * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc(&d_cand, 2 * cap * sizeof(unsigned long long)));
         HIPCHK(hipMalloc(&d_keys, 2 * cap * sizeof(uint32_t)));
         HIPCHK(hipMalloc(&d_vals, 2 * cap * sizeof(uint32_t)));
         sort_temp_bytes_ = sort_temp_bytes(static_cast<int>(cap));
@@ -782,6 +782,41 @@ void fill_state(IcpState *st, const double init[7]) {
     identity_pose(st->T_icp);
 }
 
+// k_nn's arguments for a search of `n` queries against the HBM copy of `m`
+NnParams nn_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, double sem_th) {
+    const Scratch &sc = m->sc;
+    const NnShape shape = nn_shape(n);
+    NnParams np{};
+    np.frame = d_queries;
+    np.src = nullptr;
+    np.n = static_cast<int>(n);
+    np.st = sc.d_state;
+    np.check_done = 0;
+    np.apply_pose = 0;
+    np.voxel_size = m->host.voxel_size;
+    np.chunk = shape.chunk;
+    np.chunk_log2 = shape.chunk_log2;
+    np.cap_heads = shape.cap_heads;
+    np.nchunks = static_cast<unsigned>((n + shape.chunk - 1) / shape.chunk);
+    np.tabkey = sc.d_tabkey;
+    np.blks = sc.d_blks;
+    np.table = m->d_table;
+    np.mask = static_cast<uint32_t>(m->d_table_cap - 1);
+    np.pts = m->d_pts;
+    np.pts_bytes = static_cast<uint32_t>((m->d_blocks_cap * m->host.cap + 1) * sizeof(Point4));
+    np.cap = m->host.cap;
+    np.sem_th = sem_th;
+    np.dist_init = DBL_MAX;
+    // scaled distance = d2 * sem_th for matching labels, d2 otherwise: >= min(sem_th, 1) * d2.
+    // A negative or NaN sem_th gives no usable bound: every occupied voxel is visited.
+    const bool prune = sem_th >= 0.0 && env_int("SAGEICP_NO_PRUNE", 0) == 0;
+    np.prune_scale = prune ? std::min(sem_th, 1.0) * (1.0 - 1e-9) : 0.0;
+    np.keep_all = prune ? 0u : 0x7FFFFFFu;
+    np.nn_idx = sc.d_nn;
+    np.cand_counter = nullptr;
+    return np;
+}
+
 // The ICP loop of Registration.cpp:127-138 as a stream of launches.
 int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const double init[7],
             double max_dist, double kernel, double sem_th, sageicp_comm *comm, double out[7],
@@ -845,13 +880,12 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         d_frame = sc.d_sorted;
     }
 
-    const NnShape shape = nn_shape(n);
-    NnParams np{d_frame, sc.d_src, static_cast<int>(n), sc.d_state, 1, 1, m->host.voxel_size,
-                shape.chunk, shape.chunk_log2, shape.cap_heads, sc.d_tabkey, sc.d_blks,
-                m->d_table, static_cast<uint32_t>(m->d_table_cap - 1), m->d_pts,
-                static_cast<uint32_t>((m->d_blocks_cap * m->host.cap + 1) * sizeof(Point4)), m->host.cap,
-                sem_th, DBL_MAX, sc.d_nn, sc.d_cand};
-    HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * (n + 1), s));
+    NnParams np = nn_params(m, d_frame, n, sem_th);
+    np.src = sc.d_src;
+    np.check_done = 1;
+    np.apply_pose = 1;
+    np.cand_counter = sc.d_cand;
+    HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * 2 * (n + 1), s));
     GnParams gp{sc.d_src, nullptr, static_cast<int>(n), sc.d_state, 1, m->d_pts, sc.d_nn, kernel,
                 max_dist, sc.d_partials, p2p ? 3 : (comm ? 1 : 0), sc.d_state, &sc.d_state->gn_ticket,
                 P2pParams{}};
@@ -992,6 +1026,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         stats->nn_launches = nn_launches;
         stats->resorts = resorts;
         stats->sum_candidates = sum_candidates;
+        stats->pairs_evaluated = st.sum_pairs;
         for (int i = 0; i < 64 && i < st.iter; ++i) stats->n_corr_hist[i] = st.n_corr[i];
         stats->us_wall = now_us() - t_begin;
     }
@@ -1195,12 +1230,7 @@ int sageicp_get_correspondences(const sageicp_map *m, const double *q, uint64_t 
                       m->host.voxel_size, sc.d_keys, sc.d_vals, sc.d_sort_temp, sc.sort_temp_bytes_,
                       s));
     HIPCHK(hipMemsetAsync(sc.d_tabkey, 0x7F, (n + 1) * sizeof(int4), s));
-    const NnShape shape = nn_shape(n);
-    NnParams np{sc.d_sorted, sc.d_src, static_cast<int>(n), sc.d_state, 0, 0, m->host.voxel_size,
-                shape.chunk, shape.chunk_log2, shape.cap_heads, sc.d_tabkey, sc.d_blks,
-                m->d_table, static_cast<uint32_t>(m->d_table_cap - 1), m->d_pts,
-                static_cast<uint32_t>((m->d_blocks_cap * m->host.cap + 1) * sizeof(Point4)), m->host.cap,
-                sem_th, DBL_MAX, sc.d_nn, nullptr};
+    const NnParams np = nn_params(m, sc.d_sorted, n, sem_th);     // identity pose, no loop state
     launch_nn(np, s);
     HIPCHK(hipGetLastError());
     std::vector<int32_t> idx(n);

@@ -9,7 +9,7 @@ namespace sageicp {
 
 struct NnParams {
     const Point4 *frame;      // pristine (sorted) frame, or ready-made queries (apply_pose == 0)
-    Point4 *src;              // out: the queries as searched (pose applied), for k_gn
+    Point4 *src;              // out (optional): the queries as searched (pose applied), for k_gn
     int n;
     const IcpState *st;       // pose to apply and the done flag
     int check_done;           // 1 inside the ICP loop: later launches of a finished loop are no-ops
@@ -20,42 +20,38 @@ struct NnParams {
     unsigned chunk_log2;
     unsigned cap_heads;       // forced heads inside a chunk: bit i set for every i that is a multiple
                               // of the group cap (1 when the cap equals the chunk)
+    unsigned nchunks;         // ceil(n / chunk)
     int4 *tabkey;             // [n] home voxel each cached probe-table row was built for (y, z, w)
     uint2 *blks;              // [n][32] probe-table rows {candidate offset, first point}
     const Slot *table;        // the open-addressed voxel hash
     uint32_t mask;
     const Point4 *pts;
-    uint32_t pts_bytes;       // size of the point array (< 4 GiB: k_nn addresses it by byte offset);
-                              // its last 32 B hold a NaN point, the padding of candidate lists
+    uint32_t pts_bytes;       // size of the point array (< 4 GiB: k_nn addresses it by byte offset)
     int cap;
     double sem_th;
     double dist_init;         // DBL_MAX
+    double prune_scale;       // min(sem_th, 1) * (1 - 1e-9): scaled distance >= this x squared
+                              // distance to the voxel's cell (0 when pruning is off)
+    unsigned keep_all;        // 0x7FFFFFF: visit every occupied voxel (pruning off: sem_th < 0 or
+                              // not a number); 0: prune by the cell lower bound
     int32_t *nn_idx;          // out: block*cap+slot of the semantic nearest neighbour, -1 if the
                               //      27-voxel neighbourhood is empty (acceptance is applied later)
-    unsigned long long *cand_counter;  // optional: [>= n] per-chunk running sums of C_q
+    unsigned long long *cand_counter;  // optional: [2 x nchunks] per-chunk running sums of
+                                       // {C_q, pairs evaluated}
 };
 
 // k_nn's per-wave LDS layout, in 32-bit words from the wave's base (host and device agree on it)
 struct NnLds {
-    unsigned marks;           // 64-bit start-mark bitmap over the flat candidate indices
-    unsigned delta;           // 32 x (first point - candidate offset) of the occupied voxels
     unsigned spt;             // chunk x {x, y, z, label} fp64
+    unsigned gap;             // chunk x 6 fp64: scaled squared gaps to the faces of the home cell
     unsigned skey;            // 3 x chunk home voxel indices
     unsigned wave_words;
 };
-__host__ __device__ inline NnLds nn_lds_layout(int cap, unsigned chunk) {
+__host__ __device__ inline NnLds nn_lds_layout(unsigned chunk) {
     NnLds l;
-    const unsigned ncand = 27u * static_cast<unsigned>(cap);
-#ifdef SAGE_NN_U_BIG
-    constexpr unsigned pad = (SAGE_NN_U_BIG * 64u > 128u) ? SAGE_NN_U_BIG * 64u : 128u;
-#else
-    constexpr unsigned pad = 128u;
-#endif
-    l.marks = (ncand + pad - 1u) & ~(pad - 1u);   // after the candidate list, padded to its widest stride
-    const unsigned mark_words = (((ncand + 63u) >> 6) + 1u) & ~1u;   // 64-bit words, even count
-    l.delta = l.marks + 2u * mark_words;
-    l.spt = l.delta + 32u;
-    l.skey = l.spt + 8u * chunk;
+    l.spt = 0u;
+    l.gap = 8u * chunk;
+    l.skey = l.gap + 12u * chunk;
     l.wave_words = (l.skey + 3u * chunk + 3u) & ~3u;
     return l;
 }

@@ -40,8 +40,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 #include <cstdlib>
+#include <vector>
 
 #ifndef SAGE_NN_WAVES
 #define SAGE_NN_WAVES 1
@@ -171,19 +173,30 @@ SAGE_MIN_U32_DPP(min_u32_half_mirror, "row_half_mirror")
 SAGE_MIN_U32_DPP(min_u32_mirror, "row_mirror")
 #undef SAGE_MIN_U32_DPP
 
-// One group: `len` (1..32) consecutive queries that share a home voxel, C candidates enumerated
-// in LDS.  W = 2^LW lanes serve each query, lane ci of them visiting candidates ci, ci+W, ...
-// Control flow is wave-uniform and branch-free inside the loop (indices are clamped, invalid
-// pairs are masked by select), which keeps the scalar unit — one per CU, shared by the four
-// SIMDs — out of the critical path.
+// One group: `len` (1..16) consecutive queries that share a home voxel.  W = 2^LW lanes serve each
+// query.  The 27-voxel neighbourhood is walked VOXEL BY VOXEL, the home voxel first: a voxel's
+// points are one contiguous run of 32-B records, lane ci of a query takes points ci, ci + W, ...
+// (scalar base offset + per-lane index through the raw buffer resource: no address arithmetic, no
+// candidate list).  After the home voxel every other occupied voxel is kept only if its CELL can
+// still hold a better point for at least one query of the group — an exact test:
+//   a point stored in voxel v lies in v's cell (it was inserted by the same fp64 divide +
+//   truncation, VoxelHashMap.cpp:165), so its squared distance to the query is at least the
+//   squared distance to the cell, and its semantically scaled distance (VoxelHashMap.cpp:87-88)
+//   at least min(th, 1) times that.  If that lower bound (taken with a relative slack of 1e-9
+//   and an absolute slack on every face, far above fp64 rounding) is strictly above the best
+//   scaled distance the query already holds, no point of v can win or tie.
+// The surviving voxels are visited in ascending order and every lane keeps the lexicographic
+// minimum of (scaled distance, enumeration index) — enumeration index = the reference's order, x
+// outer, y, z inner, then insertion order (VoxelHashMap.cpp:57-63,73-75) — so the result is the
+// sequential strict-< scan's, index for index.
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
-// One map point through the buffer path: `off` is its byte offset in the point array (what the
-// LDS candidate list holds), the resource carries the 64-bit base, so a load costs no address
-// arithmetic (a flat 64-bit address took three VALU instructions per candidate).
-__device__ __forceinline__ Point4 load_point(__amdgpu_buffer_rsrc_t pts, uint32_t off) {
-    const v4u a = __builtin_amdgcn_raw_buffer_load_b128(pts, off, 0, 0);
-    const v4u b = __builtin_amdgcn_raw_buffer_load_b128(pts, off + 16u, 0, 0);
+// One map point through the buffer path: byte offset = scalar `soff` (the voxel block's first
+// point) + per-lane `voff`; the resource carries the 64-bit base, so a load costs no VALU address
+// arithmetic.
+__device__ __forceinline__ Point4 load_point(__amdgpu_buffer_rsrc_t pts, uint32_t voff, uint32_t soff) {
+    const v4u a = __builtin_amdgcn_raw_buffer_load_b128(pts, voff, soff, 0);
+    const v4u b = __builtin_amdgcn_raw_buffer_load_b128(pts, voff + 16u, soff, 0);
     Point4 q;
     q.x = __hiloint2double(static_cast<int>(a.y), static_cast<int>(a.x));
     q.y = __hiloint2double(static_cast<int>(a.w), static_cast<int>(a.z));
@@ -192,10 +205,22 @@ __device__ __forceinline__ Point4 load_point(__amdgpu_buffer_rsrc_t pts, uint32_
     return q;
 }
 
-template <int LW, int U>      // W = 2^LW lanes per query, U candidate loads in flight per lane
-__device__ __forceinline__ void nn_group(const NnParams &P, __amdgpu_buffer_rsrc_t pts,
-                                         const uint32_t *cand, int lane, int start, int len,
-                                         unsigned C, const Point4 &p) {
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// lanes 0..26 <-> neighbour voxel (ox, oy, oz) + 1 = (lane / 9, lane / 3 % 3, lane % 3)
+constexpr unsigned long long kMaskXNeg = 0x00001FFull, kMaskXPos = 0x7FC0000ull;
+constexpr unsigned long long kMaskYNeg = 0x01C0E07ull, kMaskYPos = 0x70381C0ull;
+constexpr unsigned long long kMaskZNeg = 0x1249249ull, kMaskZPos = 0x4924924ull;
+constexpr unsigned kHomeVoxel = 13u;
+
+template <int LW>      // W = 2^LW lanes per query
+__device__ __forceinline__ void nn_group(const NnParams &P, __amdgpu_buffer_rsrc_t pts, int lane,
+                                         int start, int len, const uint2 ob, const Point4 &p,
+                                         const double *gap, unsigned &pairs_eval) {
     constexpr int W = 1 << LW;
     const int qi = lane >> LW;                  // query of this lane within the group
     const unsigned ci = lane & (W - 1);
@@ -205,46 +230,44 @@ __device__ __forceinline__ void nn_group(const NnParams &P, __amdgpu_buffer_rsrc
 
     // closest_distance2 starts at numeric_limits<double>::max() (VoxelHashMap.cpp:80); the value
     // travels as a kernel argument so that it sits in scalar registers
-    double best = P.dist_init;        // scaled squared distance
-    // Lane ci visits the flat candidate indices ci, ci + W, ci + 2W, ...; it remembers the STEP
-    // (a wave-uniform counter) of its best one, the flat index — the enumeration order the
-    // tie-break needs — is rebuilt once after the loop.
-    unsigned best_step = 0xFFFFFFFFu;
+    double best = P.dist_init;                  // scaled squared distance
+    unsigned best_f = 0xFFFFFFFFu;              // its enumeration index (the tie-break key)
+    unsigned best_off = 0u;                     // its byte offset in the point array
 
-    auto eval = [&](unsigned step, const Point4 &nb) {
-        const double dx = nb.x - p.x, dy = nb.y - p.y, dz = nb.z - p.z;
-        double d = dx * dx + (dy * dy + dz * dz);
-        // same label, or either side unlabelled (VoxelHashMap.cpp:87-88)
-        // ((int)(a * b) == 0  <=>  |a * b| < 1 under truncation toward zero)
-        const bool same = static_cast<int>(nb.l) == pli || fabs(nb.l * p.l) < 1.0;
-        const double ds = d * th;
-        d = same ? ds : d;
-        const bool take = d < best;       // strict <: first minimum wins in a lane; NaN never wins
-        best = min_f64(best, d);
-        best_step = take ? step : best_step;
+    // lane v < 27 holds voxel v's row: ob.x = candidates before it, ob.y = its first point
+    const unsigned cnt = dpp_u32<0x130>(ob.x) - ob.x;             // wave_shl:1 -> points in voxel v
+    const unsigned occ = static_cast<unsigned>(__ballot(lane < 27 && cnt != 0u));
+
+    auto visit = [&](int v) {                   // v is wave-uniform
+        const unsigned off_v = rl_u32(ob.x, v), cnt_v = rl_u32(cnt, v);
+        const unsigned base = rl_u32(ob.y, v) << 5;              // byte offset of 32-B points
+        pairs_eval += cnt_v;
+        for (unsigned i0 = 0; i0 < cnt_v; i0 += W) {             // uniform trip count
+            const unsigned i = i0 + ci;
+            if (i < cnt_v) {
+                const Point4 nb = load_point(pts, i << 5, base);
+                const double dx = nb.x - p.x, dy = nb.y - p.y, dz = nb.z - p.z;
+                double d = dx * dx + (dy * dy + dz * dz);
+                // same label, or either side unlabelled (VoxelHashMap.cpp:87-88)
+                // ((int)(a * b) == 0  <=>  |a * b| < 1 under truncation toward zero)
+                const bool same = static_cast<int>(nb.l) == pli || fabs(nb.l * p.l) < 1.0;
+                const double ds = d * th;
+                d = same ? ds : d;
+                const unsigned f = off_v + i;
+                // lexicographic (d, f): voxels are not visited in enumeration order (home first);
+                // a NaN distance never wins
+                const bool lt = d < best, eq = d == best, fl = f < best_f;
+                const bool take = lt | (eq & fl);               // no short-circuit branches
+                best = min_f64(best, d);
+                best_f = take ? f : best_f;
+                best_off = take ? base + (i << 5) : best_off;
+            }
+        }
     };
 
-    // The list is padded up to a multiple of U * W entries with the offset of a NaN point (its
-    // distance fails d < best and leaves v_min_f64 unchanged), so the loop needs no index clamp,
-    // no bounds test, and its LDS reads sit at immediate offsets from one per-lane address.
-    const uint32_t *cp = cand + ci;
-    unsigned step = 0;
-    for (unsigned f0 = 0; f0 < C; f0 += U * W, step += U, cp += U * W) {   // uniform trip count
-        uint32_t off[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) off[u] = cp[u * W];
-        Point4 nb[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) nb[u] = load_point(pts, off[u]);
-#pragma unroll
-        for (int u = 0; u < U; ++u) eval(step + static_cast<unsigned>(u), nb[u]);
-    }
-    unsigned best_f = (best_step == 0xFFFFFFFFu) ? 0xFFFFFFFFu : (best_step << LW) + ci;
-    const unsigned last = C ? C - 1 : 0;
+    if ((occ >> kHomeVoxel) & 1u) visit(static_cast<int>(kHomeVoxel));
 
-    // argmin over the W lanes of each query, lexicographic in (distance, enumeration index) like
-    // the sequential strict-< scan it replaces: first the minimum distance (never NaN: a NaN
-    // distance fails d < best), then the smallest index among the lanes that hold it.
+    // what every query holds after its home voxel bounds the rest of its search
     double m = best;
     if (W >= 2) m = min_f64(m, dpp_f64<kDppXor1>(m));
     if (W >= 4) m = min_f64(m, dpp_f64<kDppXor2>(m));
@@ -252,23 +275,67 @@ __device__ __forceinline__ void nn_group(const NnParams &P, __amdgpu_buffer_rsrc
     if (W >= 16) m = min_f64(m, dpp_f64<kDppMirror>(m));
     if (W >= 32) m = min_f64(m, __shfl_xor(m, 16, 64));
     if (W >= 64) m = min_f64(m, __shfl_xor(m, 32, 64));
-    best_f = (best == m) ? best_f : 0xFFFFFFFFu;
-    if (W >= 2) best_f = min_u32_xor1(best_f);
-    if (W >= 4) best_f = min_u32_xor2(best_f);
-    if (W >= 8) best_f = min_u32_half_mirror(best_f);
-    if (W >= 16) best_f = min_u32_mirror(best_f);
-    if (W >= 32) best_f = min(best_f, static_cast<unsigned>(__shfl_xor(static_cast<int>(best_f), 16, 64)));
-    if (W >= 64) best_f = min(best_f, static_cast<unsigned>(__shfl_xor(static_cast<int>(best_f), 32, 64)));
+
+    unsigned need = P.keep_all;                 // 0, or all 27 voxels when pruning is off
+    {
+        const bool xn = (kMaskXNeg >> lane) & 1ull, xp = (kMaskXPos >> lane) & 1ull;
+        const bool yn = (kMaskYNeg >> lane) & 1ull, yp = (kMaskYPos >> lane) & 1ull;
+        const bool zn = (kMaskZNeg >> lane) & 1ull, zp = (kMaskZPos >> lane) & 1ull;
+        for (int q = 0; q < len; ++q) {         // lane v < 27: lower bound of voxel v for query q
+            const double bq = readlane_f64(m, q << LW);
+            // uniform addresses: three broadcast reads, then per-lane selects
+            const double2 g01 = *reinterpret_cast<const double2 *>(gap + 6 * q);
+            const double2 g23 = *reinterpret_cast<const double2 *>(gap + 6 * q + 2);
+            const double2 g45 = *reinterpret_cast<const double2 *>(gap + 6 * q + 4);
+            double gx = xp ? g01.y : 0.0, gy = yp ? g23.y : 0.0, gz = zp ? g45.y : 0.0;
+            gx = xn ? g01.x : gx;
+            gy = yn ? g23.x : gy;
+            gz = zn ? g45.x : gz;
+            const double lb = gx + (gy + gz);
+            need |= static_cast<unsigned>(__ballot(lb <= bq));
+        }
+    }
+    need &= occ & ~(1u << kHomeVoxel);
+    while (need) {
+        const int v = __builtin_ctz(need);
+        need &= need - 1u;
+        visit(v);
+    }
+
+    // argmin over the W lanes of each query, lexicographic in (distance, enumeration index) like
+    // the sequential strict-< scan it replaces: first the minimum distance (never NaN: a NaN
+    // distance fails every comparison), then the smallest index among the lanes that hold it.
+    m = best;
+    if (W >= 2) m = min_f64(m, dpp_f64<kDppXor1>(m));
+    if (W >= 4) m = min_f64(m, dpp_f64<kDppXor2>(m));
+    if (W >= 8) m = min_f64(m, dpp_f64<kDppHalfMirror>(m));
+    if (W >= 16) m = min_f64(m, dpp_f64<kDppMirror>(m));
+    if (W >= 32) m = min_f64(m, __shfl_xor(m, 16, 64));
+    if (W >= 64) m = min_f64(m, __shfl_xor(m, 32, 64));
+    const unsigned mine = (best == m) ? best_f : 0xFFFFFFFFu;
+    unsigned minf = mine;
+    if (W >= 2) minf = min_u32_xor1(minf);
+    if (W >= 4) minf = min_u32_xor2(minf);
+    if (W >= 8) minf = min_u32_half_mirror(minf);
+    if (W >= 16) minf = min_u32_mirror(minf);
+    if (W >= 32) minf = min(minf, static_cast<unsigned>(__shfl_xor(static_cast<int>(minf), 16, 64)));
+    if (W >= 64) minf = min(minf, static_cast<unsigned>(__shfl_xor(static_cast<int>(minf), 32, 64)));
 
     // The argmin is stored unconditionally; the acceptance test on the unscaled distance
     // (VoxelHashMap.cpp:111) is applied where the pair is consumed (k_gn / the host join).
-    const uint32_t widx = cand[min(best_f, last)];
-    if (active && ci == 0)
-        P.nn_idx[start + qi] = (best_f == 0xFFFFFFFFu) ? -1 : static_cast<int>(widx >> 5);
+    // Enumeration indices are unique, so exactly one lane of a query holds the winner.
+    if (active) {
+        if (minf == 0xFFFFFFFFu) {
+            if (ci == 0) P.nn_idx[start + qi] = -1;
+        } else if (mine == minf) {
+            P.nn_idx[start + qi] = static_cast<int>(best_off >> 5);
+        }
+    }
 }
 
 #ifdef SAGE_NN_TIMING
-__device__ unsigned long long g_nn_phase[8];
+constexpr unsigned kNnTimingSlots = 1u << 17;
+__device__ unsigned long long g_nn_phase[4ull * kNnTimingSlots];   // per chunk: {head, group, lifetime, count}
 #define NN_T(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); tph[i] += _t - tprev; tprev = _t; } while (0)
 #else
 #define NN_T(i) do { } while (0)
@@ -280,43 +347,39 @@ __global__ __launch_bounds__(64 * kNnWaves, SAGE_NN_OCC) void k_nn(NnParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     if (P.check_done && P.st->done) return;
 #ifdef SAGE_NN_TIMING
-    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tph[4] = {0, 0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
     const unsigned long long tstart = tprev;
 #endif
 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));   // wave-uniform
-    // per-wave LDS (words): candidate list | start-mark bitmap | compacted voxel deltas |
-    // the chunk's transformed queries {x, y, z, label} | their home voxels [comp][query]
-    const NnLds L = nn_lds_layout(P.cap, P.chunk);
-    uint32_t *cand = smem + wv * L.wave_words;       // byte offsets of the candidates, enumeration order
+    // per-wave LDS (words): the chunk's transformed queries {x, y, z, label} | their scaled
+    // squared gaps to the six faces of the home cell | their home voxels [comp][query]
+    const NnLds L = nn_lds_layout(P.chunk);
+    uint32_t *wl = smem + wv * L.wave_words;
     // raw buffer resource over the point array (bounds-checked, 32-bit byte offsets)
     const __amdgpu_buffer_rsrc_t pts = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<Point4 *>(P.pts), 0, static_cast<int>(P.pts_bytes), 0x00020000);
-    unsigned long long *marks = reinterpret_cast<unsigned long long *>(cand + L.marks);
-    uint32_t *delta = cand + L.delta;
-    double *spt = reinterpret_cast<double *>(cand + L.spt);
-    int *skey = reinterpret_cast<int *>(cand + L.skey);
+    double *spt = reinterpret_cast<double *>(wl + L.spt);
+    double *gap = reinterpret_cast<double *>(wl + L.gap);
+    int *skey = reinterpret_cast<int *>(wl + L.skey);
 
-    // One wave per chunk of `chunk` consecutive queries (a group never crosses a chunk), four
-    // chunks per workgroup, and many more workgroups than the chip holds at once: the hardware
-    // dispatcher hands the next workgroup to whichever CU frees a slot, which balances the
-    // load.  (Work per query varies 5x across the scene; persistent waves with a static share
-    // of the queries left the kernel waiting on its heaviest wave — 2.5x the mean — and
-    // device-scope ticket counters were 20x slower.)  Workgroup b is dispatched to XCD b % 8
-    // (observed; speed only): XCD x serves the stripes x, x+8, x+16, ... of kStripe consecutive
-    // workgroups' worth of the spatially sorted frame, so each private L2 sees a few compact
-    // regions of the map and every XCD gets the same mix of dense and sparse regions.
+    // One wave per chunk of `chunk` consecutive queries (a group never crosses a chunk) and many
+    // more workgroups than the chip holds at once: the hardware dispatcher hands the next
+    // workgroup to whichever CU frees a slot, which balances the load.  (Work per query varies
+    // several-fold across the scene; persistent waves with a static share of the queries left
+    // the kernel waiting on its heaviest wave, and device-scope ticket counters were 20x slower.)
+    // Workgroup b is dispatched to XCD b % 8 (observed; speed only): XCD x serves the stripes
+    // x, x+8, x+16, ... of kStripe consecutive workgroups' worth of the spatially sorted frame,
+    // so each private L2 sees a few compact regions of the map and every XCD gets the same mix
+    // of dense and sparse regions.
     unsigned long long wave_candidates = 0;   // wave-uniform: sum over this wave's queries of C_q
+    unsigned long long wave_pairs = 0;        // (query, candidate) pairs actually evaluated
     constexpr unsigned kStripe = SAGE_NN_STRIPE / kNnWaves;   // workgroups per stripe
     unsigned cand_slot = 0;
     {
       const unsigned chunk = P.chunk;
-      // one query per wave (small frames): a single load in flight per lane and a list padded to
-      // 64 is faster there (c1: 6 %); with several queries per wave two in flight win (c2: 3 %)
-      const unsigned u6 = (chunk == 1u) ? 1u : static_cast<unsigned>(SAGE_NN_U_BIG);
-      const unsigned nchunks = (static_cast<unsigned>(P.n) + chunk - 1u) / chunk;
       const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
       const unsigned quad = ((j / kStripe) * 8u + xcd) * kStripe + (j % kStripe);
       uint2 *blks = P.blks;
@@ -328,14 +391,14 @@ __global__ __launch_bounds__(64 * kNnWaves, SAGE_NN_OCC) void k_nn(NnParams P) {
       };
       const unsigned c = __builtin_amdgcn_readfirstlane(quad * kNnWaves + wv);
       cand_slot = c;
-      if (c < nchunks) {
+      if (c < P.nchunks) {
         const unsigned q0 = c * chunk;
-        // ---- chunk prologue (was a kernel of its own: one launch + one dependent round trip per
-        // iteration).  Lane (comp, i) = (lane >> log2 chunk, lane & (chunk-1)) owns coordinate
-        // `comp` of query q0 + i: it applies the cumulative pose to the pristine frame point
-        // (TransformPoints, Registration.cpp:103-111,133 — `source` is never rewritten in place),
-        // takes the home voxel index with the reference's fp64 divide + truncation
-        // (VoxelHashMap.cpp:52-54) and parks the transformed point in LDS for the pair lanes.
+        // ---- chunk prologue.  Lane (comp, i) = (lane >> log2 chunk, lane & (chunk-1)) owns
+        // coordinate `comp` of query q0 + i: it applies the cumulative pose to the pristine frame
+        // point (TransformPoints, Registration.cpp:103-111,133 — `source` is never rewritten in
+        // place), takes the home voxel index with the reference's fp64 divide + truncation
+        // (VoxelHashMap.cpp:52-54), measures the distance to the two faces of the home cell on
+        // its axis (the pruning bounds of nn_group) and parks everything in LDS for the pair lanes.
         uint2 ob = load_table(q0);                   // the first query of a chunk is always a head
         const unsigned qi_own = static_cast<unsigned>(lane) & (chunk - 1u);
         const unsigned comp = static_cast<unsigned>(lane) >> P.chunk_log2;
@@ -354,14 +417,27 @@ __global__ __launch_bounds__(64 * kNnWaves, SAGE_NN_OCC) void k_nn(NnParams P) {
                 sv = comp == 0u ? fx : (comp == 1u ? fy : fz);
             }
             // static_cast<int>(p / voxel_size): exact fp64 divide, truncation toward zero
-            key = static_cast<int>(sv / P.voxel_size);
-            double *o = reinterpret_cast<double *>(P.src + q_own);
+            const double vs = P.voxel_size;
+            key = static_cast<int>(sv / vs);
+            // The cell of voxel index k on one axis (truncation toward zero: cell 0 is two voxels
+            // wide): [k vs, (k+1) vs) for k > 0, (-vs, vs) for k = 0, ((k-1) vs, k vs] for k < 0.
+            // Points stored in the voxel below / above the home voxel therefore lie at or beyond
+            // `below_hi` / `above_lo`; the gaps are shortened by an absolute slack that dwarfs the
+            // rounding of the divide, the product and the subtraction (~1e-16 relative).
+            const double below_hi = static_cast<double>(key <= 0 ? key - 1 : key) * vs;
+            const double above_lo = static_cast<double>(key >= 0 ? key + 1 : key) * vs;
+            const double slack = 1e-9 * vs + 1e-13 * fabs(sv);
+            const double glo = fmax((sv - below_hi) - slack, 0.0);
+            const double ghi = fmax((above_lo - sv) - slack, 0.0);
             spt[4u * qi_own + comp] = sv;
             skey[lane] = key;
-            o[comp] = sv;
-            if (comp == 0u) {
-                spt[4u * qi_own + 3u] = fl;
-                o[3] = fl;
+            gap[6u * qi_own + 2u * comp] = (glo * glo) * P.prune_scale;
+            gap[6u * qi_own + 2u * comp + 1u] = (ghi * ghi) * P.prune_scale;
+            if (comp == 0u) spt[4u * qi_own + 3u] = fl;
+            if (P.src) {                              // the queries as searched, for k_gn
+                double *o = reinterpret_cast<double *>(P.src + q_own);
+                o[comp] = sv;
+                if (comp == 0u) o[3] = fl;
             }
         }
         // Group heads: a query whose home voxel differs from its predecessor's (chunks are
@@ -395,83 +471,38 @@ __global__ __launch_bounds__(64 * kNnWaves, SAGE_NN_OCC) void k_nn(NnParams P) {
             p.x = t.x; p.y = t.y; p.z = t.z; p.l = t.w;
         }
         NN_T(0);
-
-        // Enumerate the candidates once, in reference order (x outer, y, z inner, then insertion
-        // order), into LDS: cand[f] = first point of f's voxel + (f - offset of that voxel).
-        // No scalar loop over voxels and no per-candidate search: the occupied voxels are
-        // compacted (ballot + mbcnt) into delta[r] = first point - offset, the position before
-        // each occupied voxel's first candidate is marked in a bitmap (LDS atomic OR), and the
-        // compacted voxel of flat index f is the number of marks below f — a running count of the
-        // earlier 64-bit words (scalar) plus v_mbcnt of f's own word.
-        const unsigned C = rl_u32(ob.x, 27);
-        {
-            const unsigned nxt = dpp_u32<0x130>(ob.x);            // wave_shl:1: offset of voxel v+1
-            const bool occupied = lane < 27 && nxt != ob.x;
-            const unsigned long long occ = __ballot(occupied);
-            const unsigned r = __builtin_amdgcn_mbcnt_hi(
-                static_cast<unsigned>(occ >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(occ), 0u));
-            const unsigned nwords = (C + 63u) >> 6;
-            // entries filled: whole 64-entry words, an even number of them when the pair loop
-            // strides 128 (one query on all 64 lanes); the tail beyond C points at the NaN point
-            const unsigned stepw = max(1u, ((lw == 6 ? u6 : static_cast<unsigned>(lw == 5 ? SAGE_NN_U_BIG : SAGE_NN_U_SMALL)) << lw) >> 6);
-            const unsigned nfill = ((nwords + stepw - 1u) / stepw) * stepw;
-            const uint32_t pad_off = P.pts_bytes - static_cast<uint32_t>(sizeof(Point4));
-            unsigned ln = static_cast<unsigned>(lane);
-            asm volatile("" : "+v"(ln));   // bitmap addresses are cheaper to form than to keep live
-            for (unsigned w = ln; w < nwords; w += 64u) marks[w] = 0ull;
-            if (occupied) {
-                delta[r] = (ob.y - ob.x) << 5;                    // byte offsets of 32-B points
-                if (ob.x) {
-                    const unsigned bpos = ob.x - 1u;
-                    atomicOr(&marks[bpos >> 6], 1ull << (bpos & 63u));
-                }
-            }
-            unsigned below = 0;                                   // marks in the earlier words
-            for (unsigned wb = 0; wb < nfill; wb += 64u) {
-                const unsigned long long mine = (wb + ln < nwords) ? marks[wb + ln] : 0ull;
-                const unsigned nw = min(64u, nfill - wb);
-                for (unsigned i = 0; i < nw; ++i) {
-                    const unsigned lo = rl_u32(static_cast<unsigned>(mine), static_cast<int>(i));
-                    const unsigned hi = rl_u32(static_cast<unsigned>(mine >> 32), static_cast<int>(i));
-                    const unsigned rr = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, below));
-                    const unsigned f = ((wb + i) << 6) + ln;
-                    cand[f] = (f < C) ? delta[rr] + (f << 5) : pad_off;
-                    below += __builtin_popcount(lo) + __builtin_popcount(hi);
-                }
-            }
-        }
-        wave_candidates += static_cast<unsigned long long>(C) * static_cast<unsigned>(len);
-        NN_T(1);
-
+        wave_candidates += static_cast<unsigned long long>(rl_u32(ob.x, 27)) * static_cast<unsigned>(len);
+        unsigned pe = 0;
         switch (lw) {
-            case 6:
-                if (u6 == 1) nn_group<6, 1>(P, pts, cand, lane, start, len, C, p);
-                else nn_group<6, SAGE_NN_U_BIG>(P, pts, cand, lane, start, len, C, p);
-                break;
-            case 5: nn_group<5, SAGE_NN_U_BIG>(P, pts, cand, lane, start, len, C, p); break;
-            case 4: nn_group<4, SAGE_NN_U_SMALL>(P, pts, cand, lane, start, len, C, p); break;
-            case 3: nn_group<3, SAGE_NN_U_SMALL>(P, pts, cand, lane, start, len, C, p); break;
-            case 2: nn_group<2, SAGE_NN_U_SMALL>(P, pts, cand, lane, start, len, C, p); break;
-            default: nn_group<1, SAGE_NN_U_SMALL>(P, pts, cand, lane, start, len, C, p); break;
+            case 6: nn_group<6>(P, pts, lane, start, len, ob, p, gap + 6 * h, pe); break;
+            case 5: nn_group<5>(P, pts, lane, start, len, ob, p, gap + 6 * h, pe); break;
+            case 4: nn_group<4>(P, pts, lane, start, len, ob, p, gap + 6 * h, pe); break;
+            case 3: nn_group<3>(P, pts, lane, start, len, ob, p, gap + 6 * h, pe); break;
+            default: nn_group<2>(P, pts, lane, start, len, ob, p, gap + 6 * h, pe); break;
         }
-        NN_T(2);
+        wave_pairs += static_cast<unsigned long long>(pe) * static_cast<unsigned>(len);
+        NN_T(1);
         ob = ob_next;
         }
       }
     }
 #ifdef SAGE_NN_TIMING
-    if (lane == 0) {
-        for (int i = 0; i < 3; ++i) atomicAdd(&g_nn_phase[i], tph[i]);
-        atomicAdd(&g_nn_phase[3], __builtin_amdgcn_s_memtime() - tstart);
-        atomicAdd(&g_nn_phase[4], 1ull);
-        atomicMax(&g_nn_phase[5], __builtin_amdgcn_s_memtime() - tstart);
+    // private slot per chunk (no contended atomics: they would stall the very loads being timed)
+    if (lane == 0 && cand_slot < kNnTimingSlots) {
+        unsigned long long *t = g_nn_phase + 4ull * cand_slot;
+        t[0] += tph[0];
+        t[1] += tph[1];
+        t[2] += __builtin_amdgcn_s_memtime() - tstart;
+        t[3] += 1ull;
     }
 #endif
     // sum_q C_q for the roofline accounting: one private slot per chunk, summed by the host.  (A
     // single device-scope atomic per wave serialised 8192 updates on one address and set a
     // ~100 us floor under this kernel.)
-    if (P.cand_counter && lane == 0 && wave_candidates)
-        atomicAdd(P.cand_counter + cand_slot, wave_candidates);   // fire-and-forget, private address
+    if (P.cand_counter && lane == 0 && wave_candidates) {
+        atomicAdd(P.cand_counter + 2u * cand_slot, wave_candidates);   // fire-and-forget, private address
+        atomicAdd(P.cand_counter + 2u * cand_slot + 1u, wave_pairs);
+    }
 }
 
 // ------------------------------------------------------------------------------------ WaveLanes
@@ -480,11 +511,6 @@ __global__ __launch_bounds__(64 * kNnWaves, SAGE_NN_OCC) void k_nn(NnParams P) {
 // lanes, evaluated by ONE vector instruction sequence, and read back with v_readlane.  A serial
 // lane spent ~2 us of every iteration in the 21 divisions of the 6x6 LDL^T alone.
 // Must be called with lanes 0..5 active and uniform operands.
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
 struct WaveLanes {
     static __device__ __forceinline__ void divide6(const double (&n)[6], const double (&d)[6],
                                                    double (&q)[6]) {
@@ -867,10 +893,21 @@ extern "C" void sageicp_debug_gn_phases(unsigned long long out[16], int reset) {
 #endif
 #ifdef SAGE_NN_TIMING
 extern "C" void sageicp_debug_nn_phases(unsigned long long out[8], int reset) {
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_phase), sizeof(unsigned long long) * 8);
+    // out: {sum head cycles, sum group cycles, sum wave lifetime, waves, max mean lifetime of a
+    //       chunk slot, slots used, 0, 0}
+    std::vector<unsigned long long> h(4ull * kNnTimingSlots);
+    (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_nn_phase), h.size() * sizeof(unsigned long long));
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    for (unsigned s = 0; s < kNnTimingSlots; ++s) {
+        const unsigned long long *t = &h[4ull * s];
+        if (!t[3]) continue;
+        out[0] += t[0]; out[1] += t[1]; out[2] += t[2]; out[3] += t[3];
+        if (t[2] / t[3] > out[4]) out[4] = t[2] / t[3];
+        ++out[5];
+    }
     if (reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_nn_phase), z, sizeof(z));
+        std::fill(h.begin(), h.end(), 0ull);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_nn_phase), h.data(), h.size() * sizeof(unsigned long long));
     }
 }
 #endif
@@ -889,21 +926,35 @@ __global__ __launch_bounds__(256) void k_scatter_slots(const uint32_t *idx, cons
     if (i < n) table[idx[i]] = vals[i];
 }
 
-// sum of k_nn's per-chunk candidate counters into the loop state (one workgroup; it rides on the
-// state copy the host makes anyway instead of a 1-MB read-back of the counters)
+// sums of k_nn's per-chunk counters {candidates in the neighbourhood, pairs evaluated} into the
+// loop state (one workgroup; it rides on the state copy the host makes anyway instead of a
+// read-back of the counters)
 __global__ __launch_bounds__(1024) void k_sum_candidates(const unsigned long long *c, int n,
                                                          IcpState *st) {
-    __shared__ unsigned long long part[16];
-    unsigned long long v = 0;
-    for (int i = threadIdx.x; i < n; i += 1024) v += c[i];
+    __shared__ unsigned long long part[2][16];
+    unsigned long long v = 0, w = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        v += c[2 * i];
+        w += c[2 * i + 1];
+    }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    for (int off = 32; off > 0; off >>= 1) {
+        v += __shfl_down(v, off, 64);
+        w += __shfl_down(w, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        part[0][threadIdx.x >> 6] = v;
+        part[1][threadIdx.x >> 6] = w;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned long long t = 0;
-        for (int i = 0; i < 16; ++i) t += part[i];
+        unsigned long long t = 0, u = 0;
+        for (int i = 0; i < 16; ++i) {
+            t += part[0][i];
+            u += part[1][i];
+        }
         st->sum_candidates = t;
+        st->sum_pairs = u;
     }
 }
 
@@ -945,7 +996,7 @@ int gn_grid_for(int n) {
 void launch_nn(const NnParams &p, hipStream_t s) {
     if (p.n <= 0) return;
     const int grid = nn_grid_for(p.n, static_cast<int>(p.chunk));
-    const size_t lds = kNnWaves * nn_lds_layout(p.cap, p.chunk).wave_words * sizeof(uint32_t);
+    const size_t lds = kNnWaves * nn_lds_layout(p.chunk).wave_words * sizeof(uint32_t);
     hipLaunchKernelGGL(k_nn, dim3(grid), dim3(64 * kNnWaves), lds, s, p);
 }
 
