@@ -8,19 +8,25 @@ already resident in HBM when the timed region starts.
   N = 1   workload c2: 120,000-pt scan vs 1,000,000-pt semantic voxel map, identity initial guess,
           reference start-up parameters (sigma = 2.0 -> max_corr 6.0, kernel 2/3, sem_th 0.4).
   N > 1   the SAME frame, query-sharded in contiguous blocks over the N ranks (one process per
-          GPU), map replicated, the 17 Gauss-Newton sums all-reduced over RCCL/xGMI each
-          iteration -> strong scaling.  (--workload c4 runs the 500k-vs-10M multi-GPU config.)
+          GPU), map replicated, the 17 Gauss-Newton sums exchanged over xGMI each iteration
+          -> strong scaling.  (--workload c4 runs the 500k-vs-10M multi-GPU config.)
+          `python bench.py --gpus N` launches its own ranks (torch.distributed.run) when it was
+          not started under a launcher.
 
 Prints ONE JSON line on rank 0 (see the task contract), including
-  roofline      NN kernel: algorithmic bytes (456 B/query + 16 B/candidate, SURVEY.md §8d, with
-                the candidate count taken exactly from the kernel) / HIP-event launch duration
-  cpu_baseline  the CPU oracle (a structure-faithful port of the reference path, OpenMP at the
-                fastest thread count of a short sweep) timed on a bounded sample of the same frame,
-                rank 0 at N = 1 only.
+  roofline      the search + accumulation kernel (k_icp): algorithmic bytes (SURVEY.md §8d fused
+                form: 456 B/query + 16 B/candidate + 32 B/correspondence - 8 B/query, candidates
+                counted exactly by the kernel) / HIP-event launch duration, plus what actually
+                bounds it: hbm_frac (counter bytes), valu_frac, useful_inst_frac (profiles/)
+  cpu_baseline  the CPU oracle (a structure-faithful port of the reference path, OpenMP) timed on a
+                bounded sample of the same frame: warm-up, thread sweep, median of 5 at the fastest
+                count, and the 1-thread time; rank 0 at N = 1 only.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -41,15 +47,79 @@ def parse():
                     help="default: cold (c1, c2, c4), dense (c5)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0,
+    ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="CPU time budget of the cpu_baseline sample")
     ap.add_argument("--no-profile-events", action="store_true",
                     help="do not record per-kernel HIP events in the timed region")
     return ap.parse_args()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def cpu_baseline(args, w, wl, prm, scan, iters, fps):
+    """The oracle (structure-faithful CPU port) on the same frame: reproducible protocol."""
+    import oracle                              # the checker / CPU port, timed as a baseline
+    om = oracle.Map(wl["voxel"], 100.0)
+    om.add_points(w["stream"])
+    avail = oracle.num_threads()
+
+    def run(nt, k):
+        t = time.perf_counter()
+        _, ost = om.register_frame(scan, oracle.IDENTITY, prm["max_dist"], prm["kernel"], prm["sem_th"],
+                                   nthreads=nt, max_iter=k)
+        return (time.perf_counter() - t) / max(ost.iterations, 1), ost
+
+    run(min(avail, 32), 2)                                         # page in, spin up the pool
+    t1, _ = run(1, 1)                                              # one thread, one iteration
+    # the port does not scale to every hardware thread of the box (memory-bound hash walks):
+    # sweep a few thread counts (3 iterations each) and keep the fastest as THE baseline
+    sweep = {}
+    for nt in sorted({min(avail, c) for c in (8, 16, 32, 64, 128, avail)}):
+        run(nt, 1)
+        sweep[nt] = run(nt, 3)[0]
+    threads = min(sweep, key=sweep.get)
+    # median of 5 repetitions at that count, K iterations each, within the time budget
+    k = int(max(3, min(iters, args.cpu_seconds / 5.0 / max(sweep[threads], 1e-9))))
+    reps, ost = [], None
+    for _ in range(5):
+        v, ost = run(threads, k)
+        reps.append(v)
+    reps.sort()
+    per_iter = reps[2]
+    cpu_fps = 1.0 / (per_iter * iters)
+    return {"value": round(cpu_fps, 5), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "median of 5 runs of the first %d of %d ICP iterations of the same %s frame "
+                      "(%d queries) on %d OpenMP threads (OMP_PROC_BIND=close, OMP_PLACES=cores) after "
+                      "a warm-up; per-iteration cost is constant, scaled to the %d iterations the "
+                      "frame takes" % (k, iters, args.workload, len(scan), threads, iters),
+            "seconds_per_iteration": round(per_iter, 5),
+            "seconds_per_iteration_runs": [round(v, 5) for v in reps],
+            "seconds_per_iteration_1_thread": round(t1, 4),
+            "frames_per_second_1_thread": round(1.0 / (t1 * iters), 6),
+            "threads_available": avail,
+            "seconds_per_iteration_by_threads": {str(a): round(b, 5) for a, b in sorted(sweep.items())},
+            "sweep_vs_reported": round(sweep[threads] / per_iter, 3),
+            "candidates_per_query": round(ost.sum_candidates_total / max(ost.iterations, 1) / len(scan), 1),
+            "speedup_gpu_over_cpu": round(fps / cpu_fps, 1)}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    # the CPU baseline's OpenMP pool: pinned, one thread per core (read when libgomp starts)
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
     # RCCL prints a version banner on stdout when a communicator is created; the contract is ONE
     # JSON line on stdout, so everything before the final print goes to stderr.
     sys.stdout.flush()
@@ -59,9 +129,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
-                             "--nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
 
     import numpy as np
@@ -121,24 +188,27 @@ def main():
 
     comm = None
     exchange = "none"
+    have_rccl = False
+    use_p2p = False          # this run's choice (a failed exchange disables it inside the library)
 
     def all_agree(flag):
         t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item())
 
+    RCCL_TEXT = "RCCL all-reduce of 20 fp64 sums over %d ranks + solve launch" % world
+
     if use_dist:
-        use_rccl = backend == "nccl" and os.environ.get("SAGEICP_NO_RCCL", "0") != "1"
-        if use_rccl:
+        have_rccl = backend == "nccl" and os.environ.get("SAGEICP_NO_RCCL", "0") != "1"
+        if have_rccl:
             ids = [sage.Comm.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
             comm = sage.Comm(ids[0], rank, world, local_dev)
-            exchange = "RCCL all-reduce of 20 fp64 sums + solve launch"
+            exchange = RCCL_TEXT
         else:
             comm = sage.Comm(None, rank, world, local_dev)
         # Direct exchange over xGMI (HIP IPC): preferred when every rank can set it up, RCCL
         # otherwise (SAGEICP_NO_P2P=1 forces RCCL).
-        p2p = False
         if os.environ.get("SAGEICP_NO_P2P", "0") != "1" and world <= 8:
             try:
                 mine = comm.p2p_export()
@@ -154,12 +224,12 @@ def main():
                 except Exception as e:              # noqa
                     sys.stderr.write("rank %d: p2p connect failed: %s\n" % (rank, e))
                     ok = False
-            p2p = all_agree(ok)
-            if not p2p and comm.p2p_enabled:
+            use_p2p = all_agree(ok)
+            if not use_p2p and comm.p2p_enabled:
                 comm.p2p_enable(False)
-        if p2p:
-            exchange = "direct exchange of 20 fp64 sums over xGMI (HIP IPC), solved in k_gn"
-        elif not use_rccl:
+        if use_p2p:
+            exchange = "direct exchange of 20 fp64 sums over xGMI between %d ranks (HIP IPC), solved in k_fin" % world
+        elif not have_rccl:
             raise SystemExit("no exchange path: RCCL disabled and the direct exchange unavailable")
 
     def step():
@@ -180,8 +250,18 @@ def main():
             sys.stderr.write("rank %d: warm-up failed: %s\n" % (rank, e))
             return False
 
+    def fall_back(why):
+        """every rank leaves the direct exchange for RCCL together"""
+        nonlocal use_p2p, exchange
+        if not have_rccl:
+            raise SystemExit("direct exchange failed and there is no RCCL side to fall back to")
+        if comm.p2p_enabled:
+            comm.p2p_enable(False)
+        use_p2p = False
+        exchange = RCCL_TEXT + " (" + why + ")"
+
     fence()          # every rank has its map and frame in HBM before the first exchange is waited for
-    if use_dist and comm.p2p_enabled and backend == "nccl" and os.environ.get("SAGEICP_NO_RCCL", "0") != "1":
+    if use_dist and use_p2p and have_rccl:
         # cross-check before trusting the direct exchange on this node: the same frame through
         # RCCL and through the mapped blocks must give the same pose (the summation order over
         # the ranks differs, nothing else)
@@ -195,20 +275,16 @@ def main():
             sys.stderr.write("rank %d: exchange cross-check failed: %s\n" % (rank, e))
             same = False
         if not all_agree(same):
-            comm.p2p_enable(False)
-            exchange = "RCCL all-reduce of 20 fp64 sums + solve launch (direct exchange failed its cross-check)"
+            fall_back("direct exchange failed its cross-check")
     ok = warm()
-    if use_dist and comm.p2p_enabled and not all_agree(ok):
-        # the direct exchange did not work on this node: every rank falls back to RCCL together
-        if not (backend == "nccl" and os.environ.get("SAGEICP_NO_RCCL", "0") != "1"):
-            raise SystemExit("direct exchange failed and there is no RCCL side to fall back to")
-        comm.p2p_enable(False)
-        exchange = "RCCL all-reduce of 20 fp64 sums + solve launch (direct exchange failed)"
+    if use_dist and use_p2p and not all_agree(ok):
+        fall_back("direct exchange failed")
         ok = warm()
     if not ok:
         raise SystemExit("warm-up failed")
-    # level 1: HIP events around k_nn in one iteration out of 8 of the timed region (bracketing
-    # every launch costs 8 % of the frame rate this line reports)
+
+    # level 1: HIP events around k_icp in one iteration out of 8 of the timed region (bracketing
+    # every launch costs several % of the frame rate this line reports)
     def timed():
         """EXACTLY args.steps steps between two fences; None if a step failed on this rank"""
         sage.set_profiling(0 if args.no_profile_events else 1)
@@ -218,8 +294,7 @@ def main():
         try:
             for _ in range(args.steps):
                 pose, st = step()
-                stats.append((st.iterations, st.us_nn, st.nn_launches, st.sum_candidates, st.us_gn,
-                              st.us_fin, st.n_corr_first, st.n_corr_last, st.converged))
+                stats.append(st)
         except sage.SageIcpError as e:
             sys.stderr.write("rank %d: timed step failed: %s\n" % (rank, e))
             good = False
@@ -231,10 +306,9 @@ def main():
     res = timed()
     if use_dist and not all_agree(res is not None):
         # an exchange failed in the timed region: every rank switches to RCCL and times again
-        if not (comm.p2p_enabled and backend == "nccl" and os.environ.get("SAGEICP_NO_RCCL", "0") != "1"):
+        if not use_p2p:
             raise SystemExit("a timed step failed")
-        comm.p2p_enable(False)
-        exchange = "RCCL all-reduce of 20 fp64 sums + solve launch (direct exchange failed)"
+        fall_back("direct exchange failed")
         if not all_agree(warm()):
             raise SystemExit("warm-up failed after the fallback to RCCL")
         res = timed()
@@ -254,75 +328,65 @@ def main():
             dist.destroy_process_group()
         return
 
-    iters = stats[-1][0]
+    # the host-buffer entry the C++ shim calls (frame uploaded inside the call), not the headline
+    host_entry_ms = None
+    if world == 1:
+        sage.register_frame(scan, vmap, sage.IDENTITY, prm["max_dist"], prm["kernel"], prm["sem_th"])
+        t0 = time.perf_counter()
+        k_host = max(3, min(args.steps, 10))
+        for _ in range(k_host):
+            sage.register_frame(scan, vmap, sage.IDENTITY, prm["max_dist"], prm["kernel"], prm["sem_th"])
+        host_entry_ms = 1e3 * (time.perf_counter() - t0) / k_host
+
+    last = stats[-1]
+    iters = last.iterations
     n_local = hi - lo
-    us_nn = sum(s[1] for s in stats)          # the timed sample of k_nn launches
-    launches = sum(s[2] for s in stats)
-    all_launches = sum(s[0] for s in stats)   # every k_nn launch of the timed region
-    cands = sum(s[3] for s in stats)          # sum of C_q over ALL launches (counted by the kernel)
+    us_nn = sum(s.us_nn for s in stats)             # the timed sample of k_icp launches
+    launches = sum(s.nn_launches for s in stats)
+    all_launches = sum(s.iterations for s in stats)  # every k_icp launch of the timed region
+    cands = sum(s.sum_candidates for s in stats)     # sum of C_q over ALL launches (counted by the kernel)
+    pairs = sum(s.pairs_evaluated for s in stats)
     roofline = None
     if launches:
-        bytes_per_launch = 456.0 * n_local + 16.0 * cands / all_launches   # B_nn, mean per launch
+        n_corr = 0.5 * (last.n_corr_first + last.n_corr_last) * n_local / max(len(scan), 1)
+        # SURVEY 8d, fused form: B_nn + B_gn - 8 N_q = 448 N_q + 16 sum C_q + 32 N_c
+        bytes_per_launch = 448.0 * n_local + 16.0 * cands / all_launches + 32.0 * n_corr
         avg_us = us_nn / launches
         achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9       # GB/s
-        bytes_nn = bytes_per_launch * launches
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "nn_traffic.json")
-        if os.path.exists(tpath) and args.workload == "c2" and world == 1 and args.scale == 1.0:
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": "k_nn", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": traffic,
-                    "algorithmic_bytes_per_launch": round(bytes_nn / launches),
+        roofline = {"bound": "hbm", "kernel": "k_icp (correspondence search + Gauss-Newton sums)",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": round(bytes_per_launch),
                     "avg_launch_us": round(avg_us, 2), "launches_timed": launches,
-                    "launches": all_launches,
-                    "queries_per_launch": n_local,
+                    "launches": all_launches, "queries_per_launch": n_local,
+                    "lanes_per_query": last.lanes_per_query,
                     "candidates_per_query": round(cands / all_launches / max(n_local, 1), 1),
-                    "note": "achieved = algorithmic bytes (SURVEY 8d: 456 B/query + 16 B/candidate) / "
-                            "mean k_nn duration (HIP events on the launch stream, 1 launch in 8 of "
-                            "the timed region); queries of a group share one candidate list and "
-                            "the map stays in L2 / Infinity Cache, so `traffic` (HBM bytes, "
-                            "rocprofv3 FETCH_SIZE) is several times smaller and frac can exceed 1",
-                    }
+                    "pairs_evaluated_frac": round(pairs / max(cands, 1), 4),
+                    "note": "achieved = algorithmic bytes (SURVEY 8d fused form: 448 B/query + 16 B/"
+                            "candidate + 32 B/correspondence) / mean k_icp duration (HIP events on the "
+                            "launch stream, 1 launch in 8 of the timed region).  The kernel skips, by "
+                            "an exact cell lower bound, most of the candidates the byte model charges "
+                            "(pairs_evaluated_frac) and the map stays in L2 / Infinity Cache, so this "
+                            "is an effective rate that can exceed the HBM peak; what bounds the kernel "
+                            "is in hbm_frac / valu_frac / useful_inst_frac (rocprofv3 counters of the "
+                            "same command, profiles/)"}
+        cpath = os.path.join(ROOT, "profiles", "icp_counters.json")
+        if os.path.exists(cpath) and args.workload == "c2" and world == 1 and args.scale == 1.0:
+            try:
+                c = json.load(open(cpath))
+                roofline["traffic"] = c.get("hbm_bytes_per_launch")
+                if roofline["traffic"]:
+                    roofline["hbm_frac"] = round(roofline["traffic"] / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                for key in ("valu_frac", "useful_inst_frac", "lane_utilization", "counters_source"):
+                    if key in c:
+                        roofline[key] = c[key]
+            except Exception:
+                pass
 
     fps = args.steps / elapsed
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        import oracle                              # the checker / CPU port, timed as a baseline
-        om = oracle.Map(wl["voxel"], 100.0)
-        om.add_points(w["stream"])
-        # the port does not scale to every hardware thread of the box (memory-bound hash walks):
-        # time two iterations at a few thread counts and keep the fastest as THE baseline
-        avail = oracle.num_threads()
-        sweep = {}
-        om.register_frame(scan, oracle.IDENTITY, prm["max_dist"], prm["kernel"], prm["sem_th"],
-                          max_iter=1)                       # page in
-        for nt in sorted({min(avail, c) for c in (8, 16, 32, 64, 128, avail)}):
-            t = time.perf_counter()
-            om.register_frame(scan, oracle.IDENTITY, prm["max_dist"], prm["kernel"], prm["sem_th"],
-                              nthreads=nt, max_iter=2)
-            sweep[nt] = (time.perf_counter() - t) / 2
-        threads = min(sweep, key=sweep.get)
-        per_iter = sweep[threads]
-        cap = int(max(3, min(iters, args.cpu_seconds / max(per_iter, 1e-9))))
-        t = time.perf_counter()
-        _, ost = om.register_frame(scan, oracle.IDENTITY, prm["max_dist"], prm["kernel"],
-                                   prm["sem_th"], nthreads=threads, max_iter=cap)
-        dt = time.perf_counter() - t
-        per_iter = dt / ost.iterations
-        cpu_fps = 1.0 / (per_iter * iters)
-        cpu = {"value": round(cpu_fps, 5), "unit": "frames/s", "cores": threads, "kind": "port",
-               "sample": "first %d of %d ICP iterations of the same %s frame (%d queries), "
-                         "%.1f s of CPU work on %d OpenMP threads; per-iteration cost is constant, "
-                         "scaled to the %d iterations the frame takes"
-                         % (ost.iterations, iters, args.workload, len(scan), dt, threads, iters),
-               "seconds_per_iteration": round(per_iter, 5),
-               "threads_available": avail,
-               "seconds_per_iteration_by_threads": {str(k): round(v, 5) for k, v in sorted(sweep.items())},
-               "speedup_gpu_over_cpu": round(fps / cpu_fps, 1)}
+        cpu = cpu_baseline(args, w, wl, prm, scan, iters, fps)
 
     err = None
     try:
@@ -343,6 +407,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "ms_per_step_host_entry": None if host_entry_ms is None else round(host_entry_ms, 4),
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -355,10 +420,11 @@ def main():
                                   prm["max_dist"], prm["kernel"], prm["sem_th"]),
                    "parallelism": "query-sharded x%d, map replicated, %s" % (world, exchange)
                                   if use_dist else "single GPU",
+                   "ranks": world,
                    "scan_points": len(scan), "map_points": vmap.size(),
                    "map_voxels": vmap.num_voxels(), "iterations_per_frame": iters,
-                   "correspondences_first_last": [stats[-1][6], stats[-1][7]],
-                   "converged": bool(stats[-1][8]),
+                   "correspondences_first_last": [last.n_corr_first, last.n_corr_last],
+                   "converged": bool(last.converged), "resorts_per_frame": last.resorts,
                    "pose_error_vs_planted": err, "setup_seconds": round(t_gen, 1)},
         "roofline": roofline,
         "cpu_baseline": cpu,

@@ -51,17 +51,19 @@ typedef struct sageicp_stats {
     double us_upload;           /* frame H2D + lazy map-mirror refresh inside the call */
     /* device time per kernel summed over the executed iterations (HIP events on the launch
      * stream); filled only when profiling is enabled with sageicp_set_profiling(). */
-    double us_group;            /* always 0 (the grouping pass is part of k_nn) */
-    double us_nn;               /* k_nn: pose apply + grouping + the correspondence search */
-    double us_gn;
-    double us_fin;
-    uint32_t nn_launches;       /* k_nn launches that were timed (us_nn / nn_launches = mean duration) */
+    double us_group;            /* always 0 */
+    double us_nn;               /* k_icp: pose apply + correspondence search + Gauss-Newton sums */
+    double us_gn;               /* always 0 (the accumulation is part of k_icp) */
+    double us_fin;              /* k_fin: reduction of the partials, solve, pose update */
+    uint32_t nn_launches;       /* k_icp launches that were timed (us_nn / nn_launches = mean duration) */
     uint32_t resorts;           /* re-sorts of the frame after the pose drifted (first sort excluded) */
     uint64_t sum_candidates;    /* sum over iterations and queries of C_q: map points stored in the
                                  * <=27 existing neighbour voxels of each query (this rank) */
     uint32_t n_corr_hist[64];   /* accepted correspondences of the first 64 iterations */
     uint64_t pairs_evaluated;   /* (query, map point) pairs the search actually evaluated, all
                                  * iterations: sum_candidates minus what the cell lower bound pruned */
+    uint32_t lanes_per_query;   /* lanes that shared one query in the search kernel (1..16) */
+    uint32_t reserved_;
 } sageicp_stats;
 
 /* ---- library ------------------------------------------------------------------------ */
@@ -209,6 +211,19 @@ int sageicp_pipeline_reinitialize(sageicp_pipeline *p);          /* pipeline/sag
 uint64_t sageicp_pipeline_num_poses(const sageicp_pipeline *p);  /* poses().size() */
 int sageicp_pipeline_pose(const sageicp_pipeline *p, uint64_t index, double pose_out[7]);
 const sageicp_map *sageicp_pipeline_local_map(const sageicp_pipeline *p);   /* LocalMap() */
+
+/* ---- KITTI trajectory metrics: sage_icp::metrics (metrics/Metrics.hpp:33-37) ----------------------
+ * Host-only (the reference's are CPU code too).  Poses are 4x4 homogeneous matrices, ROW-major
+ * (a KITTI poses.txt row padded with 0 0 0 1), n of them, 16 doubles each.
+ * sageicp_metrics_seq_error: SeqError, Metrics.cpp:140-155 — KITTI devkit relative error over
+ *   segments of 100..800 m starting every 10th frame: (translation %, rotation deg/100 m with
+ *   the reference's 180/3.14).  NaN when no segment is long enough, as in the reference.
+ * sageicp_metrics_absolute_trajectory_error: AbsoluteTrajectoryError, Metrics.cpp:157-191 — RMSE
+ *   of the rotation angle [rad] and of the translation [m] after a rigid Umeyama alignment. */
+int sageicp_metrics_seq_error(const double *poses_gt, const double *poses_result, uint64_t n,
+                              float *avg_trans_error, float *avg_rot_error);
+int sageicp_metrics_absolute_trajectory_error(const double *poses_gt, const double *poses_result,
+                                              uint64_t n, float *ate_rot, float *ate_trans);
 
 #ifdef __cplusplus
 }

@@ -59,6 +59,8 @@ class Stats(C.Structure):
         ("sum_candidates", C.c_uint64),
         ("n_corr_hist", C.c_uint32 * 64),
         ("pairs_evaluated", C.c_uint64),
+        ("lanes_per_query", C.c_uint32),
+        ("reserved_", C.c_uint32),
     ]
 
 
@@ -161,6 +163,9 @@ _SIGNATURES = [
     ("sageicp_pipeline_num_poses", C.c_uint64, [C.c_void_p]),
     ("sageicp_pipeline_pose", C.c_int, [C.c_void_p, C.c_uint64, _dp]),
     ("sageicp_pipeline_local_map", C.c_void_p, [C.c_void_p]),
+    ("sageicp_metrics_seq_error", C.c_int, [_dp, _dp, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    ("sageicp_metrics_absolute_trajectory_error", C.c_int,
+     [_dp, _dp, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 ]
 
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
@@ -469,3 +474,30 @@ def voxel_downsample(frame, voxel_labels, voxel_size, vox_scale, device=0):
     _check(lib().sageicp_voxel_downsample(pp, n, len(voxel_labels), counts, labels, sizes, vox_scale,
                                           out.ctypes.data_as(_dp), C.byref(k), device))
     return out[:k.value].copy()
+
+
+def _poses44(p):
+    a = np.ascontiguousarray(p, dtype=np.float64).reshape(-1, 4, 4)
+    return a, a.ctypes.data_as(_dp)
+
+
+def seq_error(poses_gt, poses_result):
+    """sage_icp::metrics::SeqError (metrics/Metrics.cpp:140-155): (avg translation error %,
+    avg rotation error deg/100 m) over the KITTI devkit segments; poses are (n, 4, 4)"""
+    g, gp = _poses44(poses_gt)
+    r, rp = _poses44(poses_result)
+    assert g.shape == r.shape
+    t, o = C.c_float(0), C.c_float(0)
+    _check(lib().sageicp_metrics_seq_error(gp, rp, g.shape[0], C.byref(t), C.byref(o)))
+    return t.value, o.value
+
+
+def absolute_trajectory_error(poses_gt, poses_result):
+    """sage_icp::metrics::AbsoluteTrajectoryError (metrics/Metrics.cpp:157-191): (ATE rotation
+    [rad], ATE translation [m]) after a rigid Umeyama alignment; poses are (n, 4, 4)"""
+    g, gp = _poses44(poses_gt)
+    r, rp = _poses44(poses_result)
+    assert g.shape == r.shape
+    a, b = C.c_float(0), C.c_float(0)
+    _check(lib().sageicp_metrics_absolute_trajectory_error(gp, rp, g.shape[0], C.byref(a), C.byref(b)))
+    return a.value, b.value

@@ -30,6 +30,7 @@
 #include "host_map.hpp"
 #include "kernels.h"
 #include "map_update.h"
+#include "metrics.hpp"
 #include "pipeline.hpp"
 #include "se3_math.h"
 #include "sageicp_types.h"
@@ -46,30 +47,18 @@ static int env_int(const char *name, int dflt) {
     const char *v = std::getenv(name);
     return v ? std::atoi(v) : dflt;
 }
-// Queries per k_nn wave (= the cap on a group of same-voxel queries), a power of two <= 16.
-// Measured on MI355X: 4 is best once the frame fills the chip several times over (c2: 80 us
-// against 83 / 99 us for 2 / 1); smaller frames are bound by the dependent chain of a single
-// wave, and shorter chunks mean more, shorter waves (a 30k-query shard: 36.8 us per iteration
-// with 2 against 38.4 / 40.3 with 4 / 1; 10k-24k frames: 2 and 1 within 2 %).
-// SAGEICP_GROUP_MAX / SAGEICP_NN_CHUNK override both for experiments.
-struct NnShape {
-    unsigned chunk, chunk_log2, cap_heads;
-};
-static NnShape nn_shape(uint64_t n) {
-    int cap = env_int("SAGEICP_GROUP_MAX", 0);
-    if (cap <= 0) cap = n <= 65536 ? 2 : 4;
-    int c = 1;
-    while (c * 2 <= cap && c < 16) c *= 2;      // three lanes per query in k_nn's prologue
-    cap = c;
-    int chunk = cap;
-    const int want = env_int("SAGEICP_NN_CHUNK", cap);
-    while (chunk * 2 <= want && chunk < 16) chunk *= 2;
-    NnShape s{static_cast<unsigned>(chunk), 0u, 0u};
-    while ((1u << s.chunk_log2) < s.chunk) ++s.chunk_log2;
-    for (int i = 0; i < chunk; i += cap) s.cap_heads |= 1u << i;
-    return s;
+// Lanes per query in k_icp (log2).  One lane per query needs the fewest instructions per query
+// but gives a frame of n points only n / 64 waves with long dependent chains; small frames and
+// shards spread each query over more lanes.  Thresholds measured on MI355X (profiles/README.md);
+// SAGEICP_LW overrides for experiments.
+static int icp_lw(uint64_t n) {
+    const int e = env_int("SAGEICP_LW", -1);
+    if (e >= 0) return e > 4 ? 4 : e;
+    if (n >= 300000) return 1;
+    if (n >= 50000) return 2;
+    if (n >= 10000) return 3;
+    return 4;
 }
-
 
 static int fail(int code, const std::string &msg) {
     g_err = msg;
@@ -100,11 +89,12 @@ struct Scratch {
     // Morton re-ordering of the frame (sort.hip)
     Point4 *d_sorted = nullptr; uint32_t *d_keys = nullptr; uint32_t *d_vals = nullptr;
     void *d_sort_temp = nullptr; size_t sort_cap = 0; size_t sort_temp_bytes_ = 0;
-    // per-iteration work buffers: transformed queries, cached probe-table rows and their keys
-    Point4 *d_src = nullptr; uint2 *d_blks = nullptr;
-    int4 *d_tabkey = nullptr;
-    double *d_partials = nullptr;
-    unsigned long long *d_cand = nullptr;      // per-chunk counters of k_nn [2 x sort_cap]
+    // per-call work buffers: the queries' cached neighbourhood rows, the workgroup partials
+    uint32_t *d_rows = nullptr;
+    uint4 *d_prev = nullptr;       // every query's record of the previous iteration (kernels.h)
+    uint32_t *d_work = nullptr;    // map points every query looked at last iteration, pristine order
+    double *d_partials = nullptr; size_t partials_cap = 0;
+    unsigned long long *d_cand = nullptr;      // per-wave counters of k_icp [2 x sort_cap]
     IcpState *d_state = nullptr;
     IcpState *h_state = nullptr;   // pinned
     IcpProgress *h_prog = nullptr; // pinned + host-mapped: written by the device every iteration
@@ -120,7 +110,6 @@ struct Scratch {
         device = dev;
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        HIPCHK(hipMalloc(&d_partials, sizeof(double) * kMaxGnBlocks * kNumSums));
         HIPCHK(hipMalloc(&d_state, sizeof(IcpState)));
 
         HIPCHK(hipHostMalloc(&h_state, sizeof(IcpState), hipHostMallocDefault));
@@ -161,17 +150,16 @@ struct Scratch {
         if (d_keys) HIPCHK(hipFree(d_keys));
         if (d_vals) HIPCHK(hipFree(d_vals));
         if (d_sort_temp) HIPCHK(hipFree(d_sort_temp));
-        if (d_src) HIPCHK(hipFree(d_src));
-        if (d_blks) HIPCHK(hipFree(d_blks));
-        if (d_tabkey) HIPCHK(hipFree(d_tabkey));
-        d_blks = nullptr; d_tabkey = nullptr;
+        if (d_rows) HIPCHK(hipFree(d_rows));
+        if (d_prev) HIPCHK(hipFree(d_prev));
+        if (d_work) HIPCHK(hipFree(d_work));
+        d_rows = nullptr; d_prev = nullptr; d_work = nullptr;
         d_sorted = nullptr; d_keys = d_vals = nullptr; d_sort_temp = nullptr; sort_cap = 0;
-        d_src = nullptr;
         const size_t cap = n + n / 4 + 1024;
         HIPCHK(hipMalloc(&d_sorted, cap * sizeof(Point4)));
-        HIPCHK(hipMalloc(&d_src, cap * sizeof(Point4)));
-        HIPCHK(hipMalloc(&d_blks, cap * 32 * sizeof(uint2)));
-        HIPCHK(hipMalloc(&d_tabkey, cap * sizeof(int4)));
+        HIPCHK(hipMalloc(&d_rows, cap * kRowWords * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&d_prev, cap * sizeof(uint4)));
+        HIPCHK(hipMalloc(&d_work, cap * sizeof(uint32_t)));
         if (d_cand) HIPCHK(hipFree(d_cand));
         d_cand = nullptr;
         HIPCHK(hipMalloc(&d_cand, 2 * cap * sizeof(unsigned long long)));
@@ -180,6 +168,15 @@ struct Scratch {
         sort_temp_bytes_ = sort_temp_bytes(static_cast<int>(cap));
         HIPCHK(hipMalloc(&d_sort_temp, sort_temp_bytes_));
         sort_cap = cap;
+        return SAGEICP_OK;
+    }
+    int reserve_partials(size_t blocks) {
+        if (blocks <= partials_cap) return SAGEICP_OK;
+        if (d_partials) HIPCHK(hipFree(d_partials));
+        d_partials = nullptr; partials_cap = 0;
+        const size_t cap = blocks + blocks / 4 + 256;
+        HIPCHK(hipMalloc(&d_partials, cap * kNumSums * sizeof(double)));
+        partials_cap = cap;
         return SAGEICP_OK;
     }
     int reserve_events(size_t iterations) {
@@ -203,9 +200,9 @@ struct Scratch {
         if (d_keys) (void)hipFree(d_keys);
         if (d_vals) (void)hipFree(d_vals);
         if (d_sort_temp) (void)hipFree(d_sort_temp);
-        if (d_src) (void)hipFree(d_src);
-        if (d_blks) (void)hipFree(d_blks);
-        if (d_tabkey) (void)hipFree(d_tabkey);
+        if (d_rows) (void)hipFree(d_rows);
+        if (d_prev) (void)hipFree(d_prev);
+        if (d_work) (void)hipFree(d_work);
         if (d_partials) (void)hipFree(d_partials);
         if (d_state) (void)hipFree(d_state);
         if (d_cand) (void)hipFree(d_cand);
@@ -417,6 +414,8 @@ struct sageicp_comm {
     int rank = 0, nranks = 1, device = 0;
     // direct exchange of the sums over xGMI (P2pBlock, sageicp_types.h)
     bool p2p = false;
+    bool poisoned = false;               // an exchange timed out: the ranks' exchange counters may
+                                         // differ, so the blocks must not be used again
     P2pBlock *my_block = nullptr;        // fine-grained device memory, exported through HIP IPC
     P2pBlock *blocks[kMaxRanks] = {};    // every rank's block as mapped here (blocks[rank] == my_block)
     unsigned long long *d_exchanges = nullptr;
@@ -782,54 +781,68 @@ void fill_state(IcpState *st, const double init[7]) {
     identity_pose(st->T_icp);
 }
 
-// k_nn's arguments for a search of `n` queries against the HBM copy of `m`
-NnParams nn_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, double sem_th) {
+// largest r2 with sqrt(r2) < max_dist: the acceptance test (nn - p).norm() < max_dist
+// (VoxelHashMap.cpp:111) without a device square root, exact for the IEEE sqrt the CPU evaluates
+double accept_threshold(double max_dist) {
+    if (!(max_dist > 0.0)) return -1.0;                       // nothing passes (also NaN)
+    double x = max_dist * max_dist;
+    if (std::isinf(x)) x = std::numeric_limits<double>::max();
+    while (x > 0.0 && !(std::sqrt(x) < max_dist)) x = std::nextafter(x, 0.0);
+    for (;;) {
+        const double up = std::nextafter(x, std::numeric_limits<double>::infinity());
+        if (std::isinf(up) || !(std::sqrt(up) < max_dist)) break;
+        x = up;
+    }
+    return std::sqrt(x) < max_dist ? x : -1.0;
+}
+
+// k_icp's arguments for a search of `n` queries against the HBM copy of `m`
+IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, double sem_th, int lw) {
     const Scratch &sc = m->sc;
-    const NnShape shape = nn_shape(n);
-    NnParams np{};
-    np.frame = d_queries;
-    np.src = nullptr;
-    np.n = static_cast<int>(n);
-    np.st = sc.d_state;
-    np.check_done = 0;
-    np.apply_pose = 0;
-    np.voxel_size = m->host.voxel_size;
-    np.chunk = shape.chunk;
-    np.chunk_log2 = shape.chunk_log2;
-    np.cap_heads = shape.cap_heads;
-    np.nchunks = static_cast<unsigned>((n + shape.chunk - 1) / shape.chunk);
-    np.tabkey = sc.d_tabkey;
-    np.blks = sc.d_blks;
-    np.table = m->d_table;
-    np.mask = static_cast<uint32_t>(m->d_table_cap - 1);
-    np.pts = m->d_pts;
-    np.pts_bytes = static_cast<uint32_t>((m->d_blocks_cap * m->host.cap + 1) * sizeof(Point4));
-    np.cap = m->host.cap;
-    np.sem_th = sem_th;
-    np.dist_init = DBL_MAX;
+    IcpParams ip{};
+    ip.frame = d_queries;
+    ip.n = static_cast<int>(n);
+    ip.st = sc.d_state;
+    ip.check_done = 0;
+    ip.apply_pose = 0;
+    ip.voxel_size = m->host.voxel_size;
+    ip.rows = sc.d_rows;
+    ip.table = m->d_table;
+    ip.mask = static_cast<uint32_t>(m->d_table_cap - 1);
+    ip.pts = m->d_pts;
+    ip.pts_bytes = static_cast<uint32_t>((m->d_blocks_cap * m->host.cap + 1) * sizeof(Point4));
+    ip.cap_bytes = static_cast<uint32_t>(m->host.cap * sizeof(Point4));
+    ip.sem_th = sem_th;
+    ip.dist_init = DBL_MAX;
     // scaled distance = d2 * sem_th for matching labels, d2 otherwise: >= min(sem_th, 1) * d2.
     // A negative or NaN sem_th gives no usable bound: every occupied voxel is visited.
     const bool prune = sem_th >= 0.0 && env_int("SAGEICP_NO_PRUNE", 0) == 0;
-    np.prune_scale = prune ? std::min(sem_th, 1.0) * (1.0 - 1e-9) : 0.0;
-    np.keep_all = prune ? 0u : 0x7FFFFFFu;
-    np.nn_idx = sc.d_nn;
-    np.cand_counter = nullptr;
-    return np;
+    ip.prune_scale = prune ? std::min(sem_th, 1.0) * (1.0 - 1e-9) : 0.0;
+    ip.keep_all = prune ? 0u : 0x7FFFFFFu;
+    ip.nn_idx = sc.d_nn;
+    ip.kernel = 0.0;
+    ip.accept_r2 = -1.0;
+    ip.nn_prev = sc.d_prev;
+    ip.partials = sc.d_partials;
+    ip.counters = nullptr;
+    const uint64_t qw = 64u >> lw;
+    ip.nwaves = static_cast<unsigned>((n + qw - 1) / qw);
+    return ip;
 }
 
-// The ICP loop of Registration.cpp:127-138 as a stream of launches.
+// The ICP loop of Registration.cpp:127-138 as a stream of launches: k_icp (search + accumulation)
+// and k_fin (reduce, solve, compose, test) per iteration.
 int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const double init[7],
             double max_dist, double kernel, double sem_th, sageicp_comm *comm, double out[7],
             sageicp_stats *stats, double us_upload, double t_begin) {
     Scratch &sc = m->sc;
     hipStream_t s = sc.stream;
     if (n > kMaxQueries) return fail(SAGEICP_ERR_INVALID, "frame too large (2^26 points max)");
-    int rc = sc.reserve_nn(n);
-    if (rc) return rc;
+    int rc;
     const bool prof = g_profiling != 0;
     const bool prof2 = g_profiling >= 2;
     // Single GPU: iterations are enqueued a few ahead of the GPU, which reports its progress
-    // through a host-mapped word (no stream synchronisation inside the loop).  With a
+    // through a host-mapped word (no stream synchronisation inside the loop).  With an RCCL
     // communicator every rank must enqueue the same number of all-reduces, so the loop advances
     // in fixed chunks (4, 8, 16, 16, ...) with one synchronisation per chunk instead.
     const bool p2p = comm && comm->p2p;
@@ -841,26 +854,42 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
 
     fill_state(sc.h_state, init);
     if (polled) {
-        sc.h_prog->word = 0;
+        std::memset(sc.h_prog, 0, sizeof(IcpProgress));
         sc.h_state->progress = sc.d_prog;
     }
     HIPCHK(hipMemcpyAsync(sc.d_state, sc.h_state, sizeof(IcpState), hipMemcpyHostToDevice, s));
 
-    // Spatial re-ordering of the frame: the loop runs on a copy sorted by map-frame voxel under
-    // the current pose, so that consecutive queries share home voxels (k_nn groups them).  The
-    // pose of a cold start travels metres; once it has carried the points ~0.1 voxel away from
-    // where they were sorted, the runs fall apart (c2: 1.9 -> 3.1 groups per chunk of 4), so the
-    // copy is re-sorted from the pristine frame at the next host check point (~60 us).
+    const int lw = icp_lw(n);
+    const int blocks = n ? icp_blocks_for(static_cast<int>(n), lw) : 1;
     if ((rc = sc.reserve_sort(n))) return rc;
+    if ((rc = sc.reserve_partials(static_cast<size_t>(blocks)))) return rc;
+    IcpParams ip = icp_params(m, sc.d_sorted, n, sem_th, lw);
+    ip.check_done = 1;
+    ip.apply_pose = 1;
+    ip.kernel = kernel;
+    ip.accept_r2 = accept_threshold(max_dist);
+    ip.counters = stats ? sc.d_cand : nullptr;
+    if (stats) HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * 2 * (ip.nwaves + 1), s));
+
+    // Spatial re-ordering of the frame: the loop runs on a copy sorted by map-frame voxel under
+    // the current pose, so that the queries of a wave share home voxels and neighbouring waves
+    // touch neighbouring voxel blocks (L1 / L2 hits, similar work per lane).  Every query's
+    // neighbourhood row is (re)built for the new order; inside the loop a row is redone only when
+    // its query crosses a voxel face.  The pose of a cold start travels metres; once it has
+    // carried the points half a voxel away from where they were sorted the order has decayed, and
+    // the copy is re-sorted from the pristine frame at the next check point.
     const Point4 *d_pristine = d_frame;
     double T_sorted[7];
     for (int i = 0; i < 7; ++i) T_sorted[i] = init[i];
-    auto sort_now = [&]() -> int {
+    // first: no iteration has run yet (no work estimate, nothing to carry over)
+    auto sort_now = [&](bool first) -> int {
+        if (first) HIPCHK(hipMemsetAsync(sc.d_work, 0, n * sizeof(uint32_t), s));
         HIPCHK(sort_frame(d_pristine, sc.d_sorted, static_cast<int>(n), sc.d_state, true,
                           m->host.voxel_size, sc.d_keys, sc.d_vals, sc.d_sort_temp,
-                          sc.sort_temp_bytes_, s));
-        // no cached probe-table row is valid for a new order (0x7F7F7F7F is not a reachable voxel index)
-        HIPCHK(hipMemsetAsync(sc.d_tabkey, 0x7F, (n + 1) * sizeof(int4), s));
+                          sc.sort_temp_bytes_, sc.d_work, first ? nullptr : sc.d_prev, s));
+        launch_rows(ip, s);
+        // the records of the last iteration were indexed by the old order
+        HIPCHK(hipMemsetAsync(sc.d_prev, 0xFF, n * sizeof(uint4), s));
         return SAGEICP_OK;
     };
     // displacement bound of a point within the map range between two poses
@@ -875,95 +904,94 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     // the loop: small frames keep their first order)
     const double resort_drift = 0.01 * env_int("SAGEICP_RESORT_PCT", 50) * m->host.voxel_size;
     const bool resort_on = n >= static_cast<uint64_t>(env_int("SAGEICP_RESORT_MIN_N", 40000));
-    if (n > 0) {
-        if ((rc = sort_now())) return rc;
-        d_frame = sc.d_sorted;
-    }
+    if (n > 0 && (rc = sort_now(true))) return rc;
 
-    NnParams np = nn_params(m, d_frame, n, sem_th);
-    np.src = sc.d_src;
-    np.check_done = 1;
-    np.apply_pose = 1;
-    np.cand_counter = sc.d_cand;
-    HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * 2 * (n + 1), s));
-    GnParams gp{sc.d_src, nullptr, static_cast<int>(n), sc.d_state, 1, m->d_pts, sc.d_nn, kernel,
-                max_dist, sc.d_partials, p2p ? 3 : (comm ? 1 : 0), sc.d_state, &sc.d_state->gn_ticket,
-                P2pParams{}};
+    FinParams fp{};
+    fp.st = sc.d_state;
+    fp.partials = sc.d_partials;
+    fp.nparts = n ? blocks : 0;
+    fp.mode = p2p ? 3 : (comm ? 1 : 0);
+    fp.standalone = 0;
     if (p2p) {
-        gp.p2p.nranks = comm->nranks;
-        gp.p2p.rank = comm->rank;
-        for (int r = 0; r < comm->nranks; ++r) gp.p2p.block[r] = comm->blocks[r];
-        gp.p2p.exchanges = comm->d_exchanges;
-        gp.p2p.timeout_ticks = 100000000ull * static_cast<unsigned long long>(
+        fp.p2p.nranks = comm->nranks;
+        fp.p2p.rank = comm->rank;
+        for (int r = 0; r < comm->nranks; ++r) fp.p2p.block[r] = comm->blocks[r];
+        fp.p2p.exchanges = comm->d_exchanges;
+        fp.p2p.timeout_ticks = 100000000ull * static_cast<unsigned long long>(
                                    std::max(1, env_int("SAGEICP_P2P_TIMEOUT_S", 10)));
         if (const int ticks = env_int("SAGEICP_P2P_TIMEOUT_TICKS", 0))      // tests: provoke a timeout
-            gp.p2p.timeout_ticks = static_cast<unsigned long long>(ticks);
+            fp.p2p.timeout_ticks = static_cast<unsigned long long>(ticks);
     }
-    const int gn_blocks = gn_grid_for(static_cast<int>(n));
 
-    double us_group = 0, us_nn = 0, us_gn = 0, us_fin = 0;
+    double us_nn = 0, us_fin = 0;
     uint32_t resorts = 0;
     uint32_t nn_launches = 0;
     // one iteration; `slot` indexes its 5 profiling events
-    // (profiling level 1: events around k_nn only — the roofline kernel; each record costs ~1 us
-    // of stream time; level 2: around every kernel)
-    // Level 1 brackets k_nn in one iteration out of 8 (two event records cost ~6 us of stream
-    // time, 8 % of a c2 iteration): the roofline figure is the mean over that sample.
+    // Profiling level 1 brackets k_icp in one iteration out of 8 (two event records cost ~6 us of
+    // stream time): the roofline figure is the mean over that sample; level 2: every kernel of
+    // every iteration.
     auto sampled = [&](int iteration) { return prof2 || (prof && (iteration & 7) == 4); };
     auto enqueue_iteration = [&](int slot, int iteration) -> int {
         const bool ev = sampled(iteration);
         if (ev) HIPCHK(hipEventRecord(sc.events[5 * slot + 1], s));
-        launch_nn(np, s);
+        launch_icp(ip, lw, true, s);
         if (ev) HIPCHK(hipEventRecord(sc.events[5 * slot + 2], s));
-        launch_gn(gp, s);
-        if (prof2) HIPCHK(hipEventRecord(sc.events[5 * slot + 3], s));
-        if (comm && !p2p) {     // k_gn's last workgroup left the local sums in state->sums
+        launch_fin(fp, s);
+        if (comm && !p2p) {     // k_fin left the local sums in state->sums
             ncclResult_t r = g_rccl.AllReduce(sc.d_state->sums, sc.d_state->sums, kNumSums,
                                               ncclDouble, ncclSum, comm->comm, s);
             if (r != ncclSuccess)
                 return fail(SAGEICP_ERR_RCCL, std::string("ncclAllReduce: ") +
                                                   (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
-            launch_fin(sc.d_state, sc.d_partials, gn_blocks, 2, 0, s);
-        }               // single GPU: k_gn's last workgroup already finished the iteration
-        if (prof2) HIPCHK(hipEventRecord(sc.events[5 * slot + 4], s));
+            FinParams f2 = fp;
+            f2.mode = 2;
+            launch_fin(f2, s);
+        }
+        if (prof2) HIPCHK(hipEventRecord(sc.events[5 * slot + 3], s));
         return SAGEICP_OK;
     };
     auto harvest = [&](int slot) {
-        float a = 0, b = 0, c = 0;
+        float a = 0, b = 0;
         (void)hipEventElapsedTime(&a, sc.events[5 * slot + 1], sc.events[5 * slot + 2]);
-        if (prof2) {
-            (void)hipEventElapsedTime(&b, sc.events[5 * slot + 2], sc.events[5 * slot + 3]);
-            (void)hipEventElapsedTime(&c, sc.events[5 * slot + 3], sc.events[5 * slot + 4]);
-        }
-        us_nn += 1e3 * a; us_gn += 1e3 * b; us_fin += 1e3 * c;
+        if (prof2) (void)hipEventElapsedTime(&b, sc.events[5 * slot + 2], sc.events[5 * slot + 3]);
+        us_nn += 1e3 * a; us_fin += 1e3 * b;
         ++nn_launches;
     };
+    // Re-sorts are decided at fixed points of the enqueue sequence from the pose of a fixed
+    // iteration, and the sort runs on whatever pose the device holds when the stream reaches it:
+    // nothing depends on when the host happens to look (results are reproducible bit for bit).
+    //   before iteration 2: order by the work iteration 1 measured (its searches were seeded);
+    //   before iterations 8, 16, ...: again when the pose has drifted.
+    const int balance_at = env_int("SAGEICP_BALANCE_AT", 2);
     if (polled) {
-        const int depth = std::max(1, env_int("SAGEICP_DEPTH", 4));
+        const int depth = std::min(8, std::max(1, env_int("SAGEICP_DEPTH", 4)));
         volatile unsigned long long *word = &sc.h_prog->word;
-        int enq = 0, seen = 0;
+        int enq = 0;
         unsigned spins = 0;
         for (;;) {
             const unsigned long long w = *word;
             const int comp = static_cast<int>(w & 0xFFFFFFFFull);
             if (w >> 32) break;                                  // converged or out of iterations
             if (enq < kMaxIterations && enq - comp < depth) {
+                if (resort_on && enq == balance_at) {
+                    if ((rc = sort_now(false))) return rc;
+                    ++resorts;
+                } else if (resort_on && enq >= 8 && (enq & 7) == 0) {
+                    const int j = std::max(1, enq - depth + 1);   // completed: comp > enq - depth
+                    volatile double *slot = sc.h_prog->T[j % kProgressRing];
+                    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                    double Tj[7];
+                    for (int i = 0; i < 7; ++i) Tj[i] = slot[i];
+                    if (slot[7] == static_cast<double>(j) && drift(Tj, T_sorted) > resort_drift) {
+                        if ((rc = sort_now(false))) return rc;
+                        for (int i = 0; i < 7; ++i) T_sorted[i] = Tj[i];
+                        ++resorts;
+                    }
+                }
                 if ((rc = enqueue_iteration(enq, enq))) return rc;
                 ++enq;
                 spins = 0;
                 continue;
-            }
-            if (resort_on && comp != seen) {                     // the pose moved: still sorted?
-                seen = comp;
-                double Tc[7];
-                __atomic_thread_fence(__ATOMIC_ACQUIRE);
-                for (int i = 0; i < 7; ++i) Tc[i] = sc.h_prog->T[i];
-                __atomic_thread_fence(__ATOMIC_ACQUIRE);
-                if (*word == w && drift(Tc, T_sorted) > resort_drift) {   // pose read untorn
-                    if ((rc = sort_now())) return rc;
-                    for (int i = 0; i < 7; ++i) T_sorted[i] = Tc[i];
-                    ++resorts;
-                }
             }
             __builtin_ia32_pause();
             if ((++spins & 0xFFFFu) == 0) {                      // every ~ms: is the stream alive?
@@ -974,7 +1002,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
                     break;     // everything ran and nothing flagged the end: read the state below
             }
         }
-        if (stats) launch_sum_candidates(sc.d_cand, static_cast<int>(n + 1), sc.d_state, s);
+        if (stats) launch_sum_counters(sc.d_cand, static_cast<int>(ip.nwaves), sc.d_state, s);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(sc.h_state, sc.d_state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -988,7 +1016,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
             const int todo = std::min(chunk, kMaxIterations - launched);
             for (int k = 0; k < todo; ++k)
                 if ((rc = enqueue_iteration(k, launched + k))) return rc;
-            if (stats) launch_sum_candidates(sc.d_cand, static_cast<int>(n + 1), sc.d_state, s);
+            if (stats) launch_sum_counters(sc.d_cand, static_cast<int>(ip.nwaves), sc.d_state, s);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(sc.h_state, sc.d_state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
@@ -999,8 +1027,8 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
             }
             launched += todo;
             if (sc.h_state->done || launched >= kMaxIterations) break;
-            if (resort_on && drift(sc.h_state->T, T_sorted) > resort_drift) {
-                if ((rc = sort_now())) return rc;
+            if (resort_on && (launched == 4 || drift(sc.h_state->T, T_sorted) > resort_drift)) {
+                if ((rc = sort_now(false))) return rc;          // by work after the first chunk, by drift later
                 for (int i = 0; i < 7; ++i) T_sorted[i] = sc.h_state->T[i];
                 ++resorts;
             }
@@ -1008,10 +1036,17 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         }
     }
     const IcpState &st = *sc.h_state;
-    if (st.exchange_failed)
+    if (st.exchange_failed) {
+        // the ranks' exchange counters may now differ by one: a later exchange could pass its wait
+        // on a stale tag and add rows of another iteration.  The blocks are dead until every rank
+        // exports and connects fresh ones.
+        if (comm) {
+            comm->p2p = false;
+            comm->poisoned = true;
+        }
         return fail(SAGEICP_ERR_RCCL, "direct exchange: a peer's sums did not arrive in time");
+    }
     for (int i = 0; i < 7; ++i) out[i] = st.T[i];
-    const unsigned long long sum_candidates = st.sum_candidates;   // summed on the device
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         stats->iterations = st.iter;
@@ -1021,12 +1056,12 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         stats->n_corr_last = st.iter > 0 ? st.n_corr[std::min(st.iter, kHistory) - 1] : 0;
         stats->last_step_norm = st.last_step_norm;
         stats->us_upload = us_upload;
-        stats->us_group = us_group;
-        stats->us_nn = us_nn; stats->us_gn = us_gn; stats->us_fin = us_fin;
+        stats->us_nn = us_nn; stats->us_fin = us_fin;
         stats->nn_launches = nn_launches;
         stats->resorts = resorts;
-        stats->sum_candidates = sum_candidates;
+        stats->sum_candidates = st.sum_candidates;
         stats->pairs_evaluated = st.sum_pairs;
+        stats->lanes_per_query = 1u << lw;
         for (int i = 0; i < 64 && i < st.iter; ++i) stats->n_corr_hist[i] = st.n_corr[i];
         stats->us_wall = now_us() - t_begin;
     }
@@ -1224,14 +1259,15 @@ int sageicp_get_correspondences(const sageicp_map *m, const double *q, uint64_t 
     identity_pose(I);
     fill_state(sc.h_state, I);
     HIPCHK(hipMemcpyAsync(sc.d_state, sc.h_state, sizeof(IcpState), hipMemcpyHostToDevice, s));
-    // same pipeline as the ICP loop, pose = identity: sort, group, search; results are mapped
+    // same pipeline as the ICP loop, pose = identity: sort, rows, search; results are mapped
     // back to the caller's query order through the sort permutation
     HIPCHK(sort_frame(sc.d_frame, sc.d_sorted, static_cast<int>(n), sc.d_state, false,
                       m->host.voxel_size, sc.d_keys, sc.d_vals, sc.d_sort_temp, sc.sort_temp_bytes_,
-                      s));
-    HIPCHK(hipMemsetAsync(sc.d_tabkey, 0x7F, (n + 1) * sizeof(int4), s));
-    const NnParams np = nn_params(m, sc.d_sorted, n, sem_th);     // identity pose, no loop state
-    launch_nn(np, s);
+                      nullptr, nullptr, s));
+    const int lw = icp_lw(n);
+    const IcpParams ip = icp_params(m, sc.d_sorted, n, sem_th, lw);     // identity pose, no loop state
+    launch_rows(ip, s);
+    launch_icp(ip, lw, false, s);
     HIPCHK(hipGetLastError());
     std::vector<int32_t> idx(n);
     std::vector<uint32_t> perm(n);
@@ -1279,9 +1315,15 @@ int sageicp_align_clouds(const double *src, const double *tgt, uint64_t n, doubl
         identity_pose(I);
         fill_state(sc.h_state, I);
         HIPCHK(hipMemcpyAsync(sc.d_state, sc.h_state, sizeof(IcpState), hipMemcpyHostToDevice, s));
-        GnParams gp{sc.d_frame, sc.d_tgt, static_cast<int>(n), sc.d_state, 0, nullptr, nullptr,
-                    kernel, 0.0, sc.d_partials, 0, sc.d_state, &sc.d_state->gn_ticket, P2pParams{}};
-        launch_gn(gp, s);
+        if ((r = sc.reserve_partials(128))) return r;
+        GnParams gp{sc.d_frame, sc.d_tgt, static_cast<int>(n), kernel, sc.d_partials};
+        FinParams fp{};
+        fp.st = sc.d_state;
+        fp.partials = sc.d_partials;
+        fp.nparts = launch_gn(gp, s);
+        fp.mode = 0;
+        fp.standalone = 1;
+        launch_fin(fp, s);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(sc.h_state, sc.d_state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -1483,6 +1525,9 @@ int sageicp_comm_p2p_connect(sageicp_comm *c, const uint8_t *handles) {
 int sageicp_comm_p2p_enable(sageicp_comm *c, int on) {
     if (!c) return fail(SAGEICP_ERR_INVALID, "null argument");
     if (on) {
+        if (c->poisoned)
+            return fail(SAGEICP_ERR_INVALID, "direct exchange failed earlier on this communicator: "
+                                             "create a new communicator and connect it");
         for (int r = 0; r < c->nranks; ++r)
             if (!c->blocks[r]) return fail(SAGEICP_ERR_INVALID, "direct exchange is not connected");
     }
@@ -1626,6 +1671,27 @@ int sageicp_pipeline_pose(const sageicp_pipeline *p, uint64_t i, double out[7]) 
 }
 const sageicp_map *sageicp_pipeline_local_map(const sageicp_pipeline *p) {
     return p ? p->impl.map : nullptr;
+}
+
+// ---- KITTI trajectory metrics (metrics/Metrics.cpp) ------------------------------------------------
+static std::vector<sageicp::metrics::M4> to_m4(const double *p, uint64_t n) {
+    std::vector<sageicp::metrics::M4> v(n);
+    for (uint64_t i = 0; i < n; ++i) std::memcpy(v[i].m, p + 16 * i, 16 * sizeof(double));
+    return v;
+}
+int sageicp_metrics_seq_error(const double *poses_gt, const double *poses_result, uint64_t n,
+                              float *avg_trans_error, float *avg_rot_error) {
+    if (!avg_trans_error || !avg_rot_error || (n && (!poses_gt || !poses_result)))
+        return fail(SAGEICP_ERR_INVALID, "null argument");
+    sageicp::metrics::seq_error(to_m4(poses_gt, n), to_m4(poses_result, n), avg_trans_error, avg_rot_error);
+    return SAGEICP_OK;
+}
+int sageicp_metrics_absolute_trajectory_error(const double *poses_gt, const double *poses_result,
+                                              uint64_t n, float *ate_rot, float *ate_trans) {
+    if (!ate_rot || !ate_trans || !n || !poses_gt || !poses_result)
+        return fail(SAGEICP_ERR_INVALID, "null argument or empty trajectory");
+    sageicp::metrics::absolute_trajectory_error(to_m4(poses_gt, n), to_m4(poses_result, n), ate_rot, ate_trans);
+    return SAGEICP_OK;
 }
 
 }  // extern "C"

@@ -7,88 +7,97 @@
 
 namespace sageicp {
 
-struct NnParams {
+// Neighbourhood row of one query: the 27 voxels around its home voxel as found in the map's hash,
+// cached across the iterations of one RegisterFrame call (the map is constant during a call and
+// the pose moves by millimetres per iteration, so a query's home voxel rarely changes).
+//   [0..26]  the hash slot's packed word (block << 8) | count of voxel (ox, oy, oz) + 1 =
+//            (v / 9, v / 3 % 3, v % 3) — x outer, y, z inner, the reference's enumeration order
+//            (VoxelHashMap.cpp:57-63) — or kEmptySlot
+//   [27]     C_q: points stored in the neighbourhood (the algorithmic-bytes accounting)
+//   [28..30] the home voxel the row was built for (kRowNeverBuilt after a re-sort)
+//   [31]     occupancy mask: bit v set when voxel v holds points
+constexpr int kRowWords = 32;
+constexpr int kRowCq = 27, kRowKey = 28, kRowOcc = 31;
+constexpr int kRowLdsStride = 36;          // words; 16-B pieces of 8 consecutive rows hit distinct banks
+
+struct IcpParams {
     const Point4 *frame;      // pristine (sorted) frame, or ready-made queries (apply_pose == 0)
-    Point4 *src;              // out (optional): the queries as searched (pose applied), for k_gn
     int n;
     const IcpState *st;       // pose to apply and the done flag
     int check_done;           // 1 inside the ICP loop: later launches of a finished loop are no-ops
     int apply_pose;
     double voxel_size;
-    unsigned chunk;           // group cap: queries per wave (a power of two <= 16); a group is a
-                              // run of queries of one chunk that share a home voxel
-    unsigned chunk_log2;
-    unsigned cap_heads;       // forced heads inside a chunk: bit i set for every i that is a multiple
-                              // of the group cap (1 when the cap equals the chunk)
-    unsigned nchunks;         // ceil(n / chunk)
-    int4 *tabkey;             // [n] home voxel each cached probe-table row was built for (y, z, w)
-    uint2 *blks;              // [n][32] probe-table rows {candidate offset, first point}
+    uint32_t *rows;           // [n][kRowWords] cached neighbourhood rows
     const Slot *table;        // the open-addressed voxel hash
     uint32_t mask;
     const Point4 *pts;
-    uint32_t pts_bytes;       // size of the point array (< 4 GiB: k_nn addresses it by byte offset)
-    int cap;
+    uint32_t pts_bytes;       // size of the point array (< 4 GiB: addressed by 32-bit byte offsets)
+    uint32_t cap_bytes;       // bytes of one voxel block: (basic + critical) * 32
     double sem_th;
     double dist_init;         // DBL_MAX
     double prune_scale;       // min(sem_th, 1) * (1 - 1e-9): scaled distance >= this x squared
                               // distance to the voxel's cell (0 when pruning is off)
     unsigned keep_all;        // 0x7FFFFFF: visit every occupied voxel (pruning off: sem_th < 0 or
                               // not a number); 0: prune by the cell lower bound
-    int32_t *nn_idx;          // out: block*cap+slot of the semantic nearest neighbour, -1 if the
-                              //      27-voxel neighbourhood is empty (acceptance is applied later)
-    unsigned long long *cand_counter;  // optional: [2 x nchunks] per-chunk running sums of
-                                       // {C_q, pairs evaluated}
+    // search-only mode (GetCorrespondences): the semantic nearest neighbour of every query
+    int32_t *nn_idx;          // out: point index (block * cap + slot) or -1
+    // fused mode (the ICP loop): acceptance + Gauss-Newton accumulation in the same launch
+    double kernel;            // robust kernel k: w = k^2 / (k + |r|^2)^2 (Registration.cpp:79)
+    double accept_r2;         // largest r2 with sqrt(r2) < max_correspondence_distance (exact form
+                              // of the acceptance test VoxelHashMap.cpp:111; -1: accept nothing)
+    uint4 *nn_prev;           // [n] in/out: every query's record of the previous iteration {key =
+                              // (voxel << 8) | slot of its nearest neighbour, its byte offset,
+                              // map points looked at, -}; key 0xFFFFFFFF: none (after a re-sort).
+                              // Seeds the next search with a tight bound; the third word orders
+                              // the next sort by work.
+    double *partials;         // out: [gridDim.x][kNumSums] one partial per workgroup
+    unsigned long long *counters;  // optional: [2 x waves] running sums of {C_q, pairs evaluated}
+    unsigned nwaves;          // waves that own queries: ceil(n / (64 >> lw))
 };
 
-// k_nn's per-wave LDS layout, in 32-bit words from the wave's base (host and device agree on it)
-struct NnLds {
-    unsigned spt;             // chunk x {x, y, z, label} fp64
-    unsigned gap;             // chunk x 6 fp64: scaled squared gaps to the faces of the home cell
-    unsigned skey;            // 3 x chunk home voxel indices
-    unsigned wave_words;
-};
-__host__ __device__ inline NnLds nn_lds_layout(unsigned chunk) {
-    NnLds l;
-    l.spt = 0u;
-    l.gap = 8u * chunk;
-    l.skey = l.gap + 12u * chunk;
-    l.wave_words = (l.skey + 3u * chunk + 3u) & ~3u;
-    return l;
-}
+constexpr int kIcpWavesPerBlock = 4;
+// lanes per query: a power of two 1..16 (lw = log2); few for frames that fill the chip (fewer
+// instructions per query), many for small frames / shards (shorter dependent chains per wave)
+int icp_blocks_for(int n, int lw);
+size_t icp_lds_bytes(int lw);
+void launch_rows(const IcpParams &p, hipStream_t s);                     // (re)build every row
+void launch_icp(const IcpParams &p, int lw, bool fused, hipStream_t s);
 
-struct GnParams {
-    const Point4 *src;        // transformed queries (or the explicit sources of align_clouds)
-    const Point4 *tgt_pairs;  // explicit targets (align_clouds entry) or nullptr
+struct GnParams {             // stand-alone AlignClouds on explicit pairs
+    const Point4 *src;
+    const Point4 *tgt;
     int n;
-    const IcpState *st;
-    int check_done;
-    const Point4 *pts;
-    const int32_t *nn_idx;
     double kernel;
-    double max_dist;          // acceptance threshold on the unscaled distance
     double *partials;         // [gridDim.x][kNumSums]
-    int fuse_mode;            // -1: partials only; 0 / 1: the last workgroup runs finish_iteration;
-                              //  3: it reduces, exchanges the sums with the peer GPUs (p2p), solves
-    IcpState *st_rw;          // state written by finish_iteration
-    unsigned *ticket;         // last-arriver ticket (zero before the first launch)
-    P2pParams p2p;            // fuse_mode 3 only
 };
+int launch_gn(const GnParams &p, hipStream_t s);   // returns the number of partials written
 
-constexpr int kMaxGnBlocks = 512;
+// Finish of an iteration, one workgroup: fixed-order reduction of the partials, [exchange of the
+// sums with the peer GPUs,] 6x6 solve, SE3 exp, pose composition, convergence test.
+//   mode 0: reduce + solve            (single GPU)
+//   mode 1: reduce -> st->sums        (multi GPU, before the RCCL all-reduce)
+//   mode 2: solve from st->sums       (multi GPU, after the all-reduce)
+//   mode 3: reduce + direct exchange over xGMI + solve
+struct FinParams {
+    IcpState *st;
+    const double *partials;
+    int nparts;
+    int mode;
+    int standalone;           // 1: run even when st->done (AlignClouds entry)
+    P2pParams p2p;            // mode 3 only
+};
+void launch_fin(const FinParams &p, hipStream_t s);
+
+constexpr int kMaxPartials = 1 << 16;
 constexpr uint64_t kMaxQueries = (1ull << 26) - 1;
 constexpr uint64_t kMaxMapPoints = (1ull << 27) - 2;   // blocks x capacity: 32-B points under 4 GiB
 
-void launch_nn(const NnParams &p, hipStream_t s);
-int launch_gn(const GnParams &p, hipStream_t s);   // returns the number of partials written
-void launch_fin(IcpState *st, const double *partials, int nparts, int mode, int standalone,
-                hipStream_t s);
 void launch_tf(Point4 *pts, int n, const IcpState *st, hipStream_t s);
 void launch_scatter_points(const uint32_t *idx, const Point4 *vals, uint32_t n, Point4 *pts,
                            hipStream_t s);
 void launch_scatter_slots(const uint32_t *idx, const Slot *vals, uint32_t n, Slot *table,
                           hipStream_t s);
-void launch_sum_candidates(const unsigned long long *c, int n, IcpState *st, hipStream_t s);
-int gn_grid_for(int n);
+void launch_sum_counters(const unsigned long long *c, int n, IcpState *st, hipStream_t s);
 
 // preprocess.hip: one level of per-label-group voxel down-sampling (optionally with the range crop)
 struct VdsParams {
@@ -118,6 +127,6 @@ hipError_t voxel_downsample_device(const VdsParams &P, void *sort_temp, size_t s
 size_t sort_temp_bytes(int n);
 hipError_t sort_frame(const Point4 *d_in, Point4 *d_out, int n, const IcpState *st, bool apply_pose,
                       double voxel_size, uint32_t *keys, uint32_t *vals, void *temp,
-                      size_t temp_bytes, hipStream_t s);
+                      size_t temp_bytes, uint32_t *work, const uint4 *prev, hipStream_t s);
 
 }  // namespace sageicp

@@ -1,39 +1,46 @@
 // Hand-written HIP kernels for gfx950 (CDNA4, wave64) — SAGE-ICP registration hot path.
-// One ICP iteration = k_nn -> k_gn, both on one stream, no host round trip.
+// One ICP iteration = k_icp -> k_fin, both on one stream, no host round trip.
 //
-//   k_nn     one wavefront per chunk of 4 consecutive queries of the spatially sorted frame.
-//            Prologue (three lanes per query): apply the cumulative pose to the pristine frame
-//            (TransformPoints, reference core/Registration.cpp:103-111,133 — `source` is never
-//            rewritten in place), home voxel by the reference's exact fp64 divide + truncation
-//            (core/VoxelHashMap.cpp:52-54), and cut the chunk into GROUPS: runs of queries that
-//            share a home voxel, which see the same 27-voxel candidate list.  A group's
-//            probe-table row (27 x map_.find, core/VoxelHashMap.cpp:66-78) is cached across
-//            iterations and re-probed by 27 lanes only when the home voxel changed.
-//            Per group the occupied voxels' points are enumerated once in reference order (x
-//            outer, y, z inner, then insertion order) into an LDS list of byte offsets (start-mark
-//            bitmap + v_mbcnt, no search, no scalar loop), and the (query x candidate) pairs are
-//            spread over the 64 lanes — W = 64 / pow2(group size) lanes per query, each lane
-//            striding the list through a raw buffer resource — followed by a W-lane two-phase
-//            argmin (v_min_f64 over DPP, then the smallest enumeration index among the lanes
-//            that hold the minimum).  Replaces VoxelHashMap::GetCorrespondences' per-point
-//            lambda (core/VoxelHashMap.cpp:51-96).
-//   k_gn     acceptance test (core/VoxelHashMap.cpp:109-115) + robust-weighted point-to-point
-//            Gauss-Newton accumulation (Registration.cpp:62-90) as 16 closed-form fp64 sums +
-//            count, LDS-transposed block reduction -> one partial per workgroup; the
-//            last-arriving workgroup then finishes the iteration: fixed-order reduction of the
-//            partials, 6x6 LDL^T solve and SE3 exp with their divisions / sincos spread over
-//            lanes, pose composition and the convergence test (Registration.cpp:92-93,135-137).
-//   k_fin    the same finish as its own launch (multi-GPU: after the RCCL all-reduce).
+//   k_icp    VoxelHashMap::GetCorrespondences (core/VoxelHashMap.cpp:48-130) and the accumulation
+//            of AlignClouds (core/Registration.cpp:59-90) in ONE launch.  W = 1..16 lanes own a
+//            query (few lanes for frames that fill the chip: fewest instructions per query; many
+//            for small frames / shards: shortest dependent chain).  Per query: apply the
+//            cumulative pose to the pristine frame point (TransformPoints, Registration.cpp:
+//            103-111,133 — `source` is never rewritten in place); home voxel by the reference's
+//            exact fp64 divide + truncation (VoxelHashMap.cpp:52-54); the query's cached
+//            neighbourhood row (27 x map_.find, VoxelHashMap.cpp:66-78, redone only when the home
+//            voxel changed) staged in LDS; scan of the home voxel, then ONLY of the neighbour
+//            voxels whose cell can still hold a better point (exact lower bound, see below);
+//            lexicographic (distance, enumeration order) argmin = the reference's sequential
+//            strict-< scan, index for index.  Fused epilogue: acceptance test on the unscaled
+//            distance (VoxelHashMap.cpp:111), robust weight and the 16 closed-form fp64 sums of
+//            JtJ / Jtr per accepted pair, reduced in a fixed order to one partial per workgroup.
+//   k_rows   builds every query's neighbourhood row after a (re-)sort of the frame (27 lanes probe
+//            the GPU-resident open-addressed hash per query).
+//   k_fin    one workgroup: fixed-order reduction of the partials (bit-reproducible), [exchange of
+//            the sums with the peer GPUs,] 6x6 LDL^T solve and SE3 exp with their divisions /
+//            sincos spread over lanes, pose composition and the convergence test
+//            (Registration.cpp:92-93,135-137).
+//   k_gn     the accumulation alone on explicit pairs (the stand-alone AlignClouds entry).
 //   k_tf     TransformPoints for the stand-alone API entry (Registration.cpp:103-111).
 //   k_scatter_points / k_scatter_slots   refresh of the HBM mirror of the host map.
 //
-// Roofline: HBM / cache-gather bound integer/byte + fp64 compare work (~0.1 flop/B) — no MFMA (a
-// 6x6 outer product sum is not a dense contraction).  What matters here is coalescing (a voxel
-// block is one contiguous run of 32-B records; identical addresses across the lanes of a group
-// collapse into one request), LDS staging of the candidate enumeration, wave-uniform
-// branch-free inner loops with as few VALU instructions per pair as the exact fp64 semantics
-// allow (19), no device-scope atomics on hot words, and load balance by hardware dispatch of
-// many small workgroups.
+// Pruning (exact).  A point stored in voxel v lies in v's cell — it was inserted by the same fp64
+// divide + truncation (VoxelHashMap.cpp:165) — so its squared distance to the query is at least
+// the squared distance from the query to the cell, and its semantically scaled distance
+// (VoxelHashMap.cpp:87-88: d2 * th for matching labels, d2 otherwise) at least min(th, 1) times
+// that.  If this lower bound — taken with a relative slack of 1e-9 and an absolute slack on
+// every face, both far above fp64 rounding — is strictly above the scaled distance the query
+// already holds after its home voxel, no point of v can win or tie, and v is skipped.  On the
+// synthetic street scenes 75-85 % of the (query, map point) pairs the reference evaluates are
+// never loaded.
+//
+// Roofline: cache-gather bound integer/byte + fp64 compare work (~0.1 flop/B) — no MFMA (a 6x6
+// outer product sum is not a dense contraction).  What matters here: one 32-B record per lane
+// and step through a raw buffer resource (no address arithmetic), rows staged once in LDS with a
+// conflict-free stride, a branch-light per-lane state machine with the next point's load in
+// flight while the current one is evaluated, no device-scope atomics, and load balance by
+// hardware dispatch of many small workgroups in XCD-aware stripes of the spatially sorted frame.
 //
 // Built with -ffp-contract=off: distances are the plain IEEE sequence
 // dx*dx + (dy*dy + dz*dz) the CPU evaluates, so the argmin is index-exact against the oracle.
@@ -45,22 +52,11 @@
 #include <cstdlib>
 #include <vector>
 
-#ifndef SAGE_NN_WAVES
-#define SAGE_NN_WAVES 1
+#ifndef SAGE_ICP_STRIPE
+#define SAGE_ICP_STRIPE 8      // workgroups of the sorted frame per XCD stripe
 #endif
-// k_nn tuning (measured on MI355X, c2): candidate loads in flight per lane when a query has 32-64
-// lanes / 2-16 lanes, and the occupancy the register allocation aims for
-#ifndef SAGE_NN_U_BIG
-#define SAGE_NN_U_BIG 2
-#endif
-#ifndef SAGE_NN_U_SMALL
-#define SAGE_NN_U_SMALL 4
-#endif
-#ifndef SAGE_NN_OCC
-#define SAGE_NN_OCC 8
-#endif
-#ifndef SAGE_NN_STRIPE
-#define SAGE_NN_STRIPE 64      // chunks of the sorted frame per XCD stripe
+#ifndef SAGE_ICP_OCC
+#define SAGE_ICP_OCC 2         // workgroups of 4 waves per SIMD the register allocation aims for
 #endif
 
 #include "kernels.h"
@@ -69,69 +65,11 @@
 
 namespace sageicp {
 
-__device__ __forceinline__ uint32_t rl_u32(uint32_t v, int lane) {
-    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), lane));
-}
 
-// -------------------------------------------------------------------------------- probe_row
-// Probe-table row of one home voxel (hx, hy, hz), built by one wave:
-//   row[v] = {exclusive candidate offset, index of the voxel block's first point}
-// for neighbour voxel v = 0..26 (x outer, y, z inner — the reference's enumeration order,
-// core/VoxelHashMap.cpp:66-78: 27 x map_.find).  27 lanes probe the GPU-resident open-addressed
-// hash (linear probing, 16-B slots, load factor <= 0.25, one 16-B load per step), a 32-lane
-// prefix sum turns the counts into offsets; entry 27 carries the total and 28..31 a sentinel, so
-// any flat candidate index is located by a fixed 5-step binary search over 32 entries.  The row
-// is also stored in `blks` (with the voxel it describes in `tabkey`) for the next iterations.
-__device__ __forceinline__ uint2 probe_row(const NnParams &P, int lane, const uint32_t *lds,
-                                           unsigned skey_word, int h, unsigned slot) {
-    // rare path (stale rows only): keep its lane-derived constants and LDS addresses from being
-    // hoisted into the registers of the caller's hot loop
-    asm volatile("" : "+v"(lane));
-    skey_word = __builtin_amdgcn_readfirstlane(skey_word);
-    asm volatile("" : "+s"(skey_word));
-    const int *skey = reinterpret_cast<const int *>(lds + skey_word);
-    const unsigned v = static_cast<unsigned>(lane);
-    // home voxel of query h of the chunk: skey[comp * chunk + h], one component per lane 0..2
-    const unsigned kv = static_cast<unsigned>(skey[min(v, 2u) * P.chunk + static_cast<unsigned>(h)]);
-    const int hx = static_cast<int>(rl_u32(kv, 0)), hy = static_cast<int>(rl_u32(kv, 1)),
-              hz = static_cast<int>(rl_u32(kv, 2));
-    uint32_t blk = kEmptySlot;
-    if (v < 27u) {
-        const int vx = hx + static_cast<int>(v / 9u) - 1;
-        const int vy = hy + static_cast<int>((v / 3u) % 3u) - 1;
-        const int vz = hz + static_cast<int>(v % 3u) - 1;
-        uint32_t sl = voxel_hash(vx, vy, vz) & P.mask;
-        for (;;) {
-            int4 e = reinterpret_cast<const int4 *>(P.table)[sl];
-            asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(e.z), "+v"(e.w));   // one 16-B load
-            if (static_cast<uint32_t>(e.w) == kEmptySlot) break;
-            if (e.x == vx && e.y == vy && e.z == vz) { blk = static_cast<uint32_t>(e.w); break; }
-            sl = (sl + 1) & P.mask;
-        }
-    }
-    const uint32_t cnt = (blk == kEmptySlot) ? 0u : (blk & 255u);
-    uint32_t incl = cnt;
-#pragma unroll
-    for (int d = 1; d < 32; d <<= 1) {
-        const uint32_t t = __shfl_up(incl, d, 32);
-        if ((v & 31u) >= static_cast<unsigned>(d)) incl += t;
-    }
-    uint2 row;
-    row.x = (v > 27u) ? 0xFFFFFFFFu : incl - cnt;
-    row.y = (blk == kEmptySlot) ? 0u : (blk >> 8) * static_cast<uint32_t>(P.cap);   // first point
-    if (v < 32u) P.blks[slot * 32u + v] = row;
-    if (v == 0u) {
-        int4 k;
-        k.x = 0; k.y = hx; k.z = hy; k.w = hz;
-        P.tabkey[slot] = k;                   // the row now describes this home voxel
-    }
-    return row;
-}
-
-// ------------------------------------------------------------------------------------- k_nn
-// Cross-lane helpers.  DPP moves run on the VALU (no LDS traffic, no scalar instructions); the
-// patterns used are involutions (quad swaps, half-row and row mirrors), so each step is an
-// exchange and every lane of a segment ends with the segment's result.
+// ---------------------------------------------------------------------------- cross-lane helpers
+// DPP moves run on the VALU (no LDS traffic, no scalar instructions); the patterns used are
+// involutions (quad swaps, half-row and row mirrors), so each step is an exchange and every lane
+// of a segment ends with the segment's result.
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -139,18 +77,13 @@ __device__ __forceinline__ double dpp_f64(double v) {
     hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
-template <int CTRL>
-__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
-    return static_cast<unsigned>(
-        __builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), CTRL, 0xF, 0xF, false));
-}
 constexpr int kDppXor1 = 0xB1;          // quad_perm [1,0,3,2]
 constexpr int kDppXor2 = 0x4E;          // quad_perm [2,3,0,1]
 constexpr int kDppHalfMirror = 0x141;   // lane i <-> 7 - i   within each 8
 constexpr int kDppMirror = 0x140;       // lane i <-> 15 - i  within each 16
 
-// v_min_f64 without the quieting v_max_f64 x, x pairs the compiler puts around fmin(): the
-// operands here are never NaN.
+// v_min_f64 without the quieting v_max_f64 x, x pairs the compiler puts around fmin(): one
+// operand (the running best) is never NaN, and a NaN candidate leaves it unchanged.
 __device__ __forceinline__ double min_f64(double a, double b) {
     double r;
     asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -173,36 +106,21 @@ SAGE_MIN_U32_DPP(min_u32_half_mirror, "row_half_mirror")
 SAGE_MIN_U32_DPP(min_u32_mirror, "row_mirror")
 #undef SAGE_MIN_U32_DPP
 
-// One group: `len` (1..16) consecutive queries that share a home voxel.  W = 2^LW lanes serve each
-// query.  The 27-voxel neighbourhood is walked VOXEL BY VOXEL, the home voxel first: a voxel's
-// points are one contiguous run of 32-B records, lane ci of a query takes points ci, ci + W, ...
-// (scalar base offset + per-lane index through the raw buffer resource: no address arithmetic, no
-// candidate list).  After the home voxel every other occupied voxel is kept only if its CELL can
-// still hold a better point for at least one query of the group — an exact test:
-//   a point stored in voxel v lies in v's cell (it was inserted by the same fp64 divide +
-//   truncation, VoxelHashMap.cpp:165), so its squared distance to the query is at least the
-//   squared distance to the cell, and its semantically scaled distance (VoxelHashMap.cpp:87-88)
-//   at least min(th, 1) times that.  If that lower bound (taken with a relative slack of 1e-9
-//   and an absolute slack on every face, far above fp64 rounding) is strictly above the best
-//   scaled distance the query already holds, no point of v can win or tie.
-// The surviving voxels are visited in ascending order and every lane keeps the lexicographic
-// minimum of (scaled distance, enumeration index) — enumeration index = the reference's order, x
-// outer, y, z inner, then insertion order (VoxelHashMap.cpp:57-63,73-75) — so the result is the
-// sequential strict-< scan's, index for index.
-typedef unsigned v4u __attribute__((ext_vector_type(4)));
-
-// One map point through the buffer path: byte offset = scalar `soff` (the voxel block's first
-// point) + per-lane `voff`; the resource carries the 64-bit base, so a load costs no VALU address
-// arithmetic.
-__device__ __forceinline__ Point4 load_point(__amdgpu_buffer_rsrc_t pts, uint32_t voff, uint32_t soff) {
-    const v4u a = __builtin_amdgcn_raw_buffer_load_b128(pts, voff, soff, 0);
-    const v4u b = __builtin_amdgcn_raw_buffer_load_b128(pts, voff + 16u, soff, 0);
-    Point4 q;
-    q.x = __hiloint2double(static_cast<int>(a.y), static_cast<int>(a.x));
-    q.y = __hiloint2double(static_cast<int>(a.w), static_cast<int>(a.z));
-    q.z = __hiloint2double(static_cast<int>(b.y), static_cast<int>(b.x));
-    q.l = __hiloint2double(static_cast<int>(b.w), static_cast<int>(b.z));
-    return q;
+template <int W>
+__device__ __forceinline__ double seg_min_f64(double m) {      // over segments of W <= 16 lanes
+    if (W >= 2) m = min_f64(m, dpp_f64<kDppXor1>(m));
+    if (W >= 4) m = min_f64(m, dpp_f64<kDppXor2>(m));
+    if (W >= 8) m = min_f64(m, dpp_f64<kDppHalfMirror>(m));
+    if (W >= 16) m = min_f64(m, dpp_f64<kDppMirror>(m));
+    return m;
+}
+template <int W>
+__device__ __forceinline__ unsigned seg_min_u32(unsigned m) {
+    if (W >= 2) m = min_u32_xor1(m);
+    if (W >= 4) m = min_u32_xor2(m);
+    if (W >= 8) m = min_u32_half_mirror(m);
+    if (W >= 16) m = min_u32_mirror(m);
+    return m;
 }
 
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
@@ -211,298 +129,442 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-// lanes 0..26 <-> neighbour voxel (ox, oy, oz) + 1 = (lane / 9, lane / 3 % 3, lane % 3)
-constexpr unsigned long long kMaskXNeg = 0x00001FFull, kMaskXPos = 0x7FC0000ull;
-constexpr unsigned long long kMaskYNeg = 0x01C0E07ull, kMaskYPos = 0x70381C0ull;
-constexpr unsigned long long kMaskZNeg = 0x1249249ull, kMaskZPos = 0x4924924ull;
-constexpr unsigned kHomeVoxel = 13u;
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
-template <int LW>      // W = 2^LW lanes per query
-__device__ __forceinline__ void nn_group(const NnParams &P, __amdgpu_buffer_rsrc_t pts, int lane,
-                                         int start, int len, const uint2 ob, const Point4 &p,
-                                         const double *gap, unsigned &pairs_eval) {
-    constexpr int W = 1 << LW;
-    const int qi = lane >> LW;                  // query of this lane within the group
-    const unsigned ci = lane & (W - 1);
-    const bool active = qi < len;
-    const int pli = static_cast<int>(p.l);
-    const double th = P.sem_th;
-
-    // closest_distance2 starts at numeric_limits<double>::max() (VoxelHashMap.cpp:80); the value
-    // travels as a kernel argument so that it sits in scalar registers
-    double best = P.dist_init;                  // scaled squared distance
-    unsigned best_f = 0xFFFFFFFFu;              // its enumeration index (the tie-break key)
-    unsigned best_off = 0u;                     // its byte offset in the point array
-
-    // lane v < 27 holds voxel v's row: ob.x = candidates before it, ob.y = its first point
-    const unsigned cnt = dpp_u32<0x130>(ob.x) - ob.x;             // wave_shl:1 -> points in voxel v
-    const unsigned occ = static_cast<unsigned>(__ballot(lane < 27 && cnt != 0u));
-
-    auto visit = [&](int v) {                   // v is wave-uniform
-        const unsigned off_v = rl_u32(ob.x, v), cnt_v = rl_u32(cnt, v);
-        const unsigned base = rl_u32(ob.y, v) << 5;              // byte offset of 32-B points
-        pairs_eval += cnt_v;
-        for (unsigned i0 = 0; i0 < cnt_v; i0 += W) {             // uniform trip count
-            const unsigned i = i0 + ci;
-            if (i < cnt_v) {
-                const Point4 nb = load_point(pts, i << 5, base);
-                const double dx = nb.x - p.x, dy = nb.y - p.y, dz = nb.z - p.z;
-                double d = dx * dx + (dy * dy + dz * dz);
-                // same label, or either side unlabelled (VoxelHashMap.cpp:87-88)
-                // ((int)(a * b) == 0  <=>  |a * b| < 1 under truncation toward zero)
-                const bool same = static_cast<int>(nb.l) == pli || fabs(nb.l * p.l) < 1.0;
-                const double ds = d * th;
-                d = same ? ds : d;
-                const unsigned f = off_v + i;
-                // lexicographic (d, f): voxels are not visited in enumeration order (home first);
-                // a NaN distance never wins
-                const bool lt = d < best, eq = d == best, fl = f < best_f;
-                const bool take = lt | (eq & fl);               // no short-circuit branches
-                best = min_f64(best, d);
-                best_f = take ? f : best_f;
-                best_off = take ? base + (i << 5) : best_off;
-            }
-        }
-    };
-
-    if ((occ >> kHomeVoxel) & 1u) visit(static_cast<int>(kHomeVoxel));
-
-    // what every query holds after its home voxel bounds the rest of its search
-    double m = best;
-    if (W >= 2) m = min_f64(m, dpp_f64<kDppXor1>(m));
-    if (W >= 4) m = min_f64(m, dpp_f64<kDppXor2>(m));
-    if (W >= 8) m = min_f64(m, dpp_f64<kDppHalfMirror>(m));
-    if (W >= 16) m = min_f64(m, dpp_f64<kDppMirror>(m));
-    if (W >= 32) m = min_f64(m, __shfl_xor(m, 16, 64));
-    if (W >= 64) m = min_f64(m, __shfl_xor(m, 32, 64));
-
-    unsigned need = P.keep_all;                 // 0, or all 27 voxels when pruning is off
-    {
-        const bool xn = (kMaskXNeg >> lane) & 1ull, xp = (kMaskXPos >> lane) & 1ull;
-        const bool yn = (kMaskYNeg >> lane) & 1ull, yp = (kMaskYPos >> lane) & 1ull;
-        const bool zn = (kMaskZNeg >> lane) & 1ull, zp = (kMaskZPos >> lane) & 1ull;
-        for (int q = 0; q < len; ++q) {         // lane v < 27: lower bound of voxel v for query q
-            const double bq = readlane_f64(m, q << LW);
-            // uniform addresses: three broadcast reads, then per-lane selects
-            const double2 g01 = *reinterpret_cast<const double2 *>(gap + 6 * q);
-            const double2 g23 = *reinterpret_cast<const double2 *>(gap + 6 * q + 2);
-            const double2 g45 = *reinterpret_cast<const double2 *>(gap + 6 * q + 4);
-            double gx = xp ? g01.y : 0.0, gy = yp ? g23.y : 0.0, gz = zp ? g45.y : 0.0;
-            gx = xn ? g01.x : gx;
-            gy = yn ? g23.x : gy;
-            gz = zn ? g45.x : gz;
-            const double lb = gx + (gy + gz);
-            need |= static_cast<unsigned>(__ballot(lb <= bq));
-        }
-    }
-    need &= occ & ~(1u << kHomeVoxel);
-    while (need) {
-        const int v = __builtin_ctz(need);
-        need &= need - 1u;
-        visit(v);
-    }
-
-    // argmin over the W lanes of each query, lexicographic in (distance, enumeration index) like
-    // the sequential strict-< scan it replaces: first the minimum distance (never NaN: a NaN
-    // distance fails every comparison), then the smallest index among the lanes that hold it.
-    m = best;
-    if (W >= 2) m = min_f64(m, dpp_f64<kDppXor1>(m));
-    if (W >= 4) m = min_f64(m, dpp_f64<kDppXor2>(m));
-    if (W >= 8) m = min_f64(m, dpp_f64<kDppHalfMirror>(m));
-    if (W >= 16) m = min_f64(m, dpp_f64<kDppMirror>(m));
-    if (W >= 32) m = min_f64(m, __shfl_xor(m, 16, 64));
-    if (W >= 64) m = min_f64(m, __shfl_xor(m, 32, 64));
-    const unsigned mine = (best == m) ? best_f : 0xFFFFFFFFu;
-    unsigned minf = mine;
-    if (W >= 2) minf = min_u32_xor1(minf);
-    if (W >= 4) minf = min_u32_xor2(minf);
-    if (W >= 8) minf = min_u32_half_mirror(minf);
-    if (W >= 16) minf = min_u32_mirror(minf);
-    if (W >= 32) minf = min(minf, static_cast<unsigned>(__shfl_xor(static_cast<int>(minf), 16, 64)));
-    if (W >= 64) minf = min(minf, static_cast<unsigned>(__shfl_xor(static_cast<int>(minf), 32, 64)));
-
-    // The argmin is stored unconditionally; the acceptance test on the unscaled distance
-    // (VoxelHashMap.cpp:111) is applied where the pair is consumed (k_gn / the host join).
-    // Enumeration indices are unique, so exactly one lane of a query holds the winner.
-    if (active) {
-        if (minf == 0xFFFFFFFFu) {
-            if (ci == 0) P.nn_idx[start + qi] = -1;
-        } else if (mine == minf) {
-            P.nn_idx[start + qi] = static_cast<int>(best_off >> 5);
-        }
-    }
+// One map point through the buffer path: `off` is its byte offset in the point array; the
+// resource carries the 64-bit base, so a load costs no 64-bit address arithmetic.
+__device__ __forceinline__ Point4 load_point(__amdgpu_buffer_rsrc_t pts, uint32_t off) {
+    const v4u a = __builtin_amdgcn_raw_buffer_load_b128(pts, off, 0, 0);
+    const v4u b = __builtin_amdgcn_raw_buffer_load_b128(pts, off + 16u, 0, 0);
+    Point4 q;
+    q.x = __hiloint2double(static_cast<int>(a.y), static_cast<int>(a.x));
+    q.y = __hiloint2double(static_cast<int>(a.w), static_cast<int>(a.z));
+    q.z = __hiloint2double(static_cast<int>(b.y), static_cast<int>(b.x));
+    q.l = __hiloint2double(static_cast<int>(b.w), static_cast<int>(b.z));
+    return q;
 }
 
+// --------------------------------------------------------------------------------- hash probing
+// The GPU-resident open-addressed hash: linear probing, 16-B slots, load factor <= 0.25, one 16-B
+// load per step.  Returns the slot's packed word (block << 8) | count, or kEmptySlot.
+__device__ __forceinline__ uint32_t probe_resolve(const Slot *table, uint32_t mask, uint32_t sl,
+                                                  int4 e, int vx, int vy, int vz) {
+    for (;;) {
+        if (static_cast<uint32_t>(e.w) == kEmptySlot) return kEmptySlot;
+        if (e.x == vx && e.y == vy && e.z == vz) return static_cast<uint32_t>(e.w);
+        sl = (sl + 1u) & mask;                    // tombstones (map_update.hip) never match
+        e = reinterpret_cast<const int4 *>(table)[sl];
+    }
+}
+__device__ __forceinline__ uint32_t probe_voxel(const Slot *table, uint32_t mask, int vx, int vy,
+                                                int vz) {
+    const uint32_t sl = voxel_hash(vx, vy, vz) & mask;
+    const int4 e = reinterpret_cast<const int4 *>(table)[sl];
+    return probe_resolve(table, mask, sl, e, vx, vy, vz);
+}
+
+// The query as searched: cumulative pose applied to the pristine frame point
+// (Registration.cpp:103-111), home voxel by exact fp64 divide + truncation toward zero
+// (VoxelHashMap.cpp:52-54).
+struct Query {
+    double x, y, z, l;
+    int kx, ky, kz;
+};
+__device__ __forceinline__ Query make_query(const Point4 &f, const IcpState *st, int apply_pose,
+                                            double voxel_size) {
+    Query q;
+    q.x = f.x; q.y = f.y; q.z = f.z; q.l = f.l;
+    if (apply_pose) {
+        const double *R = st->R;
+        const double *T = st->T;
+        q.x = R[0] * f.x + R[1] * f.y + R[2] * f.z + T[4];
+        q.y = R[3] * f.x + R[4] * f.y + R[5] * f.z + T[5];
+        q.z = R[6] * f.x + R[7] * f.y + R[8] * f.z + T[6];
+    }
+    q.kx = static_cast<int>(q.x / voxel_size);
+    q.ky = static_cast<int>(q.y / voxel_size);
+    q.kz = static_cast<int>(q.z / voxel_size);
+    return q;
+}
+
+// ------------------------------------------------------------------------------------ k_rows
+// Builds the neighbourhood row of every query: 32 lanes per query, lane v < 27 probes voxel v.
+__global__ __launch_bounds__(256) void k_rows(IcpParams P) {
+    const int lane = static_cast<int>(threadIdx.x & 63u);
+    const unsigned v = threadIdx.x & 31u;
+    const unsigned q = blockIdx.x * 8u + (threadIdx.x >> 5);
+    const bool valid = q < static_cast<unsigned>(P.n);
+    const Point4 f = P.frame[valid ? q : 0u];
+    const Query s = make_query(f, P.st, P.apply_pose, P.voxel_size);
+    uint32_t w = kEmptySlot;
+    if (valid && v < 27u)
+        w = probe_voxel(P.table, P.mask, s.kx + static_cast<int>(v / 9u) - 1,
+                        s.ky + static_cast<int>((v / 3u) % 3u) - 1, s.kz + static_cast<int>(v % 3u) - 1);
+    const unsigned c = (w == kEmptySlot) ? 0u : (w & 255u);
+    const unsigned long long b = __ballot(c != 0u);
+    const unsigned occ = static_cast<unsigned>(b >> (lane & 32));
+    unsigned cq = c;                          // sum over the 32 lanes of the query
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) cq += __shfl_xor(cq, d, 32);
+    if (!valid) return;
+    uint32_t out = w;
+    if (v == kRowCq) out = cq;
+    if (v == kRowKey) out = static_cast<uint32_t>(s.kx);
+    if (v == kRowKey + 1) out = static_cast<uint32_t>(s.ky);
+    if (v == kRowKey + 2) out = static_cast<uint32_t>(s.kz);
+    if (v == kRowOcc) out = occ;
+    P.rows[static_cast<size_t>(q) * kRowWords + v] = out;
+}
+
+// ------------------------------------------------------------------------------------- k_icp
 #ifdef SAGE_NN_TIMING
 constexpr unsigned kNnTimingSlots = 1u << 17;
-__device__ unsigned long long g_nn_phase[4ull * kNnTimingSlots];   // per chunk: {head, group, lifetime, count}
+__device__ unsigned long long g_nn_phase[8ull * kNnTimingSlots];   // per wave: 5 phases, lifetime, realtime, count
 #define NN_T(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); tph[i] += _t - tprev; tprev = _t; } while (0)
 #else
 #define NN_T(i) do { } while (0)
 #endif
 
-constexpr int kNnWaves = SAGE_NN_WAVES;     // waves per k_nn workgroup
+// per-workgroup LDS header (words): ws[4][16] fp64 sums | accepted pairs [4] | arrival counter
+constexpr unsigned kWgSums = 0, kWgPairs = 2u * 16u * kIcpWavesPerBlock, kWgArrive = kWgPairs + kIcpWavesPerBlock;
+constexpr unsigned kWgHeaderWords = 144;
+__host__ __device__ constexpr unsigned icp_wave_words(int lw) {
+    // the rows of the wave's queries (kRowLdsStride words each); reused by the epilogue's
+    // transposed reduction, 16 components x (queries + 2) fp64
+    return static_cast<unsigned>(kRowLdsStride * (64 >> lw) + 64);
+}
 
-__global__ __launch_bounds__(64 * kNnWaves, SAGE_NN_OCC) void k_nn(NnParams P) {
+template <int LW, bool FUSED>
+__global__ __launch_bounds__(64 * kIcpWavesPerBlock, SAGE_ICP_OCC) void k_icp(IcpParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     if (P.check_done && P.st->done) return;
+    constexpr int W = 1 << LW;                 // lanes per query
+    constexpr int QW = 64 >> LW;               // queries per wave
 #ifdef SAGE_NN_TIMING
-    unsigned long long tph[4] = {0, 0, 0, 0};
+    unsigned long long tph[5] = {0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
     const unsigned long long tstart = tprev;
+    const unsigned long long rstart = __builtin_amdgcn_s_memrealtime();
 #endif
+    const int lane = static_cast<int>(threadIdx.x & 63u);
+    const int wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    if (FUSED) {
+        if (threadIdx.x == 0) smem[kWgArrive] = 0u;
+        __syncthreads();
+    }
+    uint32_t *wl = smem + kWgHeaderWords + static_cast<unsigned>(wv) * icp_wave_words(LW);
 
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));   // wave-uniform
-    // per-wave LDS (words): the chunk's transformed queries {x, y, z, label} | their scaled
-    // squared gaps to the six faces of the home cell | their home voxels [comp][query]
-    const NnLds L = nn_lds_layout(P.chunk);
-    uint32_t *wl = smem + wv * L.wave_words;
-    // raw buffer resource over the point array (bounds-checked, 32-bit byte offsets)
-    const __amdgpu_buffer_rsrc_t pts = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<Point4 *>(P.pts), 0, static_cast<int>(P.pts_bytes), 0x00020000);
-    double *spt = reinterpret_cast<double *>(wl + L.spt);
-    double *gap = reinterpret_cast<double *>(wl + L.gap);
-    int *skey = reinterpret_cast<int *>(wl + L.skey);
-
-    // One wave per chunk of `chunk` consecutive queries (a group never crosses a chunk) and many
-    // more workgroups than the chip holds at once: the hardware dispatcher hands the next
-    // workgroup to whichever CU frees a slot, which balances the load.  (Work per query varies
-    // several-fold across the scene; persistent waves with a static share of the queries left
-    // the kernel waiting on its heaviest wave, and device-scope ticket counters were 20x slower.)
     // Workgroup b is dispatched to XCD b % 8 (observed; speed only): XCD x serves the stripes
     // x, x+8, x+16, ... of kStripe consecutive workgroups' worth of the spatially sorted frame,
     // so each private L2 sees a few compact regions of the map and every XCD gets the same mix
     // of dense and sparse regions.
-    unsigned long long wave_candidates = 0;   // wave-uniform: sum over this wave's queries of C_q
-    unsigned long long wave_pairs = 0;        // (query, candidate) pairs actually evaluated
-    constexpr unsigned kStripe = SAGE_NN_STRIPE / kNnWaves;   // workgroups per stripe
-    unsigned cand_slot = 0;
+    constexpr unsigned kStripe = SAGE_ICP_STRIPE;
+    const unsigned xcd = blockIdx.x & 7u, jb = blockIdx.x >> 3;
+    const unsigned wg = ((jb / kStripe) * 8u + xcd) * kStripe + (jb % kStripe);
+    const unsigned wave_id = wg * kIcpWavesPerBlock + static_cast<unsigned>(wv);   // wave-uniform
+
+    const int qw = lane >> LW;                 // this lane's query within the wave
+    const unsigned ci = static_cast<unsigned>(lane) & (W - 1u);
+    const unsigned q = wave_id * QW + static_cast<unsigned>(qw);
+    const bool valid = q < static_cast<unsigned>(P.n);
+    const unsigned qc = valid ? q : 0u;        // keeps the loads of idle lanes legal
+    uint32_t *lrow = wl + qw * kRowLdsStride;
+    const uint32_t *grow = P.rows + static_cast<size_t>(qc) * kRowWords;
+
+    // raw buffer resource over the point array (bounds-checked, 32-bit byte offsets)
+    const __amdgpu_buffer_rsrc_t pts = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<Point4 *>(P.pts), 0, static_cast<int>(P.pts_bytes), 0x00020000);
+
+    // ---- prologue: the query, its home voxel, its neighbourhood row ------------------------------
+    const uint4 rk = *reinterpret_cast<const uint4 *>(grow + kRowKey);     // key x, y, z | occupancy
+    uint4 prev = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);   // the previous iteration's record of this query
+    if (FUSED) prev = P.nn_prev[qc];
+    const Point4 f = P.frame[qc];
+    const Query s = make_query(f, P.st, P.apply_pose, P.voxel_size);
+    const bool stale = valid && (static_cast<uint32_t>(s.kx) != rk.x || static_cast<uint32_t>(s.ky) != rk.y ||
+                                 static_cast<uint32_t>(s.kz) != rk.z);
+    unsigned occ = rk.w;
+    NN_T(0);
+    if (!stale) {                              // stage words 0..27 of the cached row in LDS
+        for (unsigned p = ci; p < 7u; p += W)
+            *reinterpret_cast<uint4 *>(lrow + 4u * p) = *reinterpret_cast<const uint4 *>(grow + 4u * p);
+    }
+    if (__ballot(stale)) {
+        // Rare (a query crossed a voxel face since its row was built, ~1 % per iteration at the
+        // start of a cold registration, none near convergence): the stale lanes re-probe their 27
+        // voxels, three loads in flight, and write the row to LDS and back to the cache.
+        if (stale) {
+            unsigned o = 0u, cq = 0u;
+#pragma unroll 1
+            for (int a = 0; a < 9; ++a) {
+                const int vx = s.kx + a / 3 - 1, vy = s.ky + a % 3 - 1;
+                uint32_t sl[3];
+                int4 e[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    sl[k] = voxel_hash(vx, vy, s.kz + k - 1) & P.mask;
+                    e[k] = reinterpret_cast<const int4 *>(P.table)[sl[k]];
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const uint32_t w = probe_resolve(P.table, P.mask, sl[k], e[k], vx, vy, s.kz + k - 1);
+                    const unsigned c = (w == kEmptySlot) ? 0u : (w & 255u);
+                    const unsigned v = static_cast<unsigned>(3 * a + k);
+                    lrow[v] = w;
+                    o |= (c != 0u ? 1u : 0u) << v;
+                    cq += c;
+                    if (ci == 0u) P.rows[static_cast<size_t>(q) * kRowWords + v] = w;
+                }
+            }
+            lrow[kRowCq] = cq;
+            occ = o;
+            if (ci == 0u) {
+                uint4 t;
+                t.x = static_cast<uint32_t>(s.kx); t.y = static_cast<uint32_t>(s.ky);
+                t.z = static_cast<uint32_t>(s.kz); t.w = o;
+                *reinterpret_cast<uint4 *>(P.rows + static_cast<size_t>(q) * kRowWords + kRowKey) = t;
+                P.rows[static_cast<size_t>(q) * kRowWords + kRowCq] = cq;
+            }
+        }
+    }
+    if (!valid) occ = 0u;
+
+    // Squared gaps to the six faces of the home cell, pre-scaled by prune_scale.  The cell of voxel
+    // index k on one axis (truncation toward zero: cell 0 is two voxels wide): [k vs, (k+1) vs)
+    // for k > 0, (-vs, vs) for k = 0, ((k-1) vs, k vs] for k < 0.  Points stored in the voxel
+    // below / above the home voxel therefore lie at or beyond `below_hi` / `above_lo`; the gaps are
+    // shortened by an absolute slack that dwarfs the rounding of the divide, the product and the
+    // subtraction (~1e-16 relative).
+    double gx[3], gy[3], gz[3];
     {
-      const unsigned chunk = P.chunk;
-      const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
-      const unsigned quad = ((j / kStripe) * 8u + xcd) * kStripe + (j % kStripe);
-      uint2 *blks = P.blks;
-      auto load_table = [&](unsigned g) -> uint2 {
-          uint2 ob;
-          ob.x = 0xFFFFFFFFu; ob.y = 0u;
-          if (lane < 32) ob = blks[g * 32u + lane];
-          return ob;
-      };
-      const unsigned c = __builtin_amdgcn_readfirstlane(quad * kNnWaves + wv);
-      cand_slot = c;
-      if (c < P.nchunks) {
-        const unsigned q0 = c * chunk;
-        // ---- chunk prologue.  Lane (comp, i) = (lane >> log2 chunk, lane & (chunk-1)) owns
-        // coordinate `comp` of query q0 + i: it applies the cumulative pose to the pristine frame
-        // point (TransformPoints, Registration.cpp:103-111,133 — `source` is never rewritten in
-        // place), takes the home voxel index with the reference's fp64 divide + truncation
-        // (VoxelHashMap.cpp:52-54), measures the distance to the two faces of the home cell on
-        // its axis (the pruning bounds of nn_group) and parks everything in LDS for the pair lanes.
-        uint2 ob = load_table(q0);                   // the first query of a chunk is always a head
-        const unsigned qi_own = static_cast<unsigned>(lane) & (chunk - 1u);
-        const unsigned comp = static_cast<unsigned>(lane) >> P.chunk_log2;
-        const unsigned q_own = q0 + qi_own;
-        const bool lv = comp < 3u && q_own < static_cast<unsigned>(P.n);
-        int key = 0, ckey = 0x7F7F7F7F;
-        if (lv) {
-            const double *f = reinterpret_cast<const double *>(P.frame + q_own);
-            ckey = reinterpret_cast<const int *>(P.tabkey + q_own)[1 + comp];
-            const double fx = f[0], fy = f[1], fz = f[2], fl = f[3];
-            double sv;
-            if (P.apply_pose) {
-                const double *R = P.st->R + 3u * comp;
-                sv = R[0] * fx + R[1] * fy + R[2] * fz + P.st->T[4u + comp];
-            } else {
-                sv = comp == 0u ? fx : (comp == 1u ? fy : fz);
+        const double vs = P.voxel_size, sc = P.prune_scale;
+        auto gaps = [&](double v, int k, double (&g)[3]) {
+            const double below_hi = static_cast<double>(k <= 0 ? k - 1 : k) * vs;
+            const double above_lo = static_cast<double>(k >= 0 ? k + 1 : k) * vs;
+            const double slack = 1e-9 * vs + 1e-13 * fabs(v);
+            const double lo = fmax((v - below_hi) - slack, 0.0);
+            const double hi = fmax((above_lo - v) - slack, 0.0);
+            g[0] = (lo * lo) * sc;
+            g[1] = 0.0;
+            g[2] = (hi * hi) * sc;
+        };
+        gaps(s.x, s.kx, gx);
+        gaps(s.y, s.ky, gy);
+        gaps(s.z, s.kz, gz);
+    }
+    NN_T(1);
+
+    // ---- search -----------------------------------------------------------------------------------
+    // closest_distance2 starts at numeric_limits<double>::max() (VoxelHashMap.cpp:80); the value
+    // travels as a kernel argument so that it sits in scalar registers
+    double best = P.dist_init;                 // scaled squared distance
+    unsigned bkey = 0xFFFFFFFFu;               // (voxel << 8) | slot: the enumeration order
+    unsigned boff = 0u;                        // byte offset of the point
+    const int pli = static_cast<int>(s.l);
+    const double th = P.sem_th;
+    unsigned npairs = 0u;                      // points this query's lanes were handed
+
+    // voxel cursor of this lane: points i, i + W, ... of the open voxel
+    unsigned cnt = 0u, base = 0u, i = ci, khi = 0u;
+    auto evaluate = [&](const Point4 &nb, unsigned key, unsigned off) {
+        const double dx = nb.x - s.x, dy = nb.y - s.y, dz = nb.z - s.z;
+        double d = dx * dx + (dy * dy + dz * dz);
+        // same label, or either side unlabelled (VoxelHashMap.cpp:87-88)
+        // ((int)(a * b) == 0  <=>  |a * b| < 1 under truncation toward zero)
+        const bool same = static_cast<int>(nb.l) == pli || fabs(nb.l * s.l) < 1.0;
+        const double ds = d * th;
+        d = same ? ds : d;
+        // lexicographic (d, key): the home voxel is visited first, out of enumeration order;
+        // a NaN distance never wins
+        const bool lt = d < best, eq = d == best, kl = key < bkey;
+        const bool take = lt | (eq & kl);
+        best = min_f64(best, d);
+        bkey = take ? key : bkey;
+        boff = take ? off : boff;
+    };
+    // Per-lane state machine over the voxels in `need` (and the one already open).  A step handles
+    // two points of the open voxel (i and i + W); two register sets alternate, so while one pair
+    // is evaluated the loads of the next pair are in flight (no register copies across the loop
+    // edge: the wait before an evaluation leaves the younger loads outstanding).
+    struct Pair {
+        Point4 a, b;
+        unsigned ka, oa, ob;        // key / offset of a; b: key + W, offset ob
+        bool ha, hb;
+    };
+    auto scan = [&](unsigned need) {
+        auto issue = [&](Pair &n, bool &more) {
+            while (i >= cnt && need) {         // open this lane's next voxel
+                const unsigned v = static_cast<unsigned>(__builtin_ctz(need));
+                need &= need - 1u;
+                const uint32_t w = lrow[v];
+                cnt = w & 255u;
+                base = (w >> 8) * P.cap_bytes;
+                khi = v << 8;
+                i = ci;
+                npairs += cnt;
             }
-            // static_cast<int>(p / voxel_size): exact fp64 divide, truncation toward zero
-            const double vs = P.voxel_size;
-            key = static_cast<int>(sv / vs);
-            // The cell of voxel index k on one axis (truncation toward zero: cell 0 is two voxels
-            // wide): [k vs, (k+1) vs) for k > 0, (-vs, vs) for k = 0, ((k-1) vs, k vs] for k < 0.
-            // Points stored in the voxel below / above the home voxel therefore lie at or beyond
-            // `below_hi` / `above_lo`; the gaps are shortened by an absolute slack that dwarfs the
-            // rounding of the divide, the product and the subtraction (~1e-16 relative).
-            const double below_hi = static_cast<double>(key <= 0 ? key - 1 : key) * vs;
-            const double above_lo = static_cast<double>(key >= 0 ? key + 1 : key) * vs;
-            const double slack = 1e-9 * vs + 1e-13 * fabs(sv);
-            const double glo = fmax((sv - below_hi) - slack, 0.0);
-            const double ghi = fmax((above_lo - sv) - slack, 0.0);
-            spt[4u * qi_own + comp] = sv;
-            skey[lane] = key;
-            gap[6u * qi_own + 2u * comp] = (glo * glo) * P.prune_scale;
-            gap[6u * qi_own + 2u * comp + 1u] = (ghi * ghi) * P.prune_scale;
-            if (comp == 0u) spt[4u * qi_own + 3u] = fl;
-            if (P.src) {                              // the queries as searched, for k_gn
-                double *o = reinterpret_cast<double *>(P.src + q_own);
-                o[comp] = sv;
-                if (comp == 0u) o[3] = fl;
+            n.ha = i < cnt;
+            n.hb = i + W < cnt;
+            n.ka = khi | i;
+            n.oa = base + (i << 5);
+            n.ob = n.oa + (static_cast<unsigned>(W) << 5);
+            // issued by every lane (idle lanes re-read point 0): a load behind a branch would make
+            // the compiler drain the whole queue before the other set's evaluation
+            n.a = load_point(pts, n.ha ? n.oa : 0u);
+            n.b = load_point(pts, n.hb ? n.ob : 0u);
+            i += n.ha ? 2u * W : 0u;
+            more = (i < cnt) | (need != 0u);
+        };
+        auto consume = [&](const Pair &n) {
+            if (n.ha) evaluate(n.a, n.ka, n.oa);
+            if (n.hb) evaluate(n.b, n.ka + W, n.ob);
+        };
+        Pair A, B;
+        bool more = false;
+        issue(A, more);
+        for (;;) {
+            issue(B, more);
+            consume(A);
+            if (!__ballot(B.ha | more)) break;
+            issue(A, more);
+            consume(B);
+            if (!__ballot(A.ha | more)) break;
+        }
+    };
+
+    // The previous iteration's nearest neighbour is still a point of this neighbourhood as long as
+    // the home voxel has not changed (the row, and with it the meaning of `key`, is the same; the
+    // map is constant during a call): evaluated first, it gives every query — also one whose
+    // home voxel is empty — a tight bound before anything is scanned.  It is an ordinary
+    // candidate: meeting it again in the scan changes nothing.
+    if (FUSED) {
+        const bool seeded = valid && !stale && prev.x != 0xFFFFFFFFu;
+        const Point4 pp = load_point(pts, seeded ? prev.y : 0u);
+        if (seeded) evaluate(pp, prev.x, prev.y);
+    }
+    constexpr unsigned kHome = 13u;
+    scan(occ & (1u << kHome));
+    NN_T(2);
+    // what the query holds after its home voxel bounds the rest of its search
+    const double bound = seg_min_f64<W>(best);
+    unsigned need = P.keep_all;
+#pragma unroll
+    for (int v = 0; v < 27; ++v) {
+        if (v == static_cast<int>(kHome)) continue;
+        const double lb = gx[v / 9] + (gy[(v / 3) % 3] + gz[v % 3]);
+        need |= (lb <= bound) ? (1u << v) : 0u;
+    }
+    scan(need & occ & ~(1u << kHome));
+
+    // argmin over the W lanes of the query: first the minimum distance (never NaN: a NaN distance
+    // fails every comparison), then the smallest key among the lanes that hold it, then the
+    // winner's offset (keys are unique, so exactly one lane holds it)
+    const double m = seg_min_f64<W>(best);
+    const unsigned mine = (best == m) ? bkey : 0xFFFFFFFFu;
+    const unsigned mkey = seg_min_u32<W>(mine);
+    const unsigned woff = seg_min_u32<W>((mine == mkey) ? boff : 0xFFFFFFFFu);
+    const bool found = valid && mkey != 0xFFFFFFFFu;       // else: empty neighbourhood (hazard H1)
+    NN_T(3);
+
+    if (P.counters) {                          // C_q and pairs handed out, summed over the wave
+        unsigned a = (valid && ci == 0u) ? lrow[kRowCq] : 0u, b = (valid && ci == 0u) ? npairs : 0u;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            a += __shfl_xor(a, d, 64);
+            b += __shfl_xor(b, d, 64);
+        }
+        if (lane == 0 && wave_id < P.nwaves) {
+            P.counters[2u * wave_id] += a;     // private slot per wave: no contention
+            P.counters[2u * wave_id + 1u] += b;
+        }
+    }
+
+    if (!FUSED) {
+        if (valid && ci == 0u) P.nn_idx[q] = found ? static_cast<int>(woff >> 5) : -1;
+    } else {
+        // ---- fused epilogue: acceptance + Gauss-Newton terms of this query's pair -----------------
+        if (valid && ci == 0u) P.nn_prev[q] = make_uint4(found ? mkey : 0xFFFFFFFFu, woff, npairs, 0u);
+        double t[kCount];
+#pragma unroll
+        for (int c = 0; c < kCount; ++c) t[c] = 0.0;
+        bool use = false;
+        if (found && ci == 0u) {
+            const Point4 g = load_point(pts, woff);
+            const double rx = s.x - g.x, ry = s.y - g.y, rz = s.z - g.z;
+            const double r2 = rx * rx + (ry * ry + rz * rz);
+            // (closest_neighboor - point).norm() < max_correspondance_distance (VoxelHashMap.cpp:111)
+            use = r2 <= P.accept_r2;
+            if (use) {
+                const double k = P.kernel;
+                const double den = k + r2;
+                const double w = (k * k) / (den * den);   // square(th) / square(th + residual2)
+                const double wsx = w * s.x, wsy = w * s.y, wsz = w * s.z;
+                t[kW] = w;
+                t[kWsx] = wsx; t[kWsy] = wsy; t[kWsz] = wsz;
+                t[kWxx] = wsx * s.x; t[kWxy] = wsx * s.y; t[kWxz] = wsx * s.z;
+                t[kWyy] = wsy * s.y; t[kWyz] = wsy * s.z; t[kWzz] = wsz * s.z;
+                t[kWrx] = w * rx; t[kWry] = w * ry; t[kWrz] = w * rz;
+                t[kWcx] = w * (s.y * rz - s.z * ry);
+                t[kWcy] = w * (s.z * rx - s.x * rz);
+                t[kWcz] = w * (s.x * ry - s.y * rx);
             }
         }
-        // Group heads: a query whose home voxel differs from its predecessor's (chunks are
-        // aligned to rows of 16 lanes, so the predecessor is one DPP row-shift away), and the
-        // first query of the chunk.  Stale rows: heads whose cached probe-table row was built
-        // for another voxel (all of them in the first iteration, a handful afterwards: the pose
-        // moves by millimetres per iteration and the map does not change during a call).
-        const int prev = static_cast<int>(dpp_u32<0x111>(static_cast<unsigned>(key)));   // row_shr:1
-        const unsigned long long ne = __ballot(lv && qi_own > 0u && key != prev);
-        const unsigned long long mm = __ballot(lv && key != ckey);
-        const unsigned nvalid = min(chunk, static_cast<unsigned>(P.n) - q0);
-        const unsigned vmask = (nvalid >= 32u) ? 0xFFFFFFFFu : ((1u << nvalid) - 1u);
-        unsigned heads = (static_cast<unsigned>(ne | (ne >> chunk) | (ne >> (2u * chunk))) | P.cap_heads) & vmask;
-        const unsigned stale = static_cast<unsigned>(mm | (mm >> chunk) | (mm >> (2u * chunk))) & heads;
-        while (heads) {
-        const int h = __builtin_ctz(heads);
-        heads &= heads - 1u;
-        const int hn = heads ? __builtin_ctz(heads) : static_cast<int>(nvalid);   // end of the group
-        const uint2 ob_next = load_table(q0 + static_cast<unsigned>(heads ? hn : h));   // prefetch
-        const int start = static_cast<int>(q0) + h;
-        const int len = hn - h;
-        if ((stale >> h) & 1u) {
-            ob = probe_row(P, lane, smem, wv * L.wave_words + L.skey, h, static_cast<unsigned>(start));
+        const unsigned pairs = static_cast<unsigned>(__popcll(__ballot(use)));
+        // Wave reduction in a fixed order (bit-reproducible): the query lanes park their 16 terms
+        // transposed in LDS (the rows are no longer needed), four lanes per component add QW / 4
+        // parked values each and finish with two DPP exchanges.
+        double *red = reinterpret_cast<double *>(wl);
+        constexpr int S = QW + 2;              // fp64 stride of one component
+        if (ci == 0u) {
+#pragma unroll
+            for (int c = 0; c < kCount; ++c) red[c * S + qw] = t[c];
         }
-        // (query x candidate) pairs over the lanes: W = 64 / pow2ceil(len) lanes per query
-        const int lgq = (len <= 1) ? 0 : (32 - __builtin_clz(static_cast<unsigned>(len - 1)));
-        const int lw = 6 - lgq;
-        Point4 p;                                     // this lane's query
         {
-            const double4 t = *reinterpret_cast<const double4 *>(spt + 4 * (h + min(lane >> lw, len - 1)));
-            p.x = t.x; p.y = t.y; p.z = t.z; p.l = t.w;
+            const int c = lane >> 2, r = lane & 3;
+            double v = 0.0;
+#pragma unroll
+            for (int e = 0; e < QW / 4; ++e) v += red[c * S + r + 4 * e];
+            v += dpp_f64<kDppXor1>(v);
+            v += dpp_f64<kDppXor2>(v);
+            double *ws = reinterpret_cast<double *>(smem + kWgSums) + wv * kCount;
+            if (r == 0) ws[c] = v;
+            if (lane == 0) smem[kWgPairs + wv] = pairs;
         }
-        NN_T(0);
-        wave_candidates += static_cast<unsigned long long>(rl_u32(ob.x, 27)) * static_cast<unsigned>(len);
-        unsigned pe = 0;
-        switch (lw) {
-            case 6: nn_group<6>(P, pts, lane, start, len, ob, p, gap + 6 * h, pe); break;
-            case 5: nn_group<5>(P, pts, lane, start, len, ob, p, gap + 6 * h, pe); break;
-            case 4: nn_group<4>(P, pts, lane, start, len, ob, p, gap + 6 * h, pe); break;
-            case 3: nn_group<3>(P, pts, lane, start, len, ob, p, gap + 6 * h, pe); break;
-            default: nn_group<2>(P, pts, lane, start, len, ob, p, gap + 6 * h, pe); break;
+        // Workgroup partial: the last wave to arrive adds the four rows in wave order.
+        unsigned prior = 0u;
+        if (lane == 0)
+            prior = __hip_atomic_fetch_add(&smem[kWgArrive], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        prior = __builtin_amdgcn_readfirstlane(prior);
+        if (prior == kIcpWavesPerBlock - 1u) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const double *ws = reinterpret_cast<const double *>(smem + kWgSums);
+            double *out = P.partials + static_cast<size_t>(blockIdx.x) * kNumSums;
+            if (lane < kCount) {
+                double v = ws[lane];
+#pragma unroll
+                for (int k = 1; k < kIcpWavesPerBlock; ++k) v += ws[k * kCount + lane];
+                out[lane] = v;
+            } else if (lane == kCount) {
+                unsigned n = 0u;
+#pragma unroll
+                for (int k = 0; k < kIcpWavesPerBlock; ++k) n += smem[kWgPairs + k];
+                out[kCount] = static_cast<double>(n);
+            } else if (lane < kNumSums) {
+                out[lane] = 0.0;
+            }
         }
-        wave_pairs += static_cast<unsigned long long>(pe) * static_cast<unsigned>(len);
-        NN_T(1);
-        ob = ob_next;
-        }
-      }
     }
 #ifdef SAGE_NN_TIMING
-    // private slot per chunk (no contended atomics: they would stall the very loads being timed)
-    if (lane == 0 && cand_slot < kNnTimingSlots) {
-        unsigned long long *t = g_nn_phase + 4ull * cand_slot;
-        t[0] += tph[0];
-        t[1] += tph[1];
-        t[2] += __builtin_amdgcn_s_memtime() - tstart;
-        t[3] += 1ull;
+    // private slot per wave (no contended atomics: they would stall the very loads being timed)
+    NN_T(4);
+    if (lane == 0 && wave_id < kNnTimingSlots && wave_id < P.nwaves) {
+        unsigned long long *tt = g_nn_phase + 8ull * wave_id;
+        for (int k = 0; k < 5; ++k) tt[k] += tph[k];
+        tt[5] += __builtin_amdgcn_s_memtime() - tstart;
+        tt[6] += __builtin_amdgcn_s_memrealtime() - rstart;
+        tt[7] += 1ull;
     }
 #endif
-    // sum_q C_q for the roofline accounting: one private slot per chunk, summed by the host.  (A
-    // single device-scope atomic per wave serialised 8192 updates on one address and set a
-    // ~100 us floor under this kernel.)
-    if (P.cand_counter && lane == 0 && wave_candidates) {
-        atomicAdd(P.cand_counter + 2u * cand_slot, wave_candidates);   // fire-and-forget, private address
-        atomicAdd(P.cand_counter + 2u * cand_slot + 1u, wave_pairs);
-    }
 }
 
 // ------------------------------------------------------------------------------------ WaveLanes
@@ -536,61 +598,73 @@ struct WaveLanes {
 };
 
 // ------------------------------------------------------------------------------ finish_iteration
-// Executed by ONE workgroup of 256 threads once per ICP iteration: fixed-order reduction of the
-// k_gn workgroup partials (bit-reproducible), then one lane assembles the 6x6 normal equations
-// from the 16 closed-form sums, solves them (register-resident pivoted LDL^T), applies SE3 exp,
-// composes the pose and tests convergence (Registration.cpp:92-93,135-137).
-//   mode 0: reduce partials + solve      (single GPU)
-//   mode 1: reduce partials -> st->sums  (multi GPU, before the RCCL all-reduce)
-//   mode 2: solve from st->sums          (multi GPU, after the all-reduce)
+// Executed by ONE workgroup of 1024 threads once per ICP iteration (k_fin): fixed-order reduction
+// of the workgroup partials of k_icp (bit-reproducible), then the first wave assembles the 6x6
+// normal equations from the 16 closed-form sums, solves them (register-resident pivoted LDL^T),
+// applies SE3 exp, composes the pose and tests convergence (Registration.cpp:92-93,135-137).
 #ifdef SAGE_GN_TIMING
 __device__ unsigned long long g_gn_phase[16];
 #define FIN_STAMP(i) do { if (threadIdx.x == 0) fin_t[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define FIN_STAMP(i) do { } while (0)
 #endif
-__device__ __forceinline__ void finish_iteration(IcpState *st, const double *partials, int nparts,
-                                                 int mode) {
-    __shared__ double slice[8][32];
-    __shared__ double S[kNumSums];
+
+constexpr int kFinThreads = 1024;
+constexpr int kFinSlices = 102;             // 10 fp64 pairs per partial x 102 slices = 1020 threads
+
+__device__ __forceinline__ void reduce_partials(const double *partials, int nparts, double *S /* LDS [kNumSums] */) {
+    __shared__ double part[kFinSlices][kNumSums];
+    __shared__ double part2[6][kNumSums];
+    const int t = static_cast<int>(threadIdx.x);
+    const int pr = t % 10, sl = t / 10;
+    if (sl < kFinSlices) {
+        // fixed summation order; loads are independent, 8 in flight per thread
+        double2 v = make_double2(0.0, 0.0);
+        const double2 *src = reinterpret_cast<const double2 *>(partials) + pr;
+        int b = sl;
+        for (; b + 7 * kFinSlices < nparts; b += 8 * kFinSlices) {
+            double2 u[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) u[k] = src[static_cast<size_t>(b + k * kFinSlices) * 10];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v.x += u[k].x; v.y += u[k].y; }
+        }
+        {
+            double2 u[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int bb = b + k * kFinSlices;
+                u[k] = bb < nparts ? src[static_cast<size_t>(bb) * 10] : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v.x += u[k].x; v.y += u[k].y; }
+        }
+        part[sl][2 * pr] = v.x;
+        part[sl][2 * pr + 1] = v.y;
+    }
+    __syncthreads();
+    if (t < 6 * kNumSums) {
+        const int c = t % kNumSums, g = t / kNumSums;
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < kFinSlices / 6; ++k) v += part[g * (kFinSlices / 6) + k][c];
+        part2[g][c] = v;
+    }
+    __syncthreads();
+    if (t < kNumSums) {
+        double v = part2[0][t];
+#pragma unroll
+        for (int g = 1; g < 6; ++g) v += part2[g][t];
+        S[t] = v;
+    }
+    __syncthreads();
+}
+
+// the solve: wave 0, all 64 lanes, uniform data (see WaveLanes); lane 0 / lane 1 publish the state
+__device__ __forceinline__ void solve_and_publish(IcpState *st, const double *S) {
 #ifdef SAGE_GN_TIMING
     unsigned long long fin_t[8];
 #endif
-    FIN_STAMP(0);
-
-    if (mode != 2) {
-        const int comp = threadIdx.x & 31, sl = threadIdx.x >> 5;
-        double v = 0.0;
-        if (comp < kNumSums) {
-            // fixed summation order; loads are independent, 8 in flight per thread
-            int b = sl;
-            for (; b + 56 < nparts; b += 64) {
-                double t[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) t[u] = partials[(b + 8 * u) * kNumSums + comp];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v += t[u];
-            }
-            for (; b < nparts; b += 8) v += partials[b * kNumSums + comp];
-        }
-        slice[sl][comp] = v;
-        __syncthreads();
-        if (threadIdx.x < kNumSums) {
-            double s = 0.0;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) s += slice[i][threadIdx.x];   // fixed order
-            S[threadIdx.x] = s;
-            st->sums[threadIdx.x] = s;
-        }
-        __syncthreads();
-        if (mode == 1) return;
-    } else {
-        if (threadIdx.x < kNumSums) S[threadIdx.x] = st->sums[threadIdx.x];
-        __syncthreads();
-    }
-
-    if (threadIdx.x >= 64) return;
-    // wave 0, all 64 lanes, uniform data (see WaveLanes); lane 0 / lane 1 publish the state
     FIN_STAMP(1);
     const int lane = static_cast<int>(threadIdx.x);
     double JTJ[36], JTr[6], neg[6], x[6], est[7];
@@ -644,19 +718,22 @@ __device__ __forceinline__ void finish_iteration(IcpState *st, const double *par
     }
     if (st->done) done = 1;                    // e.g. stopped by a failed multi-GPU exchange
     if (IcpProgress *pg = st->progress) {
-        // host-mapped: the pose, then the progress word, as relaxed system-scope (write-through)
-        // stores — a release here would write back this XCD's whole L2 every iteration; the host
-        // only steers its look-ahead and its re-sort heuristic by these values and reads the
-        // final state through an ordinary copy after the loop
+        // host-mapped: the pose (tagged with its iteration) into its ring slot, then the progress
+        // word, as relaxed system-scope (write-through) stores; the host only steers its look-ahead
+        // and its re-sort decisions by these values and reads the final state through an ordinary
+        // copy after the loop
+        const unsigned long long seq = static_cast<unsigned long long>(it + 1);
+        double *slot = pg->T[seq % kProgressRing];
 #pragma unroll
         for (int i = 0; i < 7; ++i)
-            __hip_atomic_store(&pg->T[i], Tn[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&pg->word, (done << 32) | static_cast<unsigned long long>(it + 1),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&slot[i], Tn[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&slot[7], static_cast<double>(seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&pg->word, (done << 32) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 #ifdef SAGE_GN_TIMING
     fin_t[4] = __builtin_amdgcn_s_memrealtime();
-    for (int i = 0; i < 4; ++i) atomicAdd(&g_gn_phase[8 + i], fin_t[i + 1] - fin_t[i]);
+    for (int i = 1; i < 4; ++i) atomicAdd(&g_gn_phase[8 + i], fin_t[i + 1] - fin_t[i]);
+    atomicAdd(&g_gn_phase[4], 1ull);
 #endif
 }
 
@@ -715,42 +792,47 @@ __device__ __forceinline__ void exchange_sums(IcpState *st, const P2pParams &X) 
     }
 }
 
-// ------------------------------------------------------------------------------------ k_gn
-#ifdef SAGE_GN_TIMING
-#define GN_STAMP(i) do { if (threadIdx.x == 0) gn_t[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define GN_STAMP(i) do { } while (0)
-#endif
+// ------------------------------------------------------------------------------------ k_fin
+__global__ __launch_bounds__(kFinThreads) void k_fin(FinParams P) {
+    if (!P.standalone && P.st->done) return;
+    __shared__ double S[kNumSums];
+    IcpState *st = P.st;
+    if (P.mode != 2) {
+        reduce_partials(P.partials, P.nparts, S);
+        if (threadIdx.x < kNumSums) st->sums[threadIdx.x] = S[threadIdx.x];
+        if (P.mode == 1) return;
+        if (P.mode == 3) {
+            __syncthreads();
+            exchange_sums(st, P.p2p);
+            __syncthreads();
+            if (threadIdx.x < kNumSums) S[threadIdx.x] = st->sums[threadIdx.x];
+            __syncthreads();
+        }
+    } else {
+        if (threadIdx.x < kNumSums) S[threadIdx.x] = st->sums[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x >= 64) return;
+    solve_and_publish(st, S);
+}
 
+// ------------------------------------------------------------------------------------ k_gn
+// AlignClouds' accumulation (Registration.cpp:62-90) on explicit pairs: every pair is taken.
 __global__ __launch_bounds__(256) void k_gn(GnParams P) {
-    if (P.check_done && P.st->done) return;
     // block reduction scratch: component c of thread t at red[c][(t >> 4) * 17 + (t & 15)]
     // (rows of 16 values padded to 17 doubles: conflict-free for both the write and the read)
     __shared__ double red[kCount][16 * 17];
-    __shared__ unsigned wave_pairs[4];
-#ifdef SAGE_GN_TIMING
-    unsigned long long gn_t[8];
-    GN_STAMP(0);
-#endif
-
     double acc[kCount];
 #pragma unroll
     for (int i = 0; i < kCount; ++i) acc[i] = 0.0;
-    unsigned pairs = 0;   // accepted pairs of this wave (wave-uniform, exact in any order)
-
     const double k = P.kernel;
     const double k2 = k * k;
-
-    // per-pair accumulation; `use` masks rejected / out-of-range pairs (w = 0 adds exact zeros)
-    auto accumulate = [&](const Point4 &s, const Point4 &g, bool use) {
+    const int stride = gridDim.x * 256;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < P.n; q += stride) {
+        const Point4 s = P.src[q], g = P.tgt[q];
         const double sx = s.x, sy = s.y, sz = s.z;
         const double rx = sx - g.x, ry = sy - g.y, rz = sz - g.z;
         const double r2 = rx * rx + (ry * ry + rz * rz);
-        // acceptance: (closest_neighboor - point).norm() < max_correspondance_distance
-        // (VoxelHashMap.cpp:111); explicit pairs (align_clouds entry) are all taken
-        if (!P.tgt_pairs && !(sqrt(r2) < P.max_dist)) use = false;
-        pairs += static_cast<unsigned>(__popcll(__ballot(use)));
-        if (!use) return;
         const double den = k + r2;
         const double w = k2 / (den * den);   // square(th) / square(th + residual2)
         const double wsx = w * sx, wsy = w * sy, wsz = w * sz;
@@ -762,111 +844,31 @@ __global__ __launch_bounds__(256) void k_gn(GnParams P) {
         acc[kWcx] += w * (sy * rz - sz * ry);
         acc[kWcy] += w * (sz * rx - sx * rz);
         acc[kWcz] += w * (sx * ry - sy * rx);
-    };
-
-    // grid-stride over the queries, two per step so that the dependent gathers
-    // (nn_idx -> target point) of both are in flight together
-    const int stride = gridDim.x * 256;
-    for (int q = blockIdx.x * 256 + threadIdx.x; q < P.n; q += 2 * stride) {
-        const int q2 = q + stride;
-        const bool has2 = q2 < P.n;
-        int i1 = 0, i2 = 0;
-        if (!P.tgt_pairs) {
-            i1 = P.nn_idx[q];
-            i2 = has2 ? P.nn_idx[q2] : -1;
-        }
-        const Point4 s1 = P.src[q];
-        const Point4 s2 = P.src[has2 ? q2 : q];
-        Point4 g1, g2;
-        if (P.tgt_pairs) {
-            g1 = P.tgt_pairs[q];
-            g2 = P.tgt_pairs[has2 ? q2 : q];
-        } else {
-            g1 = P.pts[i1 < 0 ? 0 : i1];
-            g2 = P.pts[i2 < 0 ? 0 : i2];
-        }
-        accumulate(s1, g1, i1 >= 0);
-        accumulate(s2, g2, has2 && i2 >= 0);
     }
-
-    GN_STAMP(1);
-    // Block reduction in a fixed order (bit-reproducible): every thread parks its 16 sums in LDS,
-    // then 16 threads per component each add 16 parked values and finish with four DPP exchange
-    // steps inside their row of 16 lanes.  (A shuffle tree per component and wave cost ~3.9 us
-    // of LDS-permute traffic per launch.)
-    {
-        const int t = static_cast<int>(threadIdx.x);
-        const int slot = (t >> 4) * 17 + (t & 15);
+    // fixed-order block reduction: every thread parks its 16 sums in LDS, then 16 threads per
+    // component each add 16 parked values and finish with four DPP exchange steps
+    const int t = static_cast<int>(threadIdx.x);
+    const int slot = (t >> 4) * 17 + (t & 15);
 #pragma unroll
-        for (int c = 0; c < kCount; ++c) red[c][slot] = acc[c];
-        if ((t & 63) == 0) wave_pairs[t >> 6] = pairs;
-        __syncthreads();
-        const double *row = &red[t >> 4][(t & 15) * 17];
-        double v = row[0];
+    for (int c = 0; c < kCount; ++c) red[c][slot] = acc[c];
+    __syncthreads();
+    const double *row = &red[t >> 4][(t & 15) * 17];
+    double v = row[0];
 #pragma unroll
-        for (int i = 1; i < 16; ++i) v += row[i];
-        v += dpp_f64<kDppXor1>(v);
-        v += dpp_f64<kDppXor2>(v);
-        v += dpp_f64<kDppHalfMirror>(v);
-        v += dpp_f64<kDppMirror>(v);
-        double *out = P.partials + static_cast<size_t>(blockIdx.x) * kNumSums;
-        if ((t & 15) == 0) out[t >> 4] = v;
-        if (t == 0)
-            out[kCount] = static_cast<double>((wave_pairs[0] + wave_pairs[1]) +
-                                              (wave_pairs[2] + wave_pairs[3]));
-        if (t > kCount && t < kNumSums) out[t] = 0.0;
+    for (int i = 1; i < 16; ++i) v += row[i];
+    v += dpp_f64<kDppXor1>(v);
+    v += dpp_f64<kDppXor2>(v);
+    v += dpp_f64<kDppHalfMirror>(v);
+    v += dpp_f64<kDppMirror>(v);
+    double *out = P.partials + static_cast<size_t>(blockIdx.x) * kNumSums;
+    if ((t & 15) == 0) out[t >> 4] = v;
+    if (t == 0) {
+        const int lo = blockIdx.x * 256;
+        int cnt = 0;                         // pairs this block owns (grid-stride)
+        for (int q = lo; q < P.n; q += stride) cnt += min(256, P.n - q);
+        out[kCount] = static_cast<double>(cnt);
     }
-    if (P.fuse_mode < 0) return;
-    GN_STAMP(2);
-
-    // Last-arriver hand-off (placement independent): partials are published with an agent-scope
-    // release before the ticket, the workgroup that draws the last ticket acquires (drops its
-    // CU's stale L1 lines of `partials`, which other CUs rewrite every iteration) and finishes the
-    // iteration.  One returning atomic per workgroup (<= 512 per launch) on a private word.
-    __shared__ unsigned s_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned t = __hip_atomic_fetch_add(P.ticket, 1u, __ATOMIC_RELAXED,
-                                                  __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t == gridDim.x - 1u) ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __hip_atomic_store(P.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
-    }
-    __syncthreads();
-    GN_STAMP(3);
-    if (P.fuse_mode == 3) {
-        // multi-GPU without a collective launch: local sums -> peers -> global sums -> solve
-        finish_iteration(P.st_rw, P.partials, static_cast<int>(gridDim.x), 1);
-        __syncthreads();
-        exchange_sums(P.st_rw, P.p2p);
-        __syncthreads();
-        finish_iteration(P.st_rw, P.partials, 0, 2);
-        return;
-    }
-    finish_iteration(P.st_rw, P.partials, static_cast<int>(gridDim.x), P.fuse_mode);
-#ifdef SAGE_GN_TIMING
-    if (threadIdx.x == 0) {
-        gn_t[4] = __builtin_amdgcn_s_memrealtime();
-        for (int i = 0; i < 4; ++i) atomicAdd(&g_gn_phase[i], gn_t[i + 1] - gn_t[i]);
-        atomicAdd(&g_gn_phase[4], 1ull);
-    }
-#endif
-}
-
-// ------------------------------------------------------------------------------------ k_fin
-// Stand-alone launch of finish_iteration: the post-all-reduce solve of the multi-GPU path
-// (mode 2).  On a single GPU the last workgroup of k_gn runs it instead (no extra launch).
-__global__ __launch_bounds__(256) void k_fin(IcpState *st, const double *partials, int nparts,
-                                             int mode, int standalone) {
-    if (!standalone && st->done) return;
-    finish_iteration(st, partials, nparts, mode);
+    if (t > kCount && t < kNumSums) out[t] = 0.0;
 }
 
 // ------------------------------------------------------------------------------------ k_tf
@@ -892,18 +894,19 @@ extern "C" void sageicp_debug_gn_phases(unsigned long long out[16], int reset) {
 }
 #endif
 #ifdef SAGE_NN_TIMING
-extern "C" void sageicp_debug_nn_phases(unsigned long long out[8], int reset) {
-    // out: {sum head cycles, sum group cycles, sum wave lifetime, waves, max mean lifetime of a
-    //       chunk slot, slots used, 0, 0}
-    std::vector<unsigned long long> h(4ull * kNnTimingSlots);
+extern "C" void sageicp_debug_nn_phases(unsigned long long out[16], int reset) {
+    // out: [0..4] summed cycles of the five phases (loads, row, home scan, rest of the search,
+    // epilogue), [5] summed wave lifetime (shader cycles), [6] the same in 100-MHz ticks, [7] waves,
+    // [8] the slowest wave slot's mean lifetime (cycles), [9] slots used
+    std::vector<unsigned long long> h(8ull * kNnTimingSlots);
     (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_nn_phase), h.size() * sizeof(unsigned long long));
-    for (int i = 0; i < 8; ++i) out[i] = 0;
+    for (int i = 0; i < 16; ++i) out[i] = 0;
     for (unsigned s = 0; s < kNnTimingSlots; ++s) {
-        const unsigned long long *t = &h[4ull * s];
-        if (!t[3]) continue;
-        out[0] += t[0]; out[1] += t[1]; out[2] += t[2]; out[3] += t[3];
-        if (t[2] / t[3] > out[4]) out[4] = t[2] / t[3];
-        ++out[5];
+        const unsigned long long *t = &h[8ull * s];
+        if (!t[7]) continue;
+        for (int k = 0; k < 8; ++k) out[k] += t[k];
+        if (t[5] / t[7] > out[8]) out[8] = t[5] / t[7];
+        ++out[9];
     }
     if (reset) {
         std::fill(h.begin(), h.end(), 0ull);
@@ -926,11 +929,10 @@ __global__ __launch_bounds__(256) void k_scatter_slots(const uint32_t *idx, cons
     if (i < n) table[idx[i]] = vals[i];
 }
 
-// sums of k_nn's per-chunk counters {candidates in the neighbourhood, pairs evaluated} into the
-// loop state (one workgroup; it rides on the state copy the host makes anyway instead of a
-// read-back of the counters)
-__global__ __launch_bounds__(1024) void k_sum_candidates(const unsigned long long *c, int n,
-                                                         IcpState *st) {
+// sums of k_icp's per-wave counters {candidates in the neighbourhood, pairs handed out} into the
+// loop state (one workgroup; it rides on the state copy the host makes anyway)
+__global__ __launch_bounds__(1024) void k_sum_counters(const unsigned long long *c, int n,
+                                                       IcpState *st) {
     __shared__ unsigned long long part[2][16];
     unsigned long long v = 0, w = 0;
     for (int i = threadIdx.x; i < n; i += 1024) {
@@ -959,8 +961,8 @@ __global__ __launch_bounds__(1024) void k_sum_candidates(const unsigned long lon
 }
 
 // ------------------------------------------------------------------------------------ launchers
-void launch_sum_candidates(const unsigned long long *c, int n, IcpState *st, hipStream_t s) {
-    hipLaunchKernelGGL(k_sum_candidates, dim3(1), dim3(1024), 0, s, c, n, st);
+void launch_sum_counters(const unsigned long long *c, int n, IcpState *st, hipStream_t s) {
+    hipLaunchKernelGGL(k_sum_counters, dim3(1), dim3(1024), 0, s, c, n, st);
 }
 void launch_scatter_points(const uint32_t *idx, const Point4 *vals, uint32_t n, Point4 *pts,
                            hipStream_t s) {
@@ -971,44 +973,55 @@ void launch_scatter_slots(const uint32_t *idx, const Slot *vals, uint32_t n, Slo
     if (n) hipLaunchKernelGGL(k_scatter_slots, dim3((n + 255) / 256), dim3(256), 0, s, idx, vals, n, table);
 }
 
-int nn_grid_for(int n, int chunk) {
-    // one wave per chunk, 4 waves per workgroup, rounded up to whole stripes on all 8 XCDs
-    const long nchunks = (static_cast<long>(n) + chunk - 1) / chunk;
-    const long quads = (nchunks + kNnWaves - 1) / kNnWaves;
-    const long per_round = 8L * (SAGE_NN_STRIPE / SAGE_NN_WAVES);   // 8 XCDs x kStripe
-    const long blocks = ((quads + per_round - 1) / per_round) * per_round;
-    return static_cast<int>(blocks < per_round ? per_round : blocks);
+int icp_blocks_for(int n, int lw) {
+    // one wave per 64 >> lw queries, kIcpWavesPerBlock waves per workgroup, rounded up to whole
+    // stripes on all 8 XCDs
+    const long qw = 64 >> lw;
+    const long waves = (static_cast<long>(n) + qw - 1) / qw;
+    const long blocks = (waves + kIcpWavesPerBlock - 1) / kIcpWavesPerBlock;
+    const long per_round = 8L * SAGE_ICP_STRIPE;
+    const long r = ((blocks + per_round - 1) / per_round) * per_round;
+    return static_cast<int>(r < per_round ? per_round : r);
+}
+size_t icp_lds_bytes(int lw) {
+    return sizeof(uint32_t) * (kWgHeaderWords + kIcpWavesPerBlock * icp_wave_words(lw));
 }
 
-int gn_grid_for(int n) {
-    static const int cap = [] {
-        const char *v = std::getenv("SAGEICP_GN_BLOCKS");
-        int c = v ? std::atoi(v) : 128;   // measured best with the fused finish (ticket per block)
-        return c < 1 ? 1 : (c > kMaxGnBlocks ? kMaxGnBlocks : c);
-    }();
-    long blocks = (static_cast<long>(n) + 255) / 256;
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
-    return static_cast<int>(blocks);
-}
-
-
-void launch_nn(const NnParams &p, hipStream_t s) {
+void launch_rows(const IcpParams &p, hipStream_t s) {
     if (p.n <= 0) return;
-    const int grid = nn_grid_for(p.n, static_cast<int>(p.chunk));
-    const size_t lds = kNnWaves * nn_lds_layout(p.chunk).wave_words * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_nn, dim3(grid), dim3(64 * kNnWaves), lds, s, p);
+    hipLaunchKernelGGL(k_rows, dim3((p.n + 7) / 8), dim3(256), 0, s, p);
+}
+
+template <int LW>
+static void launch_icp_lw(const IcpParams &p, bool fused, hipStream_t s) {
+    const int grid = icp_blocks_for(p.n, LW);
+    const size_t lds = icp_lds_bytes(LW);
+    if (fused)
+        hipLaunchKernelGGL((k_icp<LW, true>), dim3(grid), dim3(64 * kIcpWavesPerBlock), lds, s, p);
+    else
+        hipLaunchKernelGGL((k_icp<LW, false>), dim3(grid), dim3(64 * kIcpWavesPerBlock), lds, s, p);
+}
+void launch_icp(const IcpParams &p, int lw, bool fused, hipStream_t s) {
+    if (p.n <= 0) return;
+    switch (lw) {
+        case 0: launch_icp_lw<0>(p, fused, s); break;
+        case 1: launch_icp_lw<1>(p, fused, s); break;
+        case 2: launch_icp_lw<2>(p, fused, s); break;
+        case 3: launch_icp_lw<3>(p, fused, s); break;
+        default: launch_icp_lw<4>(p, fused, s); break;
+    }
 }
 
 int launch_gn(const GnParams &p, hipStream_t s) {
-    const int grid = gn_grid_for(p.n);
-    hipLaunchKernelGGL(k_gn, dim3(grid), dim3(256), 0, s, p);
-    return grid;
+    long blocks = (static_cast<long>(p.n) + 255) / 256;
+    if (blocks > 128) blocks = 128;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_gn, dim3(static_cast<int>(blocks)), dim3(256), 0, s, p);
+    return static_cast<int>(blocks);
 }
 
-void launch_fin(IcpState *st, const double *partials, int nparts, int mode, int standalone,
-                hipStream_t s) {
-    hipLaunchKernelGGL(k_fin, dim3(1), dim3(256), 0, s, st, partials, nparts, mode, standalone);
+void launch_fin(const FinParams &p, hipStream_t s) {
+    hipLaunchKernelGGL(k_fin, dim3(1), dim3(kFinThreads), 0, s, p);
 }
 
 void launch_tf(Point4 *pts, int n, const IcpState *st, hipStream_t s) {

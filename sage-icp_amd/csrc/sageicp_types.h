@@ -55,12 +55,16 @@ constexpr int kNumSums = 20;               // 16 closed-form GN sums + count + 3
 constexpr int kHistory = 512;
 
 // Loop progress as the host sees it while the loop runs: a small block of pinned, host-mapped
-// memory the finishing lane writes after every iteration (the pose and one 64-bit word
-// (done << 32) | iterations, write-through stores), polled by run_icp to keep a few
-// iterations enqueued ahead of the GPU without a stream synchronisation per check.
+// memory the finishing lane writes after every iteration — the pose into slot (iteration % 16) of
+// a ring, then one 64-bit word (done << 32) | iterations, write-through stores — polled by run_icp
+// to keep a few iterations enqueued ahead of the GPU without a stream synchronisation per check.
+// The ring lets the host read the pose of a SPECIFIC iteration (the loop runs at most a handful of
+// iterations ahead of what the host has seen), so its re-sort decisions do not depend on timing.
+constexpr int kProgressRing = 16;
 struct IcpProgress {
-    unsigned long long word;   // (done << 32) | iterations completed
-    double T[7];               // cumulative pose after that many iterations
+    unsigned long long word;               // (done << 32) | iterations completed
+    unsigned long long pad_;
+    double T[kProgressRing][8];            // [it % 16]: cumulative pose after `it` iterations | it
 };
 
 // Direct exchange of the Gauss-Newton sums between the GPUs of one node (multi-GPU, no RCCL
@@ -91,7 +95,7 @@ struct IcpState {
     int32_t iter;       // iterations completed
     int32_t done;       // 1: converged or hit kMaxIterations -> later launches are no-ops
     int32_t converged;
-    uint32_t gn_ticket; // last-arriver ticket of k_gn (returns to 0 after every launch)
+    uint32_t pad0_;
     double sums[kNumSums];          // last reduced GN sums (diagnostics / multi-GPU exchange)
     unsigned long long sum_candidates;  // sum over launches and queries of C_q (roofline bytes)
     unsigned long long sum_pairs;       // (query, candidate) pairs k_nn actually evaluated

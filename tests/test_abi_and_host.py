@@ -28,8 +28,8 @@ def test_library_exports_every_declared_symbol(sage):
 
 
 def test_stats_struct_layout_matches_header(sage):
-    # 2*i32 + 3*u64 + 7*f64 + 2*u32 + u64 + 64*u32
-    assert ctypes.sizeof(sage.Stats) == 8 + 24 + 56 + 8 + 8 + 256
+    # 2*i32 + 3*u64 + 7*f64 + 2*u32 + u64 + 64*u32 + u64 + 2*u32
+    assert ctypes.sizeof(sage.Stats) == 8 + 24 + 56 + 8 + 8 + 256 + 8 + 8
 
 
 def test_no_oracle_in_product():
