@@ -106,6 +106,27 @@ SAGE_MIN_U32_DPP(min_u32_half_mirror, "row_half_mirror")
 SAGE_MIN_U32_DPP(min_u32_mirror, "row_mirror")
 #undef SAGE_MIN_U32_DPP
 
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+    return static_cast<unsigned>(
+        __builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), CTRL, 0xF, 0xF, false));
+}
+template <int W>
+__device__ __forceinline__ unsigned seg_or_u32(unsigned m) {   // over segments of W <= 16 lanes
+    if (W >= 2) m |= dpp_u32<kDppXor1>(m);
+    if (W >= 4) m |= dpp_u32<kDppXor2>(m);
+    if (W >= 8) m |= dpp_u32<kDppHalfMirror>(m);
+    if (W >= 16) m |= dpp_u32<kDppMirror>(m);
+    return m;
+}
+template <int W>
+__device__ __forceinline__ unsigned seg_add_u32(unsigned m) {
+    if (W >= 2) m += dpp_u32<kDppXor1>(m);
+    if (W >= 4) m += dpp_u32<kDppXor2>(m);
+    if (W >= 8) m += dpp_u32<kDppHalfMirror>(m);
+    if (W >= 16) m += dpp_u32<kDppMirror>(m);
+    return m;
+}
 template <int W>
 __device__ __forceinline__ double seg_min_f64(double m) {      // over segments of W <= 16 lanes
     if (W >= 2) m = min_f64(m, dpp_f64<kDppXor1>(m));
@@ -276,49 +297,85 @@ __global__ __launch_bounds__(64 * kIcpWavesPerBlock, SAGE_ICP_OCC) void k_icp(Ic
         const_cast<Point4 *>(P.pts), 0, static_cast<int>(P.pts_bytes), 0x00020000);
 
     // ---- prologue: the query, its home voxel, its neighbourhood row ------------------------------
+    // Everything the prologue needs is requested at once (one memory round trip): the row key, the
+    // frame point, the previous iteration's record and — speculatively, before the key has been
+    // checked — this lane's share of the cached row (words 0..27 in seven 16-B pieces).
+    constexpr int NP = (7 + W - 1) / W;        // pieces per lane
     const uint4 rk = *reinterpret_cast<const uint4 *>(grow + kRowKey);     // key x, y, z | occupancy
     uint4 prev = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);   // the previous iteration's record of this query
     if (FUSED) prev = P.nn_prev[qc];
     const Point4 f = P.frame[qc];
+    // (named registers, not an array: the compiler leaves a uint4 array in scratch memory)
+    auto row_piece = [&](int k) {
+        const unsigned p = min(ci + static_cast<unsigned>(W * k), 6u);
+        return *reinterpret_cast<const uint4 *>(grow + 4u * p);
+    };
+    uint4 pc0 = row_piece(0), pc1 = pc0, pc2 = pc0, pc3 = pc0, pc4 = pc0, pc5 = pc0, pc6 = pc0;
+    if (NP > 1) pc1 = row_piece(1);
+    if (NP > 2) pc2 = row_piece(2);
+    if (NP > 3) pc3 = row_piece(3);
+    if (NP > 4) pc4 = row_piece(4);
+    if (NP > 5) pc5 = row_piece(5);
+    if (NP > 6) pc6 = row_piece(6);
     const Query s = make_query(f, P.st, P.apply_pose, P.voxel_size);
     const bool stale = valid && (static_cast<uint32_t>(s.kx) != rk.x || static_cast<uint32_t>(s.ky) != rk.y ||
                                  static_cast<uint32_t>(s.kz) != rk.z);
     unsigned occ = rk.w;
     NN_T(0);
-    if (!stale) {                              // stage words 0..27 of the cached row in LDS
-        for (unsigned p = ci; p < 7u; p += W)
-            *reinterpret_cast<uint4 *>(lrow + 4u * p) = *reinterpret_cast<const uint4 *>(grow + 4u * p);
-    }
+    // stage the row in LDS (a stale one is overwritten below)
+    auto stage = [&](int k, const uint4 &v) {
+        const unsigned p = ci + static_cast<unsigned>(W * k);
+        if (p < 7u) *reinterpret_cast<uint4 *>(lrow + 4u * p) = v;
+    };
+    stage(0, pc0);
+    if (NP > 1) stage(1, pc1);
+    if (NP > 2) stage(2, pc2);
+    if (NP > 3) stage(3, pc3);
+    if (NP > 4) stage(4, pc4);
+    if (NP > 5) stage(5, pc5);
+    if (NP > 6) stage(6, pc6);
     if (__ballot(stale)) {
-        // Rare (a query crossed a voxel face since its row was built, ~1 % per iteration at the
-        // start of a cold registration, none near convergence): the stale lanes re-probe their 27
-        // voxels, three loads in flight, and write the row to LDS and back to the cache.
+        // Rare (a query crossed a voxel face since its row was built, a few % of the queries per
+        // iteration at the start of a cold registration, almost none near convergence): the lanes
+        // of a stale query share its 27 voxels, up to three probes in flight per lane, and write
+        // the row to LDS and back to the cache.
         if (stale) {
             unsigned o = 0u, cq = 0u;
+            constexpr int NV = (27 + W - 1) / W;          // voxels per lane
+            // one probe: first slot load issued by `start`, resolved (and the row word stored) by `finish`
+            auto start = [&](int v, uint32_t &sl, int4 &e) {
+                const int vc = v < 27 ? v : 26;
+                sl = voxel_hash(s.kx + vc / 9 - 1, s.ky + (vc / 3) % 3 - 1, s.kz + vc % 3 - 1) & P.mask;
+                e = reinterpret_cast<const int4 *>(P.table)[sl];
+            };
+            auto finish = [&](int v, uint32_t sl, const int4 &e) {
+                if (v >= 27) return;
+                const uint32_t w = probe_resolve(P.table, P.mask, sl, e, s.kx + v / 9 - 1,
+                                                 s.ky + (v / 3) % 3 - 1, s.kz + v % 3 - 1);
+                const unsigned c = (w == kEmptySlot) ? 0u : (w & 255u);
+                lrow[v] = w;
+                P.rows[static_cast<size_t>(q) * kRowWords + static_cast<unsigned>(v)] = w;
+                o |= (c != 0u ? 1u : 0u) << v;
+                cq += c;
+            };
 #pragma unroll 1
-            for (int a = 0; a < 9; ++a) {
-                const int vx = s.kx + a / 3 - 1, vy = s.ky + a % 3 - 1;
-                uint32_t sl[3];
-                int4 e[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    sl[k] = voxel_hash(vx, vy, s.kz + k - 1) & P.mask;
-                    e[k] = reinterpret_cast<const int4 *>(P.table)[sl[k]];
-                }
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const uint32_t w = probe_resolve(P.table, P.mask, sl[k], e[k], vx, vy, s.kz + k - 1);
-                    const unsigned c = (w == kEmptySlot) ? 0u : (w & 255u);
-                    const unsigned v = static_cast<unsigned>(3 * a + k);
-                    lrow[v] = w;
-                    o |= (c != 0u ? 1u : 0u) << v;
-                    cq += c;
-                    if (ci == 0u) P.rows[static_cast<size_t>(q) * kRowWords + v] = w;
-                }
+            for (int k0 = 0; k0 < NV; k0 += 3) {
+                const int v0 = static_cast<int>(ci) + W * k0;
+                const int v1 = k0 + 1 < NV ? v0 + W : 27, v2 = k0 + 2 < NV ? v0 + 2 * W : 27;
+                uint32_t s0, s1, s2;
+                int4 e0, e1, e2;
+                start(v0, s0, e0);
+                start(v1, s1, e1);
+                start(v2, s2, e2);
+                finish(v0, s0, e0);
+                finish(v1, s1, e1);
+                finish(v2, s2, e2);
             }
-            lrow[kRowCq] = cq;
+            o = seg_or_u32<W>(o);              // the lanes of a query are stale together
+            cq = seg_add_u32<W>(cq);
             occ = o;
             if (ci == 0u) {
+                lrow[kRowCq] = cq;
                 uint4 t;
                 t.x = static_cast<uint32_t>(s.kx); t.y = static_cast<uint32_t>(s.ky);
                 t.z = static_cast<uint32_t>(s.kz); t.w = o;
@@ -391,7 +448,7 @@ __global__ __launch_bounds__(64 * kIcpWavesPerBlock, SAGE_ICP_OCC) void k_icp(Ic
         unsigned ka, oa, ob;        // key / offset of a; b: key + W, offset ob
         bool ha, hb;
     };
-    auto scan = [&](unsigned need) {
+    auto scan = [&](unsigned need, const Point4 *seed, bool seeded, unsigned seed_key, unsigned seed_off) {
         auto issue = [&](Pair &n, bool &more) {
             while (i >= cnt && need) {         // open this lane's next voxel
                 const unsigned v = static_cast<unsigned>(__builtin_ctz(need));
@@ -422,6 +479,8 @@ __global__ __launch_bounds__(64 * kIcpWavesPerBlock, SAGE_ICP_OCC) void k_icp(Ic
         Pair A, B;
         bool more = false;
         issue(A, more);
+        // the seed's load is older than A's: waiting for it leaves A's loads in flight
+        if (seed && seeded) evaluate(*seed, seed_key, seed_off);
         for (;;) {
             issue(B, more);
             consume(A);
@@ -437,13 +496,14 @@ __global__ __launch_bounds__(64 * kIcpWavesPerBlock, SAGE_ICP_OCC) void k_icp(Ic
     // map is constant during a call): evaluated first, it gives every query — also one whose
     // home voxel is empty — a tight bound before anything is scanned.  It is an ordinary
     // candidate: meeting it again in the scan changes nothing.
+    constexpr unsigned kHome = 13u;
     if (FUSED) {
         const bool seeded = valid && !stale && prev.x != 0xFFFFFFFFu;
         const Point4 pp = load_point(pts, seeded ? prev.y : 0u);
-        if (seeded) evaluate(pp, prev.x, prev.y);
+        scan(occ & (1u << kHome), &pp, seeded, prev.x, prev.y);
+    } else {
+        scan(occ & (1u << kHome), nullptr, false, 0u, 0u);
     }
-    constexpr unsigned kHome = 13u;
-    scan(occ & (1u << kHome));
     NN_T(2);
     // what the query holds after its home voxel bounds the rest of its search
     const double bound = seg_min_f64<W>(best);
@@ -454,7 +514,7 @@ __global__ __launch_bounds__(64 * kIcpWavesPerBlock, SAGE_ICP_OCC) void k_icp(Ic
         const double lb = gx[v / 9] + (gy[(v / 3) % 3] + gz[v % 3]);
         need |= (lb <= bound) ? (1u << v) : 0u;
     }
-    scan(need & occ & ~(1u << kHome));
+    scan(need & occ & ~(1u << kHome), nullptr, false, 0u, 0u);
 
     // argmin over the W lanes of the query: first the minimum distance (never NaN: a NaN distance
     // fails every comparison), then the smallest key among the lanes that hold it, then the
