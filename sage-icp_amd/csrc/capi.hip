@@ -92,7 +92,6 @@ struct Scratch {
     // per-call work buffers: the queries' cached neighbourhood rows, the workgroup partials
     uint32_t *d_rows = nullptr;
     uint4 *d_prev = nullptr;       // every query's record of the previous iteration (kernels.h)
-    uint32_t *d_work = nullptr;    // map points every query looked at last iteration, pristine order
     double *d_partials = nullptr; size_t partials_cap = 0;
     unsigned long long *d_cand = nullptr;      // per-wave counters of k_icp [2 x sort_cap]
     IcpState *d_state = nullptr;
@@ -152,14 +151,12 @@ struct Scratch {
         if (d_sort_temp) HIPCHK(hipFree(d_sort_temp));
         if (d_rows) HIPCHK(hipFree(d_rows));
         if (d_prev) HIPCHK(hipFree(d_prev));
-        if (d_work) HIPCHK(hipFree(d_work));
-        d_rows = nullptr; d_prev = nullptr; d_work = nullptr;
+        d_rows = nullptr; d_prev = nullptr;
         d_sorted = nullptr; d_keys = d_vals = nullptr; d_sort_temp = nullptr; sort_cap = 0;
         const size_t cap = n + n / 4 + 1024;
         HIPCHK(hipMalloc(&d_sorted, cap * sizeof(Point4)));
         HIPCHK(hipMalloc(&d_rows, cap * kRowWords * sizeof(uint32_t)));
         HIPCHK(hipMalloc(&d_prev, cap * sizeof(uint4)));
-        HIPCHK(hipMalloc(&d_work, cap * sizeof(uint32_t)));
         if (d_cand) HIPCHK(hipFree(d_cand));
         d_cand = nullptr;
         HIPCHK(hipMalloc(&d_cand, 2 * cap * sizeof(unsigned long long)));
@@ -202,7 +199,6 @@ struct Scratch {
         if (d_sort_temp) (void)hipFree(d_sort_temp);
         if (d_rows) (void)hipFree(d_rows);
         if (d_prev) (void)hipFree(d_prev);
-        if (d_work) (void)hipFree(d_work);
         if (d_partials) (void)hipFree(d_partials);
         if (d_state) (void)hipFree(d_state);
         if (d_cand) (void)hipFree(d_cand);
@@ -490,10 +486,10 @@ int sync_mirror(const sageicp_map *m) {
         m->d_table_cap = h.table.size();
         table_full = true;
     }
-    const size_t blocks_cap = h.cnt.size();
+    // (the host arrays grow by doubling; the map itself never holds more than the addressable
+    // 2^27 point slots — HostMap::add_point refuses the voxel that would cross the limit)
     const size_t block_bytes = static_cast<size_t>(h.cap) * sizeof(Point4);
-    if (static_cast<uint64_t>(blocks_cap) * h.cap > kMaxMapPoints)
-        return fail(SAGEICP_ERR_CAPACITY, "voxel blocks x capacity beyond 2^27 points");
+    const size_t blocks_cap = std::min<size_t>(h.cnt.size(), kMaxMapPoints / static_cast<uint64_t>(h.cap));
     bool points_full = h.points_all_dirty || m->mirror_stale_all;
     if (blocks_cap > m->d_blocks_cap) {
         if (m->d_pts) HIPCHK(hipFree(m->d_pts));
@@ -881,12 +877,10 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     const Point4 *d_pristine = d_frame;
     double T_sorted[7];
     for (int i = 0; i < 7; ++i) T_sorted[i] = init[i];
-    // first: no iteration has run yet (no work estimate, nothing to carry over)
-    auto sort_now = [&](bool first) -> int {
-        if (first) HIPCHK(hipMemsetAsync(sc.d_work, 0, n * sizeof(uint32_t), s));
+    auto sort_now = [&]() -> int {
         HIPCHK(sort_frame(d_pristine, sc.d_sorted, static_cast<int>(n), sc.d_state, true,
                           m->host.voxel_size, sc.d_keys, sc.d_vals, sc.d_sort_temp,
-                          sc.sort_temp_bytes_, sc.d_work, first ? nullptr : sc.d_prev, s));
+                          sc.sort_temp_bytes_, s));
         launch_rows(ip, s);
         // the records of the last iteration were indexed by the old order
         HIPCHK(hipMemsetAsync(sc.d_prev, 0xFF, n * sizeof(uint4), s));
@@ -904,7 +898,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     // the loop: small frames keep their first order)
     const double resort_drift = 0.01 * env_int("SAGEICP_RESORT_PCT", 50) * m->host.voxel_size;
     const bool resort_on = n >= static_cast<uint64_t>(env_int("SAGEICP_RESORT_MIN_N", 40000));
-    if (n > 0 && (rc = sort_now(true))) return rc;
+    if (n > 0 && (rc = sort_now())) return rc;
 
     FinParams fp{};
     fp.st = sc.d_state;
@@ -960,9 +954,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     // Re-sorts are decided at fixed points of the enqueue sequence from the pose of a fixed
     // iteration, and the sort runs on whatever pose the device holds when the stream reaches it:
     // nothing depends on when the host happens to look (results are reproducible bit for bit).
-    //   before iteration 2: order by the work iteration 1 measured (its searches were seeded);
-    //   before iterations 8, 16, ...: again when the pose has drifted.
-    const int balance_at = env_int("SAGEICP_BALANCE_AT", 2);
+    // Checked before iterations 8, 16, ...: has the pose drifted half a voxel from the sorted order?
     if (polled) {
         const int depth = std::min(8, std::max(1, env_int("SAGEICP_DEPTH", 4)));
         volatile unsigned long long *word = &sc.h_prog->word;
@@ -973,17 +965,14 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
             const int comp = static_cast<int>(w & 0xFFFFFFFFull);
             if (w >> 32) break;                                  // converged or out of iterations
             if (enq < kMaxIterations && enq - comp < depth) {
-                if (resort_on && enq == balance_at) {
-                    if ((rc = sort_now(false))) return rc;
-                    ++resorts;
-                } else if (resort_on && enq >= 8 && (enq & 7) == 0) {
+                if (resort_on && enq >= 8 && (enq & 7) == 0) {
                     const int j = std::max(1, enq - depth + 1);   // completed: comp > enq - depth
                     volatile double *slot = sc.h_prog->T[j % kProgressRing];
                     __atomic_thread_fence(__ATOMIC_ACQUIRE);
                     double Tj[7];
                     for (int i = 0; i < 7; ++i) Tj[i] = slot[i];
                     if (slot[7] == static_cast<double>(j) && drift(Tj, T_sorted) > resort_drift) {
-                        if ((rc = sort_now(false))) return rc;
+                        if ((rc = sort_now())) return rc;
                         for (int i = 0; i < 7; ++i) T_sorted[i] = Tj[i];
                         ++resorts;
                     }
@@ -1027,8 +1016,8 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
             }
             launched += todo;
             if (sc.h_state->done || launched >= kMaxIterations) break;
-            if (resort_on && (launched == 4 || drift(sc.h_state->T, T_sorted) > resort_drift)) {
-                if ((rc = sort_now(false))) return rc;          // by work after the first chunk, by drift later
+            if (resort_on && drift(sc.h_state->T, T_sorted) > resort_drift) {
+                if ((rc = sort_now())) return rc;
                 for (int i = 0; i < 7; ++i) T_sorted[i] = sc.h_state->T[i];
                 ++resorts;
             }
@@ -1187,11 +1176,14 @@ uint64_t sageicp_map_num_voxels(const sageicp_map *m) {
 int sageicp_map_add_points(sageicp_map *m, const double *xyzl, uint64_t n) {
     if (!m || (n && !xyzl)) return fail(SAGEICP_ERR_INVALID, "null argument");
     if (int rc = ensure_host(m)) return rc;
-    m->host.add_points(xyzl, n);
-    if (m->host.blocks_hi >= (1u << kMaxBlockBits))
-        return fail(SAGEICP_ERR_CAPACITY, "more than 2^23 voxels");
-    if (static_cast<uint64_t>(m->host.cnt.size()) * m->host.cap > kMaxMapPoints)
-        return fail(SAGEICP_ERR_CAPACITY, "voxel blocks x capacity beyond 2^27 points");
+    uint64_t at = 0;
+    const int why = m->host.add_points(xyzl, n, &at);     // limits are checked before a point is taken
+    if (why == 1)
+        return fail(SAGEICP_ERR_CAPACITY, "map full (2^23 voxels / 2^27 point slots): stopped before point " +
+                                              std::to_string(at) + ", the points before it are in");
+    if (why == 2)
+        return fail(SAGEICP_ERR_CAPACITY, "voxel index beyond +-2^20: stopped before point " +
+                                              std::to_string(at) + ", the points before it are in");
     return SAGEICP_OK;
 }
 
@@ -1263,7 +1255,7 @@ int sageicp_get_correspondences(const sageicp_map *m, const double *q, uint64_t 
     // back to the caller's query order through the sort permutation
     HIPCHK(sort_frame(sc.d_frame, sc.d_sorted, static_cast<int>(n), sc.d_state, false,
                       m->host.voxel_size, sc.d_keys, sc.d_vals, sc.d_sort_temp, sc.sort_temp_bytes_,
-                      nullptr, nullptr, s));
+                      s));
     const int lw = icp_lw(n);
     const IcpParams ip = icp_params(m, sc.d_sorted, n, sem_th, lw);     // identity pose, no loop state
     launch_rows(ip, s);

@@ -24,6 +24,8 @@
 
 namespace sageicp {
 
+constexpr uint64_t kHostMaxPointSlots = (1ull << 27) - 2;   // == kMaxMapPoints (kernels.h): 32-B points under 4 GiB
+
 class HostMap {
 public:
     double voxel_size = 1.0;
@@ -84,8 +86,12 @@ public:
     // Sequential by definition (the retention policy is order dependent), and bound by cache
     // misses on the slot table and the point blocks: a two-stage software prefetch runs ahead of
     // the insertion cursor (slot line for point i+16, then count + block lines for point i+8).
-    void add_points(const double *xyzl, uint64_t n) {
+    // Returns 0, or the reason the insertion stopped before point `*stopped_at` (the map stays
+    // consistent: the points before it are in): 1 = block / point-slot limit, 2 = voxel index
+    // beyond +-2^20 (the device-side update and the tombstone key rely on that range).
+    int add_points(const double *xyzl, uint64_t n, uint64_t *stopped_at = nullptr) {
         constexpr uint64_t kFar = 16, kNear = 8;
+        int status = 0;
         for (uint64_t i = 0; i < n; ++i) {
             if (i + kFar < n) {
                 const double *p = xyzl + 4 * (i + kFar);
@@ -107,9 +113,14 @@ public:
                     }
                 }
             }
-            add_point(xyzl + 4 * i);
+            status = add_point(xyzl + 4 * i);
+            if (status) {
+                if (stopped_at) *stopped_at = i;
+                break;
+            }
         }
         if (n) ++generation;
+        return status;
     }
 
     void remove_far(const double origin[3]) {
@@ -251,15 +262,21 @@ private:
         return b;
     }
 
-    void add_point(const double *p) {
+    int add_point(const double *p) {
         // (v3point / voxel_size_).cast<int>(): fp64 divide, truncation toward zero
         const int32_t vx = static_cast<int32_t>(p[0] / voxel_size);
         const int32_t vy = static_cast<int32_t>(p[1] / voxel_size);
         const int32_t vz = static_cast<int32_t>(p[2] / voxel_size);
+        constexpr int32_t kLim = 1 << 20;
+        if (vx <= -kLim || vx >= kLim || vy <= -kLim || vy >= kLim || vz <= -kLim || vz >= kLim) return 2;
         uint32_t s = probe(vx, vy, vz);
         const Point4 np{p[0], p[1], p[2], p[3]};
         if (table[s].blk == kEmptySlot) {
             // new voxel: its first point is taken unconditionally (VoxelHashMap.cpp:171)
+            if (free_blocks.empty() &&
+                (blocks_hi + 1u >= (1u << kMaxBlockBits) ||
+                 (static_cast<uint64_t>(blocks_hi) + 1u) * static_cast<uint64_t>(cap) > kHostMaxPointSlots))
+                return 1;                    // checked BEFORE anything is touched
             if ((static_cast<uint64_t>(num_voxels) + 1) * 4 > table.size()) {
                 grow_table();
                 s = probe(vx, vy, vz);
@@ -274,7 +291,7 @@ private:
             ++total_points;
             mark_slot(s);
             mark_point(static_cast<size_t>(b) * cap);
-            return;
+            return 0;
         }
         const uint32_t b = table[s].blk >> 8;
         Point4 *blk = &pts[static_cast<size_t>(b) * cap];
@@ -302,10 +319,10 @@ private:
         };
         if (c < basic) {
             append();
-            return;
+            return 0;
         }
         const int label = static_cast<int>(p[3]);
-        if (label == 0) return;
+        if (label == 0) return 0;
         if (std::find(basic_labels.begin(), basic_labels.end(), label) != basic_labels.end()) {
             replace_first_unlabelled();
         } else if (c < basic + critical) {
@@ -313,6 +330,7 @@ private:
         } else {
             replace_first_unlabelled();
         }
+        return 0;
     }
 
     void erase_block(uint32_t b) {

@@ -48,8 +48,7 @@ struct IcpParams {
     uint4 *nn_prev;           // [n] in/out: every query's record of the previous iteration {key =
                               // (voxel << 8) | slot of its nearest neighbour, its byte offset,
                               // map points looked at, -}; key 0xFFFFFFFF: none (after a re-sort).
-                              // Seeds the next search with a tight bound; the third word orders
-                              // the next sort by work.
+                              // Seeds the next search with a tight bound.
     double *partials;         // out: [gridDim.x][kNumSums] one partial per workgroup
     unsigned long long *counters;  // optional: [2 x waves] running sums of {C_q, pairs evaluated}
     unsigned nwaves;          // waves that own queries: ceil(n / (64 >> lw))
@@ -127,6 +126,6 @@ hipError_t voxel_downsample_device(const VdsParams &P, void *sort_temp, size_t s
 size_t sort_temp_bytes(int n);
 hipError_t sort_frame(const Point4 *d_in, Point4 *d_out, int n, const IcpState *st, bool apply_pose,
                       double voxel_size, uint32_t *keys, uint32_t *vals, void *temp,
-                      size_t temp_bytes, uint32_t *work, const uint4 *prev, hipStream_t s);
+                      size_t temp_bytes, hipStream_t s);
 
 }  // namespace sageicp

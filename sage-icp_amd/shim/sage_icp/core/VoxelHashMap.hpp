@@ -48,7 +48,10 @@ struct VoxelHashMap {
           basic_points_per_voxel_(o.basic_points_per_voxel_),
           critical_points_per_voxel_(o.critical_points_per_voxel_),
           basic_parts_labels_(o.basic_parts_labels_),
-          map_(sageicp_map_clone(o.map_)) {}
+          map_(sageicp_map_clone(o.map_)) {
+        // a failed clone (HIP out of memory, device error) must not pass for an empty map
+        if (!map_) throw std::runtime_error(std::string("sageicp_map_clone: ") + sageicp_last_error());
+    }
     VoxelHashMap(VoxelHashMap &&o) noexcept
         : voxel_size_(o.voxel_size_),
           max_distance_(o.max_distance_),

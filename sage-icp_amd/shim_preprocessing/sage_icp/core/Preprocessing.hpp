@@ -1,11 +1,14 @@
-// Drop-in replacement for the reference header cpp/sage_icp/core/Preprocessing.hpp
+// OPTIONAL replacement for the reference header cpp/sage_icp/core/Preprocessing.hpp
 // (NeSC-IV/sage-icp @ 2024_10_08, lines 33-45): the same two free functions, running on the
-// MI355X through the C ABI of libsageicp_hip.so (preprocess.hip).  The reference's
-// Preprocessing.cpp — and with it the PCL dependency — is not compiled any more.
+// MI355X through the C ABI of libsageicp_hip.so (preprocess.hip).
 //
-// Preprocess() with dynamic_vehicle_filter == true (PCL Euclidean clustering,
-// Preprocessing.cpp:95-172) is not implemented: it throws.  Every pre-labelled configuration
-// (ros/launch/odometry_gt.launch.py) runs with the filter off.
+// Opt-in: this header lives in its own include root (sage-icp_amd/shim_preprocessing) and is NOT
+// part of the drop-in for the registration hot path.  Add that root only for configurations that
+// run with dynamic_vehicle_filter == false (ros/launch/odometry_gt.launch.py): the PCL Euclidean
+// clustering of Preprocessing.cpp:95-172 is not reproduced here, and Preprocess() throws when it
+// is asked for.  The reference's default SemanticKITTI launch (ros/launch/odometry.launch.py:50)
+// sets the filter to true — keep the reference's own Preprocessing.{hpp,cpp} there (the default
+// of INTEGRATION.md); registration still runs on the GPU.
 // VoxelDownsample() returns the survivors group by group in input order; the reference returns
 // them in tsl::robin_map bucket order (same set of points).
 #pragma once
@@ -15,7 +18,7 @@
 #include <string>
 #include <vector>
 
-#include "VoxelHashMap.hpp"
+#include "sage_icp/core/VoxelHashMap.hpp"
 #include "sageicp.h"
 
 namespace sage_icp {

@@ -16,6 +16,7 @@ def _build(tmp_path):
     cmd = ["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror",
            "-I", os.path.join(ROOT, "tests", "shim_stubs"),
            "-I", os.path.join(ROOT, "sage-icp_amd", "shim"),
+           "-I", os.path.join(ROOT, "sage-icp_amd", "shim_preprocessing"),   # opt-in
            "-I", os.path.join(ROOT, "include"),
            os.path.join(ROOT, "tests", "shim_stubs", "shim_user.cpp"),
            "-L", lib_dir, "-l:libsageicp_hip.so", "-Wl,-rpath," + lib_dir, "-o", exe]
@@ -35,3 +36,4 @@ def test_shim_runs_on_gpu(tmp_path, gpu_sage):
     exe = _build(tmp_path)
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert "planted pose recovered" in out.stdout      # RegisterFrame's answer is checked in the program
