@@ -54,7 +54,6 @@ static int env_int(const char *name, int dflt) {
 static int icp_lw(uint64_t n) {
     const int e = env_int("SAGEICP_LW", -1);
     if (e >= 0) return e > 4 ? 4 : e;
-    if (n >= 300000) return 1;
     if (n >= 50000) return 2;
     if (n >= 10000) return 3;
     return 4;

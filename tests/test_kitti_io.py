@@ -93,3 +93,46 @@ def test_kitti_format_stream_through_pipeline(tmp_path, gpu_sage, oracle):
     out = os.path.join(tmp_path, "path.txt")
     kitti_io.write_tum(out, kitti_io.read_timestamps(os.path.join(tmp_path, "times.txt")), a.poses())
     assert len(open(out).readlines()) == 5
+
+
+@pytest.mark.gpu
+def test_c3_stream_200_frames_with_kitti_correction(tmp_path, gpu_sage, oracle):
+    """BASELINE configs[2] at the length SURVEY 8d specifies: a 200-frame stream in KITTI file
+    format (sensor advancing 1 m and 0.5 deg per frame), read back WITH the 0.205 deg scan
+    correction, free-running through the GPU pipeline and through the oracle pipeline: per-frame
+    pose within the north-star tolerance, and the trajectory metrics of both agree."""
+    from sage_icp_amd import kitti_io, synthetic as syn
+    n_frames = 200
+    frames, truth = syn.make_stream(7, n_frames, points_per_frame=30000)
+    kitti_io.write_sequence(str(tmp_path), frames)
+    del frames
+    vel, lab = kitti_io.list_sequence(str(tmp_path))
+    assert len(vel) == n_frames
+    cfg = gpu_sage.make_pipeline_config()
+    a, b = gpu_sage.SageICP(cfg), oracle.Pipeline(cfg)
+    worst_t = worst_r = 0.0
+    pb_all = []
+    for v, l in zip(vel, lab):
+        f = kitti_io.load_frame(v, l, correct=True)
+        pa = a.RegisterFrame(f)[0]
+        pb = b.register_frame(f)[0]
+        pb_all.append(pb)
+        e = oracle.se3_log(oracle.se3_mul(oracle.se3_inv(pb), pa))
+        worst_t, worst_r = max(worst_t, np.linalg.norm(e[:3])), max(worst_r, np.linalg.norm(e[3:]))
+    assert worst_t < 1e-4 and worst_r < 1e-4, (worst_t, worst_r)
+
+    def mats(p7):
+        out = np.tile(np.eye(4), (len(p7), 1, 1))
+        for i, p in enumerate(p7):
+            out[i, :3, :3] = syn.quat_to_mat(np.asarray(p[:4]))
+            out[i, :3, 3] = p[4:]
+        return out
+    first = np.linalg.inv(mats(truth[:1])[0])
+    gt = np.array([first @ m for m in mats(truth)])
+    ta, ra = gpu_sage.seq_error(gt, mats(a.poses()))
+    tb, rb = gpu_sage.seq_error(gt, mats(np.array(pb_all)))
+    assert np.isfinite(ta) and abs(ta - tb) < 1e-3 and abs(ra - rb) < 1e-3
+    ate_r, ate_t = gpu_sage.absolute_trajectory_error(gt, mats(a.poses()))
+    assert np.isfinite(ate_t) and np.isfinite(ate_r)
+    print("c3 stream: worst GPU-vs-oracle pose delta %.3g m %.3g rad; seq err %.4f %% %.4f deg/100m; ATE %.4f m"
+          % (worst_t, worst_r, ta, ra, ate_t))
