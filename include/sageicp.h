@@ -167,8 +167,15 @@ int sageicp_comm_p2p_enabled(const sageicp_comm *comm);
  * with min_range < |p| < max_range, zero the label beyond label_max_range; order preserved.
  * sageicp_voxel_downsample: core/Preprocessing.cpp:44-84: per label group g, the first point that
  * falls into a voxel of size group_voxel_size[g] * vox_scale is kept; points whose label is in no
- * group are dropped.  Output is group by group in input order (the reference: hash-map order).
+ * group are dropped.  Output order: see sageicp_set_downsample_order (default: the reference's).
  * out: capacity n*4 doubles.  At most 8 groups; voxel indices must fit +-2^19. */
+/* Emission order of sageicp_voxel_downsample and of the pipeline's two down-sampling levels:
+ * 1 (default) = the reference's — the bucket order of the tsl::robin_map v1.0.1 its VoxelDownsample
+ * iterates (Preprocessing.cpp:76-82), replayed on the host from the survivors' voxel keys, so that
+ * the registered cloud and the map get exactly the points the reference's would; 0 = group by group
+ * in input order (no host step, ~1 ms less per 120k-pt frame; the poses of a free-running stream
+ * then differ from the reference's by centimetres at unchanged accuracy). */
+void sageicp_set_downsample_order(int reference_order);
 int sageicp_preprocess(const double *frame_xyzl, uint64_t n, double max_range, double min_range,
                        double label_max_range, double *out_xyzl, uint64_t *n_out, int device);
 int sageicp_voxel_downsample(const double *frame_xyzl, uint64_t n, int n_groups,

@@ -56,6 +56,12 @@ def lib():
         L.sgo_map_create.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int,
                                      C.POINTER(C.c_int), C.c_int]
         L.sgo_map_destroy.argtypes = [C.c_void_p]
+        L.sgo_set_robin_order.argtypes = [C.c_int]
+        L.sgo_robin_order_of.restype = C.c_uint64
+        L.sgo_robin_order_of.argtypes = [C.POINTER(C.c_int), C.c_uint64, C.POINTER(C.c_int), C.c_uint64,
+                                         _u64p, _u64p]
+        L.sgo_voxel_downsample.argtypes = [_dp, C.c_uint64, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                           _dp, C.c_double, _dp, _u64p]
         L.sgo_map_clear.argtypes = [C.c_void_p]
         L.sgo_map_empty.argtypes = [C.c_void_p]
         L.sgo_map_num_voxels.restype = C.c_uint64
@@ -236,6 +242,43 @@ class Map:
                                         kernel, sem_th, out.ctypes.data_as(_dp), C.byref(st),
                                         nthreads, max_iter)
         return out, st
+
+
+def set_robin_order(mode):
+    """How far the oracle follows tsl::robin_map v1.0.1 (emulated, sage_oracle.cpp RobinOrder):
+      False / 0   arrival-order emission, collect-then-erase sweep (deviations D2 + D3)
+      1           VoxelDownsample emission and Pointcloud() in bucket order (what the product does)
+      2           only the far-voxel sweep erases while iterating
+      True / 3    both: the reference's behaviour"""
+    lib().sgo_set_robin_order(3 if mode is True else int(mode))
+
+
+def voxel_downsample(frame, voxel_labels, voxel_size, vox_scale):
+    """one level of VoxelDownsample (Preprocessing.cpp:44-84); order per set_robin_order()"""
+    pts, pp = _d(frame)
+    n = pts.reshape(-1, 4).shape[0]
+    counts = (C.c_int * len(voxel_labels))(*[len(g) for g in voxel_labels])
+    flat = [l for g in voxel_labels for l in g]
+    labels = (C.c_int * max(len(flat), 1))(*flat)
+    sizes = (C.c_double * len(voxel_size))(*voxel_size)
+    out = np.empty((n, 4))
+    k = C.c_uint64(0)
+    lib().sgo_voxel_downsample(pp, n, len(voxel_labels), counts, labels, sizes, C.c_double(vox_scale),
+                               out.ctypes.data_as(_dp), C.byref(k))
+    return out[:k.value].copy()
+
+
+def robin_order_of(keys, erase=()):
+    """iteration order (indices into `keys`) and bucket count of the emulated tsl::robin_map after
+    inserting `keys` ((n,3) ints) and erasing `erase`"""
+    k = np.ascontiguousarray(keys, dtype=np.int32).reshape(-1, 3)
+    e = np.ascontiguousarray(erase, dtype=np.int32).reshape(-1, 3)
+    out = np.empty(len(k), dtype=np.uint64)
+    bc = C.c_uint64(0)
+    ip = C.POINTER(C.c_int)
+    m = lib().sgo_robin_order_of(k.ctypes.data_as(ip), len(k), e.ctypes.data_as(ip), len(e),
+                                 out.ctypes.data_as(_u64p), C.byref(bc))
+    return out[:m].astype(np.int64), int(bc.value)
 
 
 def num_threads():

@@ -42,11 +42,21 @@
 //       distance-tests an uninitialised Vector4d there (VoxelHashMap.cpp:80,111: UB).
 //   D2  RemovePointsFarFromLocation collects the far voxels first and erases them
 //       afterwards.  The reference erases while iterating a tsl::robin_map
-//       (VoxelHashMap.cpp:177-183), whose result depends on the library's bucket
-//       layout.
-//   D3  hash-map iteration order (Pointcloud() order, summation order) is that of
-//       this file's container, not tsl::robin_map's.  It never changes results
-//       beyond fp64 summation order.
+//       (VoxelHashMap.cpp:177-183): the entry that the backward-shift deletion moves
+//       into the bucket just erased is skipped by the iterator's ++ and survives
+//       until a later frame.
+//   D3  hash-map iteration order is that of this file's container, not
+//       tsl::robin_map's.  That matters on a STREAM: VoxelDownsample emits its
+//       survivors in bucket order (Preprocessing.cpp:76-82), the second down-sampling
+//       keeps the first point per voxel in THAT order, and AddPoints' retention policy
+//       and stored order depend on arrival order — so the registered cloud and the map
+//       differ point-wise (not statistically) from the reference's.
+//   Both can be switched to the reference's behaviour: sgo_set_robin_order(3) makes the
+//   down-sampling, Pointcloud() and the far-voxel sweep follow an emulation of
+//   tsl::robin_map v1.0.1 (RobinOrder below: power-of-two buckets grown from zero at load
+//   0.5, robin-hood displacement, backward-shift deletion, the reference's 20-bit
+//   VoxelHash).  tests/test_robin_order.py measures what the two choices cost on the
+//   200-frame c3 stream.
 
 #include <algorithm>
 #include <array>
@@ -78,6 +88,112 @@ struct VoxelHash {
         return ((1u << 20) - 1u) & (a * 73856093u ^ b * 19349663u ^ c * 83492791u);
     }
 };
+
+// ---------------------------------------------------------------- tsl::robin_map order
+// Emulation of the bucket array of tsl::robin_map<Voxel, T, VoxelHash> v1.0.1 with its default
+// policies (tsl::rh::power_of_two_growth_policy<2>, max load factor 0.5, min load factor 0,
+// StoreHash = false), restated from the published algorithm (the library is a FetchContent
+// dependency, 3rdparty/tsl_robin/tsl_robin.cmake:24, absent from this image):
+//   * default construction: 0 buckets; an insertion first grows the array when
+//     size() >= size_t(float(bucket_count) * 0.5f): 0 -> 2 -> 4 -> 8 ... (rehash_on_extreme_load)
+//   * bucket of a key: hash & (bucket_count - 1); insertion walks forward while its distance
+//     from the ideal bucket is <= the resident's, then swaps itself in and pushes the poorer
+//     residents on (insert_value_impl: swap only when strictly farther from home)
+//   * rehash: old buckets in index order, each re-inserted by the same rule
+//   * erase: clear the bucket, then shift the following entries back by one while their
+//     distance from home is > 0 (wrapping around the end of the array)
+//   * iteration: bucket 0 .. bucket_count-1, skipping empty ones
+// Not modelled: the growth forced by a probe distance beyond DIST_FROM_IDEAL_BUCKET_LIMIT (never
+// reached with <= 10^5 voxels per table).  Only the ORDER is emulated here; the payload is an
+// index into the caller's storage.
+struct RobinOrder {
+    struct Bucket {
+        int dist = -1;          // distance from the ideal bucket, -1 = empty
+        Voxel key{0, 0, 0};
+        size_t val = 0;
+    };
+    std::vector<Bucket> b;
+    size_t n = 0;
+
+    size_t mask() const { return b.size() - 1; }
+    static size_t hash(const Voxel &v) { return VoxelHash()(v); }
+
+    void place(Bucket e) {      // insert_value_on_rehash / insert_value_impl: e.dist is its current distance
+        size_t i = (hash(e.key) + static_cast<size_t>(e.dist)) & mask();
+        for (;;) {
+            if (e.dist > b[i].dist) {
+                if (b[i].dist < 0) { b[i] = e; return; }
+                std::swap(e, b[i]);
+            }
+            ++e.dist;
+            i = (i + 1) & mask();
+        }
+    }
+    void grow() {
+        std::vector<Bucket> old;
+        old.swap(b);
+        b.assign(old.empty() ? 2 : old.size() * 2, Bucket());
+        for (const Bucket &e : old)
+            if (e.dist >= 0) {
+                Bucket f = e;
+                f.dist = 0;
+                place(f);
+            }
+    }
+    long find(const Voxel &k) const {
+        if (b.empty()) return -1;
+        size_t i = hash(k) & mask();
+        for (int d = 0; d <= b[i].dist; ++d, i = (i + 1) & mask())
+            if (b[i].key == k) return static_cast<long>(i);
+        return -1;
+    }
+    // the key must be absent (callers test find() first, as the reference does)
+    void insert(const Voxel &k, size_t val) {
+        if (n >= static_cast<size_t>(static_cast<float>(b.size()) * 0.5f)) grow();
+        // the walk of insert_impl ends at the first bucket whose resident is closer to home
+        size_t i = hash(k) & mask();
+        int d = 0;
+        while (d <= b[i].dist) { ++d; i = (i + 1) & mask(); }
+        Bucket e;
+        e.dist = d; e.key = k; e.val = val;
+        place(e);
+        ++n;
+    }
+    void erase_at(size_t i) {
+        b[i] = Bucket();
+        --n;
+        size_t prev = i, j = (i + 1) & mask();
+        while (b[j].dist > 0) {
+            b[prev] = b[j];
+            --b[prev].dist;
+            b[j] = Bucket();
+            prev = j;
+            j = (j + 1) & mask();
+        }
+    }
+    template <class F>
+    void for_each(F f) const {
+        for (const Bucket &e : b)
+            if (e.dist >= 0) f(e.key, e.val);
+    }
+    // `for (auto &[k, v] : map) if (pred(k, v)) map.erase(k);` — the range-for's iterator steps
+    // to the next bucket after the body, so whatever the erase shifted into the current bucket
+    // is not visited in this sweep
+    template <class P, class E>
+    void sweep_erase(P pred, E on_erase) {
+        for (size_t i = 0; i < b.size(); ++i) {
+            if (b[i].dist < 0) continue;
+            if (pred(b[i].key, b[i].val)) {
+                on_erase(b[i].key, b[i].val);
+                erase_at(i);
+            }
+        }
+    }
+    void clear() { b.clear(); n = 0; }
+};
+
+int g_robin_order = 0;     // sgo_set_robin_order: bit 0 = VoxelDownsample emission and Pointcloud() in bucket
+                           // order, bit 1 = the far-voxel sweep erases while iterating
 
 // core/VoxelHashMap.hpp:39-71
 struct Block {
@@ -116,6 +232,7 @@ struct Map {
     int critical;
     std::vector<int> basic_labels;
     std::unordered_map<Voxel, Block, VoxelHash> map;
+    RobinOrder order;          // the bucket layout tsl::robin_map would have (kept in step with `map`)
 };
 
 // ---------------------------------------------------------------- SO3 / SE3 (Sophus 1.22)
@@ -418,7 +535,12 @@ void *sgo_map_create(double voxel_size, double max_distance, int basic, int crit
     return m;
 }
 void sgo_map_destroy(void *h) { delete static_cast<Map *>(h); }
-void sgo_map_clear(void *h) { static_cast<Map *>(h)->map.clear(); }
+void sgo_map_clear(void *h) {
+    static_cast<Map *>(h)->map.clear();
+    static_cast<Map *>(h)->order.clear();
+}
+void sgo_set_robin_order(int mask) { g_robin_order = mask; }
+int sgo_get_robin_order(void) { return g_robin_order; }
 int sgo_map_empty(const void *h) { return static_cast<const Map *>(h)->map.empty() ? 1 : 0; }
 uint64_t sgo_map_num_voxels(const void *h) { return static_cast<const Map *>(h)->map.size(); }
 uint64_t sgo_map_size(const void *h) {
@@ -440,21 +562,33 @@ void sgo_map_add_points(void *h, const double *xyzl, uint64_t n) {
             // a new voxel takes its first point unconditionally (VoxelHashMap.cpp:171)
             Block b{{p}, m.basic, m.critical, &m.basic_labels};
             m.map.emplace(v, std::move(b));
+            m.order.insert(v, 0);
         }
     }
 }
 
-// VoxelHashMap.cpp:176-184 (deviation D2: collect, then erase)
+// VoxelHashMap.cpp:176-184 (default: deviation D2, collect then erase; with
+// sgo_set_robin_order(1): erase while iterating the emulated robin_map, as the reference does)
 void sgo_map_remove_far(void *h, const double origin[3]) {
     Map &m = *static_cast<Map *>(h);
     const double max_distance2 = m.max_distance * m.max_distance;
-    std::vector<Voxel> far;
-    for (const auto &kv : m.map) {
-        const Vec4 &pt = kv.second.points.front();
+    auto is_far = [&](const Voxel &v) {
+        const Vec4 &pt = m.map.find(v)->second.points.front();
         const double dx = pt[0] - origin[0], dy = pt[1] - origin[1], dz = pt[2] - origin[2];
-        if (dx * dx + (dy * dy + dz * dz) > max_distance2) far.push_back(kv.first);
+        return dx * dx + (dy * dy + dz * dz) > max_distance2;
+    };
+    if (g_robin_order & 2) {
+        m.order.sweep_erase([&](const Voxel &v, size_t) { return is_far(v); },
+                            [&](const Voxel &v, size_t) { m.map.erase(v); });
+        return;
     }
-    for (const auto &v : far) m.map.erase(v);
+    std::vector<Voxel> far;
+    for (const auto &kv : m.map)
+        if (is_far(kv.first)) far.push_back(kv.first);
+    for (const auto &v : far) {
+        m.map.erase(v);
+        m.order.erase_at(static_cast<size_t>(m.order.find(v)));
+    }
 }
 
 // VoxelHashMap.cpp:149-160 + :144-147
@@ -470,12 +604,18 @@ void sgo_map_update_pose(void *h, const double *xyzl, uint64_t n, const double T
 
 // VoxelHashMap.cpp:132-142
 uint64_t sgo_map_pointcloud(const void *h, double *out_xyzl, uint64_t cap) {
+    const Map &m = *static_cast<const Map *>(h);
     uint64_t n = 0;
-    for (const auto &kv : static_cast<const Map *>(h)->map)
-        for (const auto &p : kv.second.points) {
+    auto emit = [&](const Block &blk) {
+        for (const auto &p : blk.points) {
             if (n < cap) std::memcpy(out_xyzl + 4 * n, p.data(), 32);
             ++n;
         }
+    };
+    if (g_robin_order & 1)
+        m.order.for_each([&](const Voxel &v, size_t) { emit(m.map.find(v)->second); });
+    else
+        for (const auto &kv : m.map) emit(kv.second);
     return n;
 }
 
@@ -701,8 +841,10 @@ struct OraclePipeline {
 static void oracle_voxel_downsample(const OraclePipeline &P, const std::vector<double> &in,
                                     double scale, std::vector<double> &out) {
     const size_t G = P.groups.size();
-    std::vector<std::unordered_map<Voxel, char, VoxelHash>> grid(G);
-    std::vector<std::vector<double>> kept(G);
+    // (Preprocessing.cpp:50-56 reserves copies it never uses: the grids that ARE used, indices
+    // 0..G-1, are default-constructed and grow from zero buckets)
+    std::vector<RobinOrder> grid(G);
+    std::vector<std::vector<size_t>> kept(G);          // arrival order per group (default emission)
     for (size_t i = 0; i < in.size() / 4; ++i) {
         const double *p = &in[4 * i];
         const int label = static_cast<int>(p[3]);
@@ -716,13 +858,23 @@ static void oracle_voxel_downsample(const OraclePipeline &P, const std::vector<d
         const double vs = P.group_voxel[group] * scale;
         const Voxel v{static_cast<int>(p[0] / vs), static_cast<int>(p[1] / vs),
                       static_cast<int>(p[2] / vs)};
-        if (grid[group].count(v)) continue;
-        grid[group].emplace(v, 0);
-        kept[group].insert(kept[group].end(), p, p + 4);
+        if (grid[group].find(v) >= 0) continue;
+        grid[group].insert(v, i);
+        kept[group].push_back(i);
     }
     out.clear();
-    for (size_t g = 0; g < G; ++g) out.insert(out.end(), kept[g].begin(), kept[g].end());
+    for (size_t g = 0; g < G; ++g) {
+        if (g_robin_order & 1)  // Preprocessing.cpp:76-82: bucket order of the group's robin_map
+            grid[g].for_each([&](const Voxel &, size_t i) { out.insert(out.end(), &in[4 * i], &in[4 * i] + 4); });
+        else
+            for (size_t i : kept[g]) out.insert(out.end(), &in[4 * i], &in[4 * i] + 4);
+    }
 }
+
+// stand-alone entry for tests: one level of VoxelDownsample
+void sgo_voxel_downsample(const double *frame, uint64_t n, int n_groups, const int *group_label_counts,
+                          const int *group_labels, const double *group_voxel_size, double scale,
+                          double *out, uint64_t *n_out);
 
 void *sgo_pipeline_create(const sgo_pipeline_config *c) {
     OraclePipeline *P = new OraclePipeline;
@@ -754,7 +906,7 @@ int sgo_pipeline_register_frame(void *h, const double *frame, uint64_t n, double
     std::vector<double> cropped;
     for (uint64_t i = 0; i < n; ++i) {
         const double *p = frame + 4 * i;
-        const double norm = std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+        const double norm = std::sqrt(p[0] * p[0] + (p[1] * p[1] + p[2] * p[2]));   // Eigen's reduction order
         if (norm < c.max_range && norm > c.min_range) {
             const double l = (norm > c.label_max_range) ? 0.0 : p[3];
             cropped.insert(cropped.end(), {p[0], p[1], p[2], l});
@@ -811,6 +963,41 @@ int sgo_pipeline_register_frame(void *h, const double *frame, uint64_t n, double
     if (n_source) *n_source = source.size() / 4;
     if (sigma_out) *sigma_out = sigma;
     return 0;
+}
+
+void sgo_voxel_downsample(const double *frame, uint64_t n, int n_groups, const int *group_label_counts,
+                          const int *group_labels, const double *group_voxel_size, double scale,
+                          double *out, uint64_t *n_out) {
+    OraclePipeline P;
+    const int *gl = group_labels;
+    for (int g = 0; g < n_groups; ++g) {
+        P.groups.emplace_back(gl, gl + group_label_counts[g]);
+        gl += group_label_counts[g];
+        P.group_voxel.push_back(group_voxel_size[g]);
+    }
+    std::vector<double> in(frame, frame + 4 * n), res;
+    oracle_voxel_downsample(P, in, scale, res);
+    std::memcpy(out, res.data(), res.size() * sizeof(double));
+    *n_out = res.size() / 4;
+}
+
+// the emulated robin_map on its own (tests): inserts `keys` (n x 3 ints, absent keys only), erases
+// `erase` (m x 3), returns the iteration order as indices into `keys`
+uint64_t sgo_robin_order_of(const int *keys, uint64_t n, const int *erase, uint64_t m, uint64_t *order_out,
+                            uint64_t *bucket_count) {
+    RobinOrder r;
+    for (uint64_t i = 0; i < n; ++i) {
+        const Voxel v{keys[3 * i], keys[3 * i + 1], keys[3 * i + 2]};
+        if (r.find(v) < 0) r.insert(v, i);
+    }
+    for (uint64_t i = 0; i < m; ++i) {
+        const long at = r.find(Voxel{erase[3 * i], erase[3 * i + 1], erase[3 * i + 2]});
+        if (at >= 0) r.erase_at(static_cast<size_t>(at));
+    }
+    uint64_t k = 0;
+    r.for_each([&](const Voxel &, size_t i) { order_out[k++] = i; });
+    if (bucket_count) *bucket_count = r.b.size();
+    return k;
 }
 
 }  // extern "C"

@@ -12,7 +12,7 @@ for k, spec in enumerate(sys.argv[1:] or [""]):
     if flags not in built:
         out = os.path.join(ROOT, "gpurun_out/libsageicp_var%d.so" % len(built))
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                               "-ffp-contract=off"] + flags.split() + src + ["-o", out, "-ldl"])
+                               "-ffp-contract=off"] + flags.split() + src + ["-o", out, "-ldl", "-lpthread"])
         built[flags] = out
     env = dict(os.environ, KNOB_CHILD=spec.strip() or "(default)", KNOB_LIB=built[flags])
     for kv in envs.split():

@@ -115,6 +115,7 @@ _SIGNATURES = [
     ("sageicp_last_error", C.c_char_p, []),
     ("sageicp_device_count", C.c_int, []),
     ("sageicp_set_profiling", None, [C.c_int]),
+    ("sageicp_set_downsample_order", None, [C.c_int]),
     ("sageicp_map_create", C.c_void_p,
      [C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]),
     ("sageicp_map_destroy", None, [C.c_void_p]),
@@ -202,6 +203,11 @@ def _d(a):
 
 def device_count():
     return int(lib().sageicp_device_count())
+
+
+def set_downsample_order(reference_order=True):
+    """True (default): VoxelDownsample emits in the reference's robin_map bucket order; False: arrival order"""
+    lib().sageicp_set_downsample_order(1 if reference_order else 0)
 
 
 def set_profiling(level):

@@ -24,6 +24,8 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/sageicp.h"
@@ -32,6 +34,7 @@
 #include "map_update.h"
 #include "metrics.hpp"
 #include "pipeline.hpp"
+#include "robin_order.hpp"
 #include "se3_math.h"
 #include "sageicp_types.h"
 
@@ -40,6 +43,9 @@ namespace sageicp {
 // ---- errors --------------------------------------------------------------------------
 static thread_local std::string g_err;
 static int g_profiling = 0;
+// VoxelDownsample emits its survivors in the reference's order (the bucket order of its
+// tsl::robin_map, replayed on the host: robin_order.hpp) unless switched to arrival order
+static int g_reference_order = 1;
 
 // tuning knobs (defaults chosen by measurement on MI355X; the environment overrides are for
 // experiments only)
@@ -220,6 +226,11 @@ struct Prep {
     uint32_t table_cap = 0;
     void *d_sort_temp = nullptr;
     size_t sort_bytes = 0;
+    unsigned long long *d_okeys = nullptr;   // survivors' voxel keys (reference-order emission)
+    uint32_t *d_perm = nullptr;
+    std::vector<unsigned long long> h_keys;
+    std::vector<uint32_t> h_hash, h_perm;
+    double us_order = 0;                // host time of the last run's order replays
     uint32_t *d_nkept = nullptr;        // [2]
     int *d_overflow = nullptr;
     int *d_gcounts = nullptr, *d_glabels = nullptr;
@@ -263,6 +274,8 @@ struct Prep {
         HIPCHK(hipMalloc(&d_sval, 2 * c * sizeof(uint32_t)));
         HIPCHK(hipMalloc(&d_keys, static_cast<size_t>(t) * sizeof(unsigned long long)));
         HIPCHK(hipMalloc(&d_winner, static_cast<size_t>(t) * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&d_okeys, c * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc(&d_perm, c * sizeof(uint32_t)));
         table_cap = t;
         sort_bytes = vds_sort_temp_bytes(static_cast<int>(c));
         HIPCHK(hipMalloc(&d_sort_temp, sort_bytes));
@@ -281,6 +294,9 @@ struct Prep {
         if (d_sval) (void)hipFree(d_sval);
         if (d_keys) (void)hipFree(d_keys);
         if (d_winner) (void)hipFree(d_winner);
+        if (d_okeys) (void)hipFree(d_okeys);
+        if (d_perm) (void)hipFree(d_perm);
+        d_okeys = nullptr; d_perm = nullptr;
         if (d_sort_temp) (void)hipFree(d_sort_temp);
         if (h_pin) (void)hipHostFree(h_pin);
         d_in = d_tmp = d_fd = d_src = nullptr;
@@ -308,6 +324,7 @@ struct Prep {
             const double *gvs, const int *crop, const double *scales, int n_levels,
             std::vector<std::vector<double>> &out, bool download = true) {
         kept_levels[0] = kept_levels[1] = 0;
+        us_order = 0;
         if (n > kMaxQueries) return fail(SAGEICP_ERR_INVALID, "frame too large (2^26 points max)");
         if (n_groups > 8) return fail(SAGEICP_ERR_INVALID, "at most 8 label groups");
         size_t nlabels = 0;
@@ -338,12 +355,61 @@ struct Prep {
             P.keys = d_keys; P.winner = d_winner; P.mask = table_cap - 1;
             P.tmp = d_tmp; P.slot_of = d_slot; P.sort_key = d_skey; P.sort_val = d_sval;
             P.overflow = d_overflow;
+            const bool reorder = g_reference_order && P.n_groups > 0;
+            P.out_keys = reorder ? d_okeys : nullptr;
             Point4 *dst = outs[l & 1];
             HIPCHK(voxel_downsample_device(P, d_sort_temp, sort_bytes, d_nkept + (l & 1), dst, stream));
             uint32_t kept = 0;
             HIPCHK(hipMemcpyAsync(&kept, d_nkept + (l & 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
             kept_levels[l & 1] = kept;
+            if (reorder && kept) {
+                // the reference's emission order (Preprocessing.cpp:76-82): replay, group by
+                // group, the insertions into its robin_map and permute the survivors
+                const double t0 = now_us();
+                h_keys.resize(kept);
+                HIPCHK(hipMemcpyAsync(h_keys.data(), d_okeys, kept * sizeof(unsigned long long),
+                                      hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+                h_hash.resize(kept);
+                h_perm.clear();
+                h_perm.reserve(kept);
+                const long long B = 1ll << 19;
+                for (uint32_t i = 0; i < kept; ++i) {
+                    const unsigned long long k = h_keys[i];
+                    h_hash[i] = reference_voxel_hash(static_cast<int32_t>(static_cast<long long>((k >> 40) & 0xFFFFFu) - B),
+                                                     static_cast<int32_t>(static_cast<long long>((k >> 20) & 0xFFFFFu) - B),
+                                                     static_cast<int32_t>(static_cast<long long>(k & 0xFFFFFu) - B));
+                }
+                // survivors are grouped (stable sort by group); the groups' tables are independent:
+                // one host thread per group
+                std::vector<std::pair<uint32_t, uint32_t>> runs;
+                for (uint32_t a = 0; a < kept;) {
+                    uint32_t b = a;
+                    while (b < kept && (h_keys[b] >> 60) == (h_keys[a] >> 60)) ++b;
+                    runs.emplace_back(a, b);
+                    a = b;
+                }
+                std::vector<std::vector<uint32_t>> parts(runs.size());
+                auto replay = [&](size_t r) {
+                    parts[r].reserve(runs[r].second - runs[r].first);
+                    RobinOrderReplay::iteration_order(h_hash.data() + runs[r].first,
+                                                      runs[r].second - runs[r].first, runs[r].first, parts[r]);
+                };
+                if (kept > 16384 && runs.size() > 1) {
+                    std::vector<std::thread> th;
+                    for (size_t r = 1; r < runs.size(); ++r) th.emplace_back(replay, r);
+                    replay(0);
+                    for (auto &t : th) t.join();
+                } else {
+                    for (size_t r = 0; r < runs.size(); ++r) replay(r);
+                }
+                for (const auto &part : parts) h_perm.insert(h_perm.end(), part.begin(), part.end());
+                HIPCHK(hipMemcpyAsync(d_perm, h_perm.data(), kept * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+                launch_vds_permute(dst, d_perm, kept, d_tmp, stream);
+                HIPCHK(hipMemcpyAsync(dst, d_tmp, kept * sizeof(Point4), hipMemcpyDeviceToDevice, stream));
+                us_order += now_us() - t0;
+            }
             if (download) {       // otherwise the level's cloud stays in d_fd / d_src for the caller
                 char *hp = static_cast<char *>(h_pin) + static_cast<size_t>(1 + (l & 1)) * cap * sizeof(Point4);
                 if (kept) HIPCHK(hipMemcpyAsync(hp, dst, kept * sizeof(Point4), hipMemcpyDeviceToHost, stream));
@@ -1069,6 +1135,7 @@ int sageicp_device_count(void) {
     return c;
 }
 void sageicp_set_profiling(int level) { g_profiling = level; }
+void sageicp_set_downsample_order(int reference_order) { g_reference_order = reference_order ? 1 : 0; }
 
 // ---- map ----------------------------------------------------------------------------------
 sageicp_map *sageicp_map_create(double voxel_size, double max_distance, int basic, int critical,

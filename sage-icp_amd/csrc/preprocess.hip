@@ -102,10 +102,27 @@ __global__ __launch_bounds__(256) void k_vds_count(const uint32_t *sorted_key, i
     if (i == n - 1 && !here) *n_kept = static_cast<uint32_t>(n);
 }
 
+// survivors in group-major arrival order; optionally their (group, voxel) keys for the host's
+// replay of the reference's emission order (robin_order.hpp)
 __global__ __launch_bounds__(256) void k_vds_gather(const Point4 *tmp, const uint32_t *sorted_val,
-                                                    const uint32_t *n_kept, Point4 *out) {
+                                                    const uint32_t *n_kept, Point4 *out,
+                                                    const uint32_t *slot_of,
+                                                    const unsigned long long *keys,
+                                                    unsigned long long *out_keys) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < *n_kept) out[i] = tmp[sorted_val[i]];
+    if (i >= *n_kept) return;
+    const uint32_t src = sorted_val[i];
+    out[i] = tmp[src];
+    if (out_keys) out_keys[i] = keys[slot_of[src]];
+}
+
+__global__ __launch_bounds__(256) void k_vds_permute(const Point4 *in, const uint32_t *perm, uint32_t n,
+                                                     Point4 *out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[perm[i]];
+}
+void launch_vds_permute(const Point4 *in, const uint32_t *perm, uint32_t n, Point4 *out, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_vds_permute, dim3((n + 255) / 256), dim3(256), 0, s, in, perm, n, out);
 }
 
 size_t vds_sort_temp_bytes(int n) {
@@ -133,7 +150,8 @@ hipError_t voxel_downsample_device(const VdsParams &P, void *sort_temp, size_t s
                                            P.sort_val, P.sort_val + P.n, P.n, 0, 4, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_vds_count, dim3(grid), dim3(256), 0, s, P.sort_key + P.n, P.n, d_n_kept);
-    hipLaunchKernelGGL(k_vds_gather, dim3(grid), dim3(256), 0, s, P.tmp, P.sort_val + P.n, d_n_kept, out);
+    hipLaunchKernelGGL(k_vds_gather, dim3(grid), dim3(256), 0, s, P.tmp, P.sort_val + P.n, d_n_kept, out,
+                       P.slot_of, P.keys, P.n_groups >= 0 ? P.out_keys : nullptr);
     return hipGetLastError();
 }
 

@@ -9,8 +9,9 @@
 // is asked for.  The reference's default SemanticKITTI launch (ros/launch/odometry.launch.py:50)
 // sets the filter to true — keep the reference's own Preprocessing.{hpp,cpp} there (the default
 // of INTEGRATION.md); registration still runs on the GPU.
-// VoxelDownsample() returns the survivors group by group in input order; the reference returns
-// them in tsl::robin_map bucket order (same set of points).
+// VoxelDownsample() returns the survivors in the reference's order — the bucket order of its
+// tsl::robin_map, replayed by the library (csrc/robin_order.hpp) — unless
+// sageicp_set_downsample_order(0) selects the faster group-by-group input order.
 #pragma once
 
 #include <Eigen/Core>

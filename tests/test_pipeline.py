@@ -20,7 +20,7 @@ def _sorted(a):
 
 
 @pytest.mark.gpu
-def test_first_frame_preprocessing_and_map_update_match_oracle(gpu_sage, oracle):
+def test_first_frame_preprocessing_and_map_update_match_oracle(gpu_sage, oracle, reference_emission_order):
     sage = gpu_sage
     from sage_icp_amd import synthetic as syn
     frames, _ = syn.make_stream(7, 1, points_per_frame=40000)
@@ -48,7 +48,7 @@ def test_first_frame_preprocessing_and_map_update_match_oracle(gpu_sage, oracle)
 
 
 @pytest.mark.gpu
-def test_downsample_keeps_first_point_per_voxel_per_group(gpu_sage, oracle):
+def test_downsample_keeps_first_point_per_voxel_per_group(gpu_sage, oracle, reference_emission_order):
     sage = gpu_sage
     # two label groups with different voxel sizes; second point in the same voxel is dropped
     cfg = sage.make_pipeline_config(voxel_labels=[[40], [50]], voxel_size=[1.0, 4.0], min_range=0.1)
@@ -67,7 +67,7 @@ def test_downsample_keeps_first_point_per_voxel_per_group(gpu_sage, oracle):
 
 
 @pytest.mark.gpu
-def test_stream_pose_parity_restarted_and_free_running(gpu_sage, oracle):
+def test_stream_pose_parity_restarted_and_free_running(gpu_sage, oracle, reference_emission_order):
     from sage_icp_amd import synthetic as syn
     frames, truth = syn.make_stream(11, 12, points_per_frame=30000)
     cfg = gpu_sage.make_pipeline_config()
@@ -96,7 +96,7 @@ def test_stream_pose_parity_restarted_and_free_running(gpu_sage, oracle):
 def _py_preprocess(frame, max_range, min_range, label_max_range):
     out = []
     for p in frame:
-        norm = float(np.sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]))
+        norm = float(np.sqrt(p[0] * p[0] + (p[1] * p[1] + p[2] * p[2])))     # Eigen's reduction order
         if norm < max_range and norm > min_range:
             out.append([p[0], p[1], p[2], 0.0 if norm > label_max_range else p[3]])
     return np.array(out).reshape(-1, 4)
@@ -133,17 +133,30 @@ def test_device_preprocess_matches_python(gpu_sage):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("scale", [0.5, 1.5])
-def test_device_voxel_downsample_matches_python(gpu_sage, scale):
+def test_device_voxel_downsample_matches_python(gpu_sage, oracle, scale):
     from sage_icp_amd import synthetic as syn
     frames, _ = syn.make_stream(33, 1, points_per_frame=60000)
     f = frames[0]
     f[::19, 3] = 77                                     # label of no group -> dropped
     f[1::23, :3] *= -1.0                                # negative coordinates: trunc toward zero
     labels, sizes = gpu_sage.KITTI_VOXEL_LABELS, gpu_sage.KITTI_VOXEL_SIZE
-    out = gpu_sage.voxel_downsample(f, labels, sizes, scale)
     ref = _py_voxel_downsample(f, labels, sizes, scale)
+    gpu_sage.set_downsample_order(False)
+    try:
+        out = gpu_sage.voxel_downsample(f, labels, sizes, scale)
+    finally:
+        gpu_sage.set_downsample_order(True)
     assert len(ref) > 1000 and out.shape == ref.shape
-    assert np.array_equal(out, ref), "same survivors in the same (group, input) order"
+    assert np.array_equal(out, ref), "arrival order: same survivors in the same (group, input) order"
+    # default: the reference's emission order (tsl::robin_map bucket order, group by group)
+    out = gpu_sage.voxel_downsample(f, labels, sizes, scale)
+    oracle.set_robin_order(1)
+    try:
+        oref = oracle.voxel_downsample(f, labels, sizes, scale)
+    finally:
+        oracle.set_robin_order(0)
+    assert np.array_equal(out, oref) and not np.array_equal(out, ref)
+    assert np.array_equal(_sorted(out), _sorted(ref))
     # every point in one voxel: a single survivor, the first
     one = np.tile([[0.31, 0.32, 0.33, 40.0]], (500, 1)) + np.arange(500)[:, None] * [1e-6, 0, 0, 0]
     assert np.array_equal(gpu_sage.voxel_downsample(one, [[40]], [1.0], 1.0), one[:1])

@@ -1,0 +1,150 @@
+"""The oracle's emulation of tsl::robin_map v1.0.1 iteration order (oracle/sage_oracle.cpp,
+RobinOrder) against a second, independent restatement in Python, and the three places the
+reference's results depend on that order.  CPU only."""
+import numpy as np
+import pytest
+
+
+def vhash(k):
+    """core/VoxelHashMap.hpp:72-77"""
+    a, b, c = (int(v) & 0xFFFFFFFF for v in k)
+    return ((a * 73856093) ^ (b * 19349663) ^ (c * 83492791)) & 0xFFFFFFFF & ((1 << 20) - 1)
+
+
+class PyRobin:
+    """robin-hood linear probing, power-of-two growth from 0 at load 0.5, backward-shift erase —
+    written from the published description of tsl::robin_map, independently of the C++ one"""
+
+    def __init__(self):
+        self.slots = []          # None or [key, value, dist]
+        self.n = 0
+
+    def _insert_raw(self, key, val):
+        mask = len(self.slots) - 1
+        i, cur = vhash(key) & mask, [key, val, 0]
+        while True:
+            r = self.slots[i]
+            if r is None:
+                self.slots[i] = cur
+                return
+            if cur[2] > r[2]:
+                self.slots[i], cur = cur, r
+            cur[2] += 1
+            i = (i + 1) & mask
+
+    def insert(self, key, val):
+        if self.n >= int(np.float32(len(self.slots)) * np.float32(0.5)):
+            old = [s for s in self.slots if s is not None]      # bucket order
+            self.slots = [None] * (2 if not self.slots else 2 * len(self.slots))
+            for k, v, _ in old:
+                self._insert_raw(k, v)
+        self._insert_raw(key, val)
+        self.n += 1
+
+    def find(self, key):
+        if not self.slots:
+            return -1
+        mask = len(self.slots) - 1
+        i, d = vhash(key) & mask, 0
+        while self.slots[i] is not None and d <= self.slots[i][2]:
+            if self.slots[i][0] == key:
+                return i
+            i, d = (i + 1) & mask, d + 1
+        return -1
+
+    def erase(self, key):
+        i = self.find(key)
+        if i < 0:
+            return
+        mask = len(self.slots) - 1
+        self.slots[i] = None
+        self.n -= 1
+        j = (i + 1) & mask
+        while self.slots[j] is not None and self.slots[j][2] > 0:
+            self.slots[j][2] -= 1
+            self.slots[i], self.slots[j] = self.slots[j], None
+            i, j = j, (j + 1) & mask
+
+    def order(self):
+        return [s[1] for s in self.slots if s is not None]
+
+
+def test_growth_schedule(oracle):
+    """0 -> 2 -> 4 -> 8 ...: an insertion grows the array when size >= buckets / 2"""
+    keys = np.array([[i, 0, 0] for i in range(40)])
+    for n, buckets in [(1, 2), (2, 4), (3, 8), (4, 8), (5, 16), (8, 16), (9, 32), (17, 64), (33, 128)]:
+        order, bc = oracle.robin_order_of(keys[:n])
+        assert bc == buckets and sorted(order) == list(range(n))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_order_matches_independent_restatement(oracle, seed):
+    rng = np.random.default_rng(seed)
+    span = [3, 30, 300, 3000, 40, 8][seed]
+    keys = np.unique(rng.integers(-span, span, size=(1500, 3)), axis=0)
+    rng.shuffle(keys)
+    erase = keys[rng.choice(len(keys), len(keys) // 3, replace=False)]
+    r = PyRobin()
+    for i, k in enumerate(keys):
+        r.insert(tuple(k), i)
+    got, bc = oracle.robin_order_of(keys)
+    assert list(got) == r.order() and bc == len(r.slots)
+    for k in erase:
+        r.erase(tuple(k))
+    got, _ = oracle.robin_order_of(keys, erase)
+    assert list(got) == r.order()
+
+
+def test_voxel_downsample_order_switch(oracle):
+    """same survivors either way; arrival order by default, bucket order with the switch"""
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-20, 20, size=(5000, 4))
+    pts[:, 3] = rng.choice([0, 40, 50, 70, 71], size=5000)
+    labels, sizes = [[40, 44], [50], [70, 71], [0]], [0.6, 1.0, 0.9, 1.0]
+    oracle.set_robin_order(False)
+    try:
+        a = oracle.voxel_downsample(pts, labels, sizes, 1.0)
+        oracle.set_robin_order(1)
+        b = oracle.voxel_downsample(pts, labels, sizes, 1.0)
+    finally:
+        oracle.set_robin_order(False)
+    assert a.shape == b.shape and not np.array_equal(a, b)
+    assert sorted(map(tuple, a)) == sorted(map(tuple, b))
+    # group by group, b is the PyRobin order of a's voxels
+    off = 0
+    for g, vs in zip(labels, sizes):
+        sel = a[np.isin(a[:, 3].astype(int), g)]
+        r = PyRobin()
+        for i, p in enumerate(sel):
+            r.insert(tuple(int(v) for v in (p[:3] / vs)), i)
+        assert np.array_equal(b[off:off + len(sel)], sel[r.order()])
+        off += len(sel)
+
+
+def test_far_voxel_sweep_skips_what_shifts_into_the_erased_bucket(oracle):
+    """erase-while-iterating (VoxelHashMap.cpp:177-183): with the switch on, a far voxel that the
+    backward shift moves into the bucket just erased survives this sweep and goes in the next"""
+    rng = np.random.default_rng(5)
+    pts = np.zeros((6000, 4))
+    pts[:, :3] = rng.uniform(-60, 60, size=(6000, 3))
+    pts[:, 3] = 40
+    results = {}
+    for on in (False, True):
+        oracle.set_robin_order(3 if on else 0)
+        try:
+            m = oracle.Map(1.0, 30.0)
+            m.add_points(pts)
+            before = m.num_voxels()
+            m.remove_far(np.zeros(3))
+            first = m.num_voxels()
+            m.remove_far(np.zeros(3))
+            results[on] = (before, first, m.num_voxels(), m.pointcloud())
+        finally:
+            oracle.set_robin_order(False)
+    b0, f0, s0, pc0 = results[False]
+    b1, f1, s1, pc1 = results[True]
+    assert b0 == b1 and f0 == s0                       # collect-then-erase finishes in one sweep
+    assert f1 > f0                                     # the reference's sweep leaves some behind ...
+    assert np.all(np.linalg.norm(pc0[:, :3], axis=1) <= 30.0 + 2.0)
+    assert s1 < f1                                     # ... and takes (most of) them the next time
+    assert sorted(map(tuple, pc0)) == sorted(map(tuple, pc1)) or s1 >= s0
