@@ -79,6 +79,15 @@ sageicp_map *sageicp_map_create(double voxel_size, double max_distance,
                                 int basic_points_per_voxel, int critical_points_per_voxel,
                                 const int *basic_parts_labels, int n_labels, int device);
 void sageicp_map_destroy(sageicp_map *map);
+/* Single-process multi-GPU mode: the map spans `n` (1..8) devices — a full copy per device, every
+ * mutation applied to all of them — and sageicp_register_frame[_resident] shards the frame over
+ * them (contiguous blocks, one host thread and stream per device; the Gauss-Newton sums meet in
+ * peer-mapped exchange blocks), so the unchanged caller of sage_icp::RegisterFrame() — the ROS2
+ * node's single executor thread, ros/ros2/OdometryServer.cpp:104,356 — uses several GPUs.
+ * devices[0] is rank 0 (where a resident frame and the pipeline's buffers live).  The
+ * environment variable SAGEICP_DEVICES=0,1,2,3 applies the same to every map the process creates. */
+int sageicp_map_set_devices(sageicp_map *map, const int *devices, int n);
+int sageicp_map_num_devices(const sageicp_map *map);
 /* copy construction / copy assignment (ros/ros2/OdometryServer.cpp:104 copy-assigns the pipeline) */
 sageicp_map *sageicp_map_clone(const sageicp_map *map);
 int sageicp_map_clear(sageicp_map *map);                    /* Clear(), VoxelHashMap.hpp:93 */

@@ -119,6 +119,8 @@ _SIGNATURES = [
     ("sageicp_map_create", C.c_void_p,
      [C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]),
     ("sageicp_map_destroy", None, [C.c_void_p]),
+    ("sageicp_map_set_devices", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
+    ("sageicp_map_num_devices", C.c_int, [C.c_void_p]),
     ("sageicp_map_clone", C.c_void_p, [C.c_void_p]),
     ("sageicp_map_clear", C.c_int, [C.c_void_p]),
     ("sageicp_map_empty", C.c_int, [C.c_void_p]),
@@ -308,6 +310,14 @@ class VoxelHashMap:
         return VoxelHashMap(self.voxel_size_, self.max_distance_, self.basic_points_per_voxel_,
                             self.critical_points_per_voxel_, self.basic_parts_labels_,
                             self.device, _handle=h)
+
+    def set_devices(self, devices):
+        """single-process multi-GPU mode: the map spans these devices, RegisterFrame shards over them"""
+        arr = (C.c_int * len(devices))(*devices)
+        _check(lib().sageicp_map_set_devices(self._h, arr, len(devices)))
+
+    def num_devices(self):
+        return int(lib().sageicp_map_num_devices(self._h))
 
     # names follow the reference's members
     def Clear(self):

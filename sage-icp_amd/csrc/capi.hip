@@ -23,6 +23,7 @@
 #include <limits>
 #include <cstring>
 #include <mutex>
+#include <array>
 #include <string>
 #include <thread>
 #include <utility>
@@ -462,6 +463,12 @@ struct sageicp_map {
     mutable MapCounters ctr{};
     mutable UpdateScratch up{};
     mutable size_t up_n = 0, up_nb = 0;
+    // Single-process multi-GPU mode (SAGEICP_DEVICES / sageicp_map_set_devices): one more complete
+    // copy of the map per extra device.  Every mutation is applied to all of them, RegisterFrame
+    // shards the frame over them (one host thread and one stream per device) and the ranks'
+    // Gauss-Newton sums meet in peer-mapped exchange blocks.  `this` is rank 0.
+    std::vector<sageicp_map *> replicas;
+    mutable std::vector<struct sageicp_comm *> ranks;   // created at the first sharded registration
 };
 
 struct sageicp_frame {
@@ -480,6 +487,7 @@ struct sageicp_comm {
     P2pBlock *my_block = nullptr;        // fine-grained device memory, exported through HIP IPC
     P2pBlock *blocks[kMaxRanks] = {};    // every rank's block as mapped here (blocks[rank] == my_block)
     unsigned long long *d_exchanges = nullptr;
+    bool peer_mapped = false;            // blocks[] are plain peer pointers of this process (no IPC handles to close)
 };
 
 // ---- RCCL, bound at run time (only multi-GPU runs need it) ------------------------------------
@@ -495,6 +503,12 @@ struct Rccl {
 };
 Rccl g_rccl;
 std::mutex g_rccl_mu;
+
+int device_update_all(sageicp_map *m, const double *xyzl, uint64_t n, const double pose[7],
+                      const Point4 *d_points);
+int register_sharded(const sageicp_map *m, const double *h_frame, const Point4 *d_frame, uint64_t n,
+                     const double init[7], double max_dist, double kernel, double sem_th,
+                     double pose_out[7], sageicp_stats *stats, double t0);
 
 int load_rccl() {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
@@ -1122,6 +1136,143 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     return SAGEICP_OK;
 }
 
+
+// ---- single-process multi-GPU mode -------------------------------------------------------------
+// Update(points, pose) on every copy of the map.  `d_points` (optional) lives on rank 0's device.
+int device_update_all(sageicp_map *m, const double *xyzl, uint64_t n, const double pose[7],
+                      const Point4 *d_points) {
+    int rc = device_update(m, xyzl, n, pose, d_points);
+    if (rc || m->replicas.empty()) return rc;
+    std::vector<double> host;
+    if (d_points) {                               // the other devices take the points from the host
+        host.resize(4 * n);
+        HIPCHK(hipSetDevice(m->device));
+        if (n) HIPCHK(hipMemcpy(host.data(), d_points, n * sizeof(Point4), hipMemcpyDeviceToHost));
+        xyzl = host.data();
+    }
+    for (sageicp_map *r : m->replicas)
+        if ((rc = device_update(r, xyzl, n, pose))) return rc;
+    return SAGEICP_OK;
+}
+
+// exchange blocks of the ranks of one process: fine-grained device memory, reached by the other
+// devices through peer access (no IPC)
+int create_ranks(const sageicp_map *m) {
+    const int N = 1 + static_cast<int>(m->replicas.size());
+    if (static_cast<int>(m->ranks.size()) == N) {
+        for (sageicp_comm *c : m->ranks)
+            if (c->poisoned)
+                return fail(SAGEICP_ERR_RCCL, "an earlier exchange between the devices of this map timed out: "
+                                              "call sageicp_map_set_devices again");
+        return SAGEICP_OK;
+    }
+    std::vector<int> dev(N);
+    dev[0] = m->device;
+    for (int k = 1; k < N; ++k) dev[k] = m->replicas[k - 1]->device;
+    for (int a = 0; a < N; ++a)
+        for (int b = 0; b < N; ++b) {
+            if (dev[a] == dev[b]) continue;
+            int can = 0;
+            HIPCHK(hipDeviceCanAccessPeer(&can, dev[a], dev[b]));
+            if (!can) return fail(SAGEICP_ERR_HIP, "devices of one map need peer access to each other");
+            HIPCHK(hipSetDevice(dev[a]));
+            const hipError_t e = hipDeviceEnablePeerAccess(dev[b], 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                return fail(SAGEICP_ERR_HIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+            (void)hipGetLastError();
+        }
+    std::vector<sageicp_comm *> ranks(N, nullptr);
+    auto undo = [&]() {
+        for (sageicp_comm *c : ranks) sageicp_comm_destroy(c);
+    };
+    for (int k = 0; k < N; ++k) {
+        sageicp_comm *c = new sageicp_comm;
+        ranks[k] = c;
+        c->rank = k; c->nranks = N; c->device = dev[k];
+        c->peer_mapped = true;
+        if (hipSetDevice(dev[k]) != hipSuccess ||
+            hipExtMallocWithFlags(reinterpret_cast<void **>(&c->my_block), sizeof(P2pBlock),
+                                  hipDeviceMallocFinegrained) != hipSuccess ||
+            hipMemset(c->my_block, 0, sizeof(P2pBlock)) != hipSuccess ||
+            hipMalloc(&c->d_exchanges, sizeof(unsigned long long)) != hipSuccess ||
+            hipMemset(c->d_exchanges, 0, sizeof(unsigned long long)) != hipSuccess ||
+            hipDeviceSynchronize() != hipSuccess) {
+            undo();
+            return fail(SAGEICP_ERR_HIP, "allocating the exchange blocks failed");
+        }
+    }
+    for (int k = 0; k < N; ++k) {
+        for (int r = 0; r < N; ++r) ranks[k]->blocks[r] = ranks[r]->my_block;
+        ranks[k]->p2p = true;
+    }
+    m->ranks = ranks;
+    return SAGEICP_OK;
+}
+
+// RegisterFrame over all devices of the map: rank k registers block k of the frame (contiguous
+// blocks of ceil(n / N) points) against its copy of the map, on its own host thread and
+// stream; the sums meet in k_fin (direct exchange).  Exactly one of h_frame / d_frame is given
+// (d_frame on rank 0's device).
+int register_sharded(const sageicp_map *m, const double *h_frame, const Point4 *d_frame, uint64_t n,
+                     const double init[7], double max_dist, double kernel, double sem_th,
+                     double pose_out[7], sageicp_stats *stats, double t0) {
+    int rc = create_ranks(m);
+    if (rc) return rc;
+    const int N = 1 + static_cast<int>(m->replicas.size());
+    std::vector<const sageicp_map *> maps(N);
+    maps[0] = m;
+    for (int k = 1; k < N; ++k) maps[k] = m->replicas[k - 1];
+    const uint64_t per = (n + N - 1) / N;
+    std::vector<int> codes(N, SAGEICP_OK);
+    std::vector<std::string> errors(N);
+    std::vector<std::array<double, 7>> poses(N);
+    std::vector<sageicp_stats> st(N);
+    auto work = [&](int k) {
+        const sageicp_map *mk = maps[k];
+        const uint64_t lo = std::min<uint64_t>(n, k * per), cnt = std::min<uint64_t>(n, lo + per) - lo;
+        auto body = [&]() -> int {
+            HIPCHK(hipSetDevice(mk->device));
+            int r = sync_mirror(mk);
+            if (r) return r;
+            Scratch &sc = mk->sc;
+            if ((r = sc.reserve_frame(cnt))) return r;
+            const Point4 *mine = sc.d_frame;
+            if (cnt) {
+                if (h_frame)
+                    HIPCHK(hipMemcpyAsync(sc.d_frame, h_frame + 4 * lo, cnt * sizeof(Point4),
+                                          hipMemcpyHostToDevice, sc.stream));
+                else if (k == 0)
+                    mine = d_frame + lo;
+                else
+                    HIPCHK(hipMemcpyPeerAsync(sc.d_frame, mk->device, d_frame + lo, m->device,
+                                              cnt * sizeof(Point4), sc.stream));
+            }
+            return run_icp(mk, mine, cnt, init, max_dist, kernel, sem_th, m->ranks[k], poses[k].data(),
+                           &st[k], now_us() - t0, t0);
+        };
+        codes[k] = body();
+        if (codes[k]) errors[k] = g_err;          // g_err is per thread
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < N; ++k) th.emplace_back(work, k);
+    work(0);
+    for (auto &t : th) t.join();
+    (void)hipSetDevice(m->device);
+    for (int k = 0; k < N; ++k)
+        if (codes[k]) return fail(codes[k], "device rank " + std::to_string(k) + ": " + errors[k]);
+    std::memcpy(pose_out, poses[0].data(), 56);
+    if (stats) {
+        *stats = st[0];
+        stats->n_queries = n;
+        for (int k = 1; k < N; ++k) {
+            stats->sum_candidates += st[k].sum_candidates;
+            stats->pairs_evaluated += st[k].pairs_evaluated;
+        }
+        stats->us_wall = now_us() - t0;
+    }
+    return SAGEICP_OK;
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -1149,11 +1300,57 @@ sageicp_map *sageicp_map_create(double voxel_size, double max_distance, int basi
     sageicp_map *m = new sageicp_map;
     m->host.configure(voxel_size, max_distance, basic, critical, labels, n_labels);
     m->device = device;
+    // SAGEICP_DEVICES=0,1,2,3: every map of this process spans these devices (the knob for callers
+    // that cannot be changed, e.g. the ROS node behind the header shim); the first is rank 0
+    if (const char *list = std::getenv("SAGEICP_DEVICES")) {
+        std::vector<int> devs;
+        for (const char *q = list; *q;) {
+            char *end = nullptr;
+            const long v = std::strtol(q, &end, 10);
+            if (end == q) break;
+            devs.push_back(static_cast<int>(v));
+            q = (*end == ',') ? end + 1 : end;
+        }
+        if (devs.size() > 1 && sageicp_map_set_devices(m, devs.data(), static_cast<int>(devs.size()))) {
+            sageicp_map_destroy(m);
+            return nullptr;
+        }
+    }
     return m;
 }
 
+int sageicp_map_set_devices(sageicp_map *m, const int *devices, int n) {
+    if (!m || !devices || n < 1 || n > kMaxRanks)
+        return fail(SAGEICP_ERR_INVALID, "sageicp_map_set_devices: 1..8 devices");
+    if (m->sc.stream && devices[0] != m->device)
+        return fail(SAGEICP_ERR_INVALID, "sageicp_map_set_devices: the map already lives on another first device");
+    const int count = sageicp_device_count();
+    for (int k = 0; k < n; ++k)
+        if (count > 0 && (devices[k] < 0 || devices[k] >= count))
+            return fail(SAGEICP_ERR_INVALID, "sageicp_map_set_devices: device ordinal out of range");
+    if (int rc = ensure_host(m)) return rc;
+    for (sageicp_map *r : m->replicas) sageicp_map_destroy(r);
+    m->replicas.clear();
+    for (sageicp_comm *c : m->ranks) sageicp_comm_destroy(c);
+    m->ranks.clear();
+    m->device = devices[0];
+    for (int k = 1; k < n; ++k) {
+        sageicp_map *r = new sageicp_map;
+        r->device = devices[k];
+        r->host = m->host;                 // the same map, mirrored on its own device at first use
+        r->mirror_stale_all = true;
+        m->replicas.push_back(r);
+    }
+    return SAGEICP_OK;
+}
+int sageicp_map_num_devices(const sageicp_map *m) { return m ? 1 + static_cast<int>(m->replicas.size()) : 0; }
+
 void sageicp_map_destroy(sageicp_map *m) {
     if (!m) return;
+    for (sageicp_comm *c : m->ranks) sageicp_comm_destroy(c);
+    m->ranks.clear();
+    for (sageicp_map *r : m->replicas) sageicp_map_destroy(r);
+    m->replicas.clear();
     if (m->sc.stream) {
         (void)hipSetDevice(m->device);
         (void)hipStreamSynchronize(m->sc.stream);
@@ -1205,8 +1402,7 @@ static int clone_on_device(const sageicp_map *src, sageicp_map *m) {
     return SAGEICP_OK;
 }
 
-sageicp_map *sageicp_map_clone(const sageicp_map *src) {
-    if (!src) return nullptr;
+static sageicp_map *clone_one(const sageicp_map *src) {
     sageicp_map *m = new sageicp_map;
     m->device = src->device;
     if (src->on_device) {
@@ -1221,12 +1417,28 @@ sageicp_map *sageicp_map_clone(const sageicp_map *src) {
     return m;
 }
 
+sageicp_map *sageicp_map_clone(const sageicp_map *src) {
+    if (!src) return nullptr;
+    sageicp_map *m = clone_one(src);
+    if (!m) return nullptr;
+    for (const sageicp_map *r : src->replicas) {
+        sageicp_map *c = clone_one(r);
+        if (!c) {
+            sageicp_map_destroy(m);
+            return nullptr;
+        }
+        m->replicas.push_back(c);
+    }
+    return m;
+}
+
 int sageicp_map_clear(sageicp_map *m) {
     if (!m) return fail(SAGEICP_ERR_INVALID, "null map");
     m->on_device = false;     // whatever the device holds is dropped with the rest
     m->aux_valid = false;
     m->host.clear();
     m->mirror_stale_all = true;
+    for (sageicp_map *r : m->replicas) sageicp_map_clear(r);
     return SAGEICP_OK;
 }
 int sageicp_map_empty(const sageicp_map *m) { return (!m || map_is_empty(m)) ? 1 : 0; }
@@ -1250,6 +1462,8 @@ int sageicp_map_add_points(sageicp_map *m, const double *xyzl, uint64_t n) {
     if (why == 2)
         return fail(SAGEICP_ERR_CAPACITY, "voxel index beyond +-2^20: stopped before point " +
                                               std::to_string(at) + ", the points before it are in");
+    for (sageicp_map *r : m->replicas)
+        if (int rc = sageicp_map_add_points(r, xyzl, n)) return rc;
     return SAGEICP_OK;
 }
 
@@ -1257,6 +1471,8 @@ int sageicp_map_remove_far(sageicp_map *m, const double origin[3]) {
     if (!m || !origin) return fail(SAGEICP_ERR_INVALID, "null argument");
     if (int rc = ensure_host(m)) return rc;
     m->host.remove_far(origin);
+    for (sageicp_map *r : m->replicas)
+        if (int rc = sageicp_map_remove_far(r, origin)) return rc;
     return SAGEICP_OK;
 }
 
@@ -1281,7 +1497,7 @@ int sageicp_map_update_pose(sageicp_map *m, const double *xyzl, uint64_t n, cons
 
 int sageicp_map_update_pose_device(sageicp_map *m, const double *xyzl, uint64_t n, const double pose[7]) {
     if (!m || (n && !xyzl) || !pose) return fail(SAGEICP_ERR_INVALID, "null argument");
-    return device_update(m, xyzl, n, pose);
+    return device_update_all(m, xyzl, n, pose, nullptr);
 }
 
 uint64_t sageicp_map_pointcloud(const sageicp_map *m, double *out, uint64_t cap) {
@@ -1292,7 +1508,10 @@ uint64_t sageicp_map_pointcloud(const sageicp_map *m, double *out, uint64_t cap)
 
 int sageicp_map_sync(const sageicp_map *m) {
     if (!m) return fail(SAGEICP_ERR_INVALID, "null map");
-    return sync_mirror(m);
+    if (int rc = sync_mirror(m)) return rc;
+    for (const sageicp_map *r : m->replicas)
+        if (int rc = sync_mirror(r)) return rc;
+    return SAGEICP_OK;
 }
 
 // ---- search ---------------------------------------------------------------------------------
@@ -1439,6 +1658,8 @@ int sageicp_register_frame(const sageicp_map *m, const double *frame, uint64_t n
         if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->n_queries = n; }
         return SAGEICP_OK;
     }
+    if (!m->replicas.empty())
+        return register_sharded(m, frame, nullptr, n, init, max_dist, kernel, sem_th, pose_out, stats, t0);
     int rc = sync_mirror(m);
     if (rc) return rc;
     Scratch &sc = m->sc;
@@ -1490,6 +1711,10 @@ int sageicp_register_frame_resident(const sageicp_map *m, const sageicp_frame *f
         std::memcpy(pose_out, init, 56);
         if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->n_queries = f->n; }
         return SAGEICP_OK;
+    }
+    if (!m->replicas.empty()) {
+        if (comm) return fail(SAGEICP_ERR_INVALID, "a map that spans several devices shards the frame itself");
+        return register_sharded(m, nullptr, f->d, f->n, init, max_dist, kernel, sem_th, pose_out, stats, t0);
     }
     int rc = sync_mirror(m);
     if (rc) return rc;
@@ -1599,7 +1824,7 @@ void sageicp_comm_destroy(sageicp_comm *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (int r = 0; r < c->nranks && r < kMaxRanks; ++r)
-        if (r != c->rank && c->blocks[r]) (void)hipIpcCloseMemHandle(c->blocks[r]);
+        if (r != c->rank && c->blocks[r] && !c->peer_mapped) (void)hipIpcCloseMemHandle(c->blocks[r]);
     if (c->my_block) (void)hipFree(c->my_block);
     if (c->d_exchanges) (void)hipFree(c->d_exchanges);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
@@ -1705,7 +1930,7 @@ int sageicp_pipeline_register_frame(sageicp_pipeline *p, const double *frame, ui
         int update_map(const double pose[7]) {
             const uint64_t n_fd = p->prep.kept_levels[0];
             if (p->impl.map_update_on_device_())
-                return device_update(p->impl.map, nullptr, n_fd, pose, p->prep.d_fd);
+                return device_update_all(p->impl.map, nullptr, n_fd, pose, p->prep.d_fd);
             std::vector<double> fd(4 * n_fd);
             if (n_fd) {
                 HIPCHK(hipSetDevice(p->device));

@@ -153,3 +153,27 @@ def test_synthetic_workload_is_deterministic_and_exact(sage):
     r = np.linalg.norm(w1["scan"][:, :3], axis=1)
     assert r.min() > 4.0 and r.max() < 101.0
     assert np.array_equal(w1["scan"][:, :3], w1["scan"][:, :3].astype(np.float32).astype(np.float64))
+
+
+def test_multi_device_map_replicates_mutations_on_the_host(sage):
+    """sageicp_map_set_devices works without a GPU for everything that is host logic: every copy
+    of the map takes every mutation, clones keep the device list"""
+    rng = np.random.default_rng(9)
+    pts = rng.uniform(-20, 20, size=(4000, 4))
+    pts[:, 3] = rng.choice([0, 40, 70], size=len(pts))
+    a = sage.VoxelHashMap(1.0, 15.0)
+    a.set_devices([0, 1, 2])
+    assert a.num_devices() == 3
+    a.AddPoints(pts)
+    b = sage.VoxelHashMap(1.0, 15.0)
+    b.AddPoints(pts)
+    assert a.size() == b.size() and a.num_voxels() == b.num_voxels()
+    a.RemovePointsFarFromLocation([0.0, 0.0, 0.0])
+    b.RemovePointsFarFromLocation([0.0, 0.0, 0.0])
+    assert np.array_equal(a.Pointcloud(), b.Pointcloud())
+    c = a.clone()
+    assert c.num_devices() == 3 and c.size() == a.size()
+    a.Clear()
+    assert a.Empty() and not c.Empty()
+    with pytest.raises(sage.SageIcpError):
+        a.set_devices(list(range(9)))

@@ -433,6 +433,21 @@ def test_streaming_frames_with_map_updates(gpu_sage, oracle):
         pose = opose
 
 
+def test_rccl_refuses_two_ranks_on_one_device():
+    """documented limit of this box: RCCL (like NCCL) rejects a communicator with two ranks on the
+    same GPU, so the N > 1 RCCL path can only run on the driver's multi-GPU node; what runs here is
+    the 1-rank RCCL path, the direct exchange between 2 processes and between 2-3 ranks of one
+    process (below)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SAGEICP_BENCH_DEVICE="0", SAGEICP_NO_P2P="1", MASTER_ADDR="127.0.0.1")
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1",
+                          "--warmup", "0", "--scale", "0.05", "--no-cpu-baseline"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert run.returncode != 0      # bench.py --gpus 2 launched its own ranks; RCCL refused the pair
+
+
 def test_register_frame_through_rccl_comm_world1(gpu_sage, oracle):
     """the RCCL exchange path (reduce -> ncclAllReduce -> solve) with a one-rank communicator"""
     w, om = _workload(gpu_sage, oracle, "c2", 0.05)
@@ -465,6 +480,43 @@ def test_register_frame_through_direct_exchange_world1(gpu_sage, oracle):
     both.p2p_enable(False)
     b = gpu_sage.register_frame(f, w["map"], gpu_sage.IDENTITY, 6.0, 2 / 3, 0.4, comm=both)
     assert np.array_equal(a, ref) and np.array_equal(b, ref)
+
+
+def test_single_process_multi_device_mode(gpu_sage, oracle):
+    """sageicp_map_set_devices: one map handle spanning two ranks (both on the one GPU of this
+    box), the frame sharded inside sage_icp::RegisterFrame's entry, one host thread per rank, the
+    sums exchanged through peer-mapped blocks — same pose and iteration count as one device, for
+    the host-buffer entry, the resident-frame entry, after a device-side Update and for a clone"""
+    from sage_icp_amd import synthetic as syn
+    w, om = _workload(gpu_sage, oracle, "c2", 0.1)
+    p = syn.PARAMS["cold"]
+    ref, rst = gpu_sage.register_frame(w["scan"], w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"],
+                                       p["sem_th"], return_stats=True)
+    m2 = gpu_sage.VoxelHashMap(1.0, 100.0)
+    m2.set_devices([0, 0])
+    assert m2.num_devices() == 2
+    m2.AddPoints(w["stream"])
+    assert m2.size() == w["map"].size()
+    for frame in (w["scan"], gpu_sage.Frame(m2, w["scan"])):
+        pose, st = gpu_sage.register_frame(frame, m2, gpu_sage.IDENTITY, p["max_dist"], p["kernel"],
+                                           p["sem_th"], return_stats=True)
+        dt, dr = pose_error(oracle, ref, pose)
+        assert dt < 1e-9 and dr < 1e-9 and st.iterations == rst.iterations
+        assert st.n_queries == len(w["scan"]) and st.sum_candidates == rst.sum_candidates
+        assert st.n_corr_last == rst.n_corr_last
+    # three ranks, an uneven split, after a device-side map update on every copy; and a clone
+    m3 = gpu_sage.VoxelHashMap(1.0, 100.0)
+    m3.set_devices([0, 0, 0])
+    m3.AddPoints(w["stream"])
+    m3.UpdateOnDevice(w["scan"][:5001], ref)
+    w["map"].UpdateOnDevice(w["scan"][:5001], ref)
+    assert m3.size() == w["map"].size()
+    one = gpu_sage.register_frame(w["scan"][:9001], w["map"], ref, p["max_dist"], p["kernel"], p["sem_th"])
+    for mm in (m3, m3.clone()):
+        assert mm.num_devices() == 3
+        got = gpu_sage.register_frame(w["scan"][:9001], mm, ref, p["max_dist"], p["kernel"], p["sem_th"])
+        dt, dr = pose_error(oracle, one, got)
+        assert dt < 1e-9 and dr < 1e-9
 
 
 def test_direct_exchange_between_two_processes(gpu_sage, tmp_path):
