@@ -33,7 +33,8 @@ extern "C" {
 #define SAGEICP_ERR_NO_DEVICE (-2)  /* no usable gfx950 device / HIP runtime failure at init */
 #define SAGEICP_ERR_HIP (-3)        /* a HIP call failed */
 #define SAGEICP_ERR_RCCL (-4)       /* RCCL could not be loaded or a collective failed */
-#define SAGEICP_ERR_CAPACITY (-5)   /* > 2^23 voxels, > 255 points per voxel, or > 2^27 point slots */
+#define SAGEICP_ERR_CAPACITY (-5)   /* > 2^24 voxels, > 255 points per voxel, > 2^31 point slots, or a voxel
+                                     * index beyond +-2^20 */
 
 typedef struct sageicp_map sageicp_map;       /* opaque: host map + device mirror + scratch */
 typedef struct sageicp_frame sageicp_frame;   /* opaque: a scan resident in HBM */

@@ -249,7 +249,9 @@ def set_robin_order(mode):
       False / 0   arrival-order emission, collect-then-erase sweep (deviations D2 + D3)
       1           VoxelDownsample emission and Pointcloud() in bucket order (what the product does)
       2           only the far-voxel sweep erases while iterating
-      True / 3    both: the reference's behaviour"""
+      True / 3    both: the reference's behaviour
+    Maps (and pipelines) follow the bucket order only if they were CREATED while the mode was
+    non-zero: set it first."""
     lib().sgo_set_robin_order(3 if mode is True else int(mode))
 
 

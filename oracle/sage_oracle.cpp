@@ -232,7 +232,10 @@ struct Map {
     int critical;
     std::vector<int> basic_labels;
     std::unordered_map<Voxel, Block, VoxelHash> map;
-    RobinOrder order;          // the bucket layout tsl::robin_map would have (kept in step with `map`)
+    RobinOrder order;          // the bucket layout tsl::robin_map would have, kept in step with `map`
+    bool track_order = false;  // ... only for maps created while sgo_set_robin_order() is non-zero: with
+                               // the reference's 20-bit hash a robin-hood table degenerates into one
+                               // cluster beyond ~10^6 voxels (quadratic insertion, in the reference too)
 };
 
 // ---------------------------------------------------------------- SO3 / SE3 (Sophus 1.22)
@@ -532,6 +535,7 @@ void *sgo_map_create(double voxel_size, double max_distance, int basic, int crit
     m->basic = basic;
     m->critical = critical;
     m->basic_labels.assign(basic_labels, basic_labels + n_labels);
+    m->track_order = g_robin_order != 0;
     return m;
 }
 void sgo_map_destroy(void *h) { delete static_cast<Map *>(h); }
@@ -562,7 +566,7 @@ void sgo_map_add_points(void *h, const double *xyzl, uint64_t n) {
             // a new voxel takes its first point unconditionally (VoxelHashMap.cpp:171)
             Block b{{p}, m.basic, m.critical, &m.basic_labels};
             m.map.emplace(v, std::move(b));
-            m.order.insert(v, 0);
+            if (m.track_order) m.order.insert(v, 0);
         }
     }
 }
@@ -577,7 +581,7 @@ void sgo_map_remove_far(void *h, const double origin[3]) {
         const double dx = pt[0] - origin[0], dy = pt[1] - origin[1], dz = pt[2] - origin[2];
         return dx * dx + (dy * dy + dz * dz) > max_distance2;
     };
-    if (g_robin_order & 2) {
+    if ((g_robin_order & 2) && m.track_order) {
         m.order.sweep_erase([&](const Voxel &v, size_t) { return is_far(v); },
                             [&](const Voxel &v, size_t) { m.map.erase(v); });
         return;
@@ -587,7 +591,7 @@ void sgo_map_remove_far(void *h, const double origin[3]) {
         if (is_far(kv.first)) far.push_back(kv.first);
     for (const auto &v : far) {
         m.map.erase(v);
-        m.order.erase_at(static_cast<size_t>(m.order.find(v)));
+        if (m.track_order) m.order.erase_at(static_cast<size_t>(m.order.find(v)));
     }
 }
 
@@ -612,7 +616,7 @@ uint64_t sgo_map_pointcloud(const void *h, double *out_xyzl, uint64_t cap) {
             ++n;
         }
     };
-    if (g_robin_order & 1)
+    if ((g_robin_order & 1) && m.track_order)
         m.order.for_each([&](const Voxel &v, size_t) { emit(m.map.find(v)->second); });
     else
         for (const auto &kv : m.map) emit(kv.second);

@@ -566,7 +566,7 @@ int sync_mirror(const sageicp_map *m) {
         table_full = true;
     }
     // (the host arrays grow by doubling; the map itself never holds more than the addressable
-    // 2^27 point slots — HostMap::add_point refuses the voxel that would cross the limit)
+    // 2^31 point slots — HostMap::add_point refuses the voxel that would cross the limit)
     const size_t block_bytes = static_cast<size_t>(h.cap) * sizeof(Point4);
     const size_t blocks_cap = std::min<size_t>(h.cnt.size(), kMaxMapPoints / static_cast<uint64_t>(h.cap));
     bool points_full = h.points_all_dirty || m->mirror_stale_all;
@@ -773,13 +773,13 @@ int device_update(sageicp_map *m, const double *xyzl, uint64_t n, const double p
     }
     // capacity for the worst case (every point opens a voxel); the host rule is load <= 1/4
     const uint64_t need_blocks = static_cast<uint64_t>(m->ctr.blocks_hi) + n;
-    if (need_blocks >= (1ull << kMaxBlockBits)) return fail(SAGEICP_ERR_CAPACITY, "more than 2^23 voxels");
+    if (need_blocks + 3 >= (1ull << kMaxBlockBits)) return fail(SAGEICP_ERR_CAPACITY, "more than 2^24 voxels");
     size_t blocks = m->d_blocks_cap;
     if (need_blocks > blocks) blocks = std::max<size_t>(need_blocks, std::max<size_t>(1024, 2 * blocks));
     if (static_cast<uint64_t>(blocks) * h.cap > kMaxMapPoints) {
         blocks = need_blocks;
         if (static_cast<uint64_t>(blocks) * h.cap > kMaxMapPoints)
-            return fail(SAGEICP_ERR_CAPACITY, "voxel blocks x capacity beyond 2^27 points");
+            return fail(SAGEICP_ERR_CAPACITY, "voxel blocks x capacity beyond 2^31 points");
     }
     if ((rc = grow_device_blocks(m, blocks, m->ctr.blocks_hi))) return rc;
     if (!m->on_device && !(m->aux_valid && m->aux_generation == h.generation)) {
@@ -885,8 +885,11 @@ IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, 
     ip.table = m->d_table;
     ip.mask = static_cast<uint32_t>(m->d_table_cap - 1);
     ip.pts = m->d_pts;
-    ip.pts_bytes = static_cast<uint32_t>((m->d_blocks_cap * m->host.cap + 1) * sizeof(Point4));
+    const uint64_t pts_bytes = (static_cast<uint64_t>(m->d_blocks_cap) * m->host.cap + 1) * sizeof(Point4);
+    ip.big = pts_bytes >= (1ull << 32) || env_int("SAGEICP_FORCE_BIG", 0);
+    ip.pts_bytes = ip.big ? 0u : static_cast<uint32_t>(pts_bytes);
     ip.cap_bytes = static_cast<uint32_t>(m->host.cap * sizeof(Point4));
+    ip.cap_points = static_cast<uint32_t>(m->host.cap);
     ip.sem_th = sem_th;
     ip.dist_init = DBL_MAX;
     // scaled distance = d2 * sem_th for matching labels, d2 otherwise: >= min(sem_th, 1) * d2.
@@ -1457,7 +1460,7 @@ int sageicp_map_add_points(sageicp_map *m, const double *xyzl, uint64_t n) {
     uint64_t at = 0;
     const int why = m->host.add_points(xyzl, n, &at);     // limits are checked before a point is taken
     if (why == 1)
-        return fail(SAGEICP_ERR_CAPACITY, "map full (2^23 voxels / 2^27 point slots): stopped before point " +
+        return fail(SAGEICP_ERR_CAPACITY, "map full (2^24 voxels / 2^31 point slots): stopped before point " +
                                               std::to_string(at) + ", the points before it are in");
     if (why == 2)
         return fail(SAGEICP_ERR_CAPACITY, "voxel index beyond +-2^20: stopped before point " +

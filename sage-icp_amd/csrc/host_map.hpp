@@ -18,13 +18,85 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <new>
+#include <utility>
 #include <vector>
+
+#include <sys/mman.h>
 
 #include "sageicp_types.h"
 
 namespace sageicp {
 
-constexpr uint64_t kHostMaxPointSlots = (1ull << 27) - 2;   // == kMaxMapPoints (kernels.h): 32-B points under 4 GiB
+// The host copy of the voxel blocks: gigabytes for a big map (1,280 B per voxel at 20 + 20 points).
+// A std::vector would copy and zero-fill the whole array at every doubling; this store grows with
+// mremap (pages move, nothing is copied, untouched blocks are never faulted in) and asks for huge
+// pages.  New elements read as zero, like vector::resize(n, Point4{}).
+class PointStore {
+public:
+    PointStore() = default;
+    PointStore(const PointStore &o) { *this = o; }
+    PointStore(PointStore &&o) noexcept { swap(o); }
+    PointStore &operator=(const PointStore &o) {
+        if (this == &o) return *this;
+        release();
+        if (o.n_) {
+            resize(o.n_, o.used_hint_);
+            std::memcpy(p_, o.p_, std::min(o.n_, o.used_hint_) * sizeof(Point4));
+        }
+        return *this;
+    }
+    PointStore &operator=(PointStore &&o) noexcept {
+        swap(o);
+        return *this;
+    }
+    ~PointStore() { release(); }
+
+    Point4 *data() { return p_; }
+    const Point4 *data() const { return p_; }
+    size_t size() const { return n_; }
+    Point4 &operator[](size_t i) { return p_[i]; }
+    const Point4 &operator[](size_t i) const { return p_[i]; }
+    void clear() { release(); }
+    // `used`: elements [0, used) may hold data (what a copy has to carry); grow-only otherwise
+    void resize(size_t n, size_t used = ~static_cast<size_t>(0)) {
+        used_hint_ = std::min(used, n);
+        if (n == n_) return;
+        const size_t bytes = round_up(n * sizeof(Point4));
+        if (n == 0) { release(); return; }
+        void *q;
+        if (!p_) {
+            q = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        } else {
+            q = mremap(p_, cap_bytes_, bytes, MREMAP_MAYMOVE);
+        }
+        if (q == MAP_FAILED) throw std::bad_alloc();
+        (void)madvise(q, bytes, MADV_HUGEPAGE);
+        if (n < n_)          // shrinking keeps zero semantics for a later growth
+            std::memset(static_cast<char *>(q) + n * sizeof(Point4), 0,
+                        std::min(bytes, n_ * sizeof(Point4)) - n * sizeof(Point4));
+        p_ = static_cast<Point4 *>(q);
+        cap_bytes_ = bytes;
+        n_ = n;
+    }
+    void set_used(size_t used) { used_hint_ = std::min(used, n_); }
+
+private:
+    Point4 *p_ = nullptr;
+    size_t n_ = 0, cap_bytes_ = 0, used_hint_ = 0;
+    static size_t round_up(size_t b) { return (b + (2u << 20) - 1) & ~static_cast<size_t>((2u << 20) - 1); }
+    void release() {
+        if (p_) munmap(p_, cap_bytes_);
+        p_ = nullptr;
+        n_ = cap_bytes_ = used_hint_ = 0;
+    }
+    void swap(PointStore &o) {
+        std::swap(p_, o.p_); std::swap(n_, o.n_); std::swap(cap_bytes_, o.cap_bytes_);
+        std::swap(used_hint_, o.used_hint_);
+    }
+};
+
+constexpr uint64_t kHostMaxPointSlots = (1ull << 31) - 512;   // == kMaxMapPoints (kernels.h): point indices fit an int32
 
 class HostMap {
 public:
@@ -38,7 +110,7 @@ public:
     std::vector<Slot> table;          // power-of-two capacity
     uint32_t mask = 0;
     uint32_t num_voxels = 0;
-    std::vector<Point4> pts;          // block b owns pts[b*cap .. b*cap+cap)
+    PointStore pts;                   // block b owns pts[b*cap .. b*cap+cap)
     std::vector<uint8_t> cnt;         // points in block b (0 = block is free)
     std::vector<uint8_t> zeros;       // how many of them are unlabelled ((int)label == 0)
     std::vector<int32_t> keys;        // 3 ints per block: its voxel key
@@ -158,7 +230,7 @@ public:
         cnt.assign(blocks_cap, 0);
         zeros.assign(blocks_cap, 0);
         keys.assign(3 * blocks_cap, 0);
-        pts.resize(blocks_cap * cap, Point4{0, 0, 0, 0});     // blocks [0, bhi) filled by the caller
+        pts.resize(blocks_cap * cap, static_cast<size_t>(bhi) * cap);     // blocks [0, bhi) filled by the caller
         for (const Slot &e : dtab) {
             if (e.blk == kEmptySlot || e.blk == kTombstone) continue;
             table[probe(e.x, e.y, e.z)] = e;
@@ -256,8 +328,9 @@ private:
                 cnt.resize(nb, 0);
                 zeros.resize(nb, 0);
                 keys.resize(nb * 3, 0);
-                pts.resize(nb * cap, Point4{0, 0, 0, 0});
+                pts.resize(nb * cap, static_cast<size_t>(blocks_hi) * cap);
             }
+            pts.set_used(static_cast<size_t>(blocks_hi) * cap);      // what a copy of the map carries
         }
         return b;
     }
@@ -274,7 +347,7 @@ private:
         if (table[s].blk == kEmptySlot) {
             // new voxel: its first point is taken unconditionally (VoxelHashMap.cpp:171)
             if (free_blocks.empty() &&
-                (blocks_hi + 1u >= (1u << kMaxBlockBits) ||
+                (blocks_hi + 3u >= (1u << kMaxBlockBits) ||
                  (static_cast<uint64_t>(blocks_hi) + 1u) * static_cast<uint64_t>(cap) > kHostMaxPointSlots))
                 return 1;                    // checked BEFORE anything is touched
             if ((static_cast<uint64_t>(num_voxels) + 1) * 4 > table.size()) {

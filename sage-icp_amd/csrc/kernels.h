@@ -31,8 +31,11 @@ struct IcpParams {
     const Slot *table;        // the open-addressed voxel hash
     uint32_t mask;
     const Point4 *pts;
-    uint32_t pts_bytes;       // size of the point array (< 4 GiB: addressed by 32-bit byte offsets)
+    uint32_t pts_bytes;       // size of the point array when it is under 4 GiB (32-bit byte offsets
+                              // through a buffer resource); bigger maps: `big`, 64-bit addresses
     uint32_t cap_bytes;       // bytes of one voxel block: (basic + critical) * 32
+    uint32_t cap_points;      // basic + critical
+    int big;                  // 1: the point array is 4 GiB or more
     double sem_th;
     double dist_init;         // DBL_MAX
     double prune_scale;       // min(sem_th, 1) * (1 - 1e-9): scaled distance >= this x squared
@@ -89,7 +92,7 @@ void launch_fin(const FinParams &p, hipStream_t s);
 
 constexpr int kMaxPartials = 1 << 16;
 constexpr uint64_t kMaxQueries = (1ull << 26) - 1;
-constexpr uint64_t kMaxMapPoints = (1ull << 27) - 2;   // blocks x capacity: 32-B points under 4 GiB
+constexpr uint64_t kMaxMapPoints = (1ull << 31) - 512;   // blocks x capacity: point indices fit an int32 (nn_idx)
 
 void launch_tf(Point4 *pts, int n, const IcpState *st, hipStream_t s);
 void launch_scatter_points(const uint32_t *idx, const Point4 *vals, uint32_t n, Point4 *pts,

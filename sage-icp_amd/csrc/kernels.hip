@@ -152,11 +152,20 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
-// One map point through the buffer path: `off` is its byte offset in the point array; the
-// resource carries the 64-bit base, so a load costs no 64-bit address arithmetic.
-__device__ __forceinline__ Point4 load_point(__amdgpu_buffer_rsrc_t pts, uint32_t off) {
-    const v4u a = __builtin_amdgcn_raw_buffer_load_b128(pts, off, 0, 0);
-    const v4u b = __builtin_amdgcn_raw_buffer_load_b128(pts, off + 16u, 0, 0);
+// One map point.  Maps under 4 GiB go through the buffer path: `off` is the point's byte offset,
+// the resource carries the 64-bit base, so a load costs no 64-bit address arithmetic.  Bigger maps
+// (BIG: `off` is the point's index) pay one 64-bit shift-add per load.
+template <bool BIG>
+__device__ __forceinline__ Point4 load_point(__amdgpu_buffer_rsrc_t pts, const Point4 *base, uint32_t off) {
+    v4u a, b;
+    if (BIG) {
+        const v4u *g = reinterpret_cast<const v4u *>(base + off);
+        a = g[0];
+        b = g[1];
+    } else {
+        a = __builtin_amdgcn_raw_buffer_load_b128(pts, off, 0, 0);
+        b = __builtin_amdgcn_raw_buffer_load_b128(pts, off + 16u, 0, 0);
+    }
     Point4 q;
     q.x = __hiloint2double(static_cast<int>(a.y), static_cast<int>(a.x));
     q.y = __hiloint2double(static_cast<int>(a.w), static_cast<int>(a.z));
@@ -255,12 +264,13 @@ __host__ __device__ constexpr unsigned icp_wave_words(int lw) {
     return static_cast<unsigned>(kRowLdsStride * (64 >> lw) + 64);
 }
 
-template <int LW, bool FUSED>
+template <int LW, bool FUSED, bool BIG>
 __global__ __launch_bounds__(64 * kIcpWavesPerBlock, SAGE_ICP_OCC) void k_icp(IcpParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     if (P.check_done && P.st->done) return;
     constexpr int W = 1 << LW;                 // lanes per query
     constexpr int QW = 64 >> LW;               // queries per wave
+    constexpr int SH = BIG ? 0 : 5;            // points are addressed by byte offset, or by index (BIG)
 #ifdef SAGE_NN_TIMING
     unsigned long long tph[5] = {0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
@@ -416,7 +426,7 @@ __global__ __launch_bounds__(64 * kIcpWavesPerBlock, SAGE_ICP_OCC) void k_icp(Ic
     // travels as a kernel argument so that it sits in scalar registers
     double best = P.dist_init;                 // scaled squared distance
     unsigned bkey = 0xFFFFFFFFu;               // (voxel << 8) | slot: the enumeration order
-    unsigned boff = 0u;                        // byte offset of the point
+    unsigned boff = 0u;                        // offset of the point (bytes, or points when BIG)
     const int pli = static_cast<int>(s.l);
     const double th = P.sem_th;
     unsigned npairs = 0u;                      // points this query's lanes were handed
@@ -455,7 +465,7 @@ __global__ __launch_bounds__(64 * kIcpWavesPerBlock, SAGE_ICP_OCC) void k_icp(Ic
                 need &= need - 1u;
                 const uint32_t w = lrow[v];
                 cnt = w & 255u;
-                base = (w >> 8) * P.cap_bytes;
+                base = (w >> 8) * (BIG ? P.cap_points : P.cap_bytes);
                 khi = v << 8;
                 i = ci;
                 npairs += cnt;
@@ -463,12 +473,12 @@ __global__ __launch_bounds__(64 * kIcpWavesPerBlock, SAGE_ICP_OCC) void k_icp(Ic
             n.ha = i < cnt;
             n.hb = i + W < cnt;
             n.ka = khi | i;
-            n.oa = base + (i << 5);
-            n.ob = n.oa + (static_cast<unsigned>(W) << 5);
+            n.oa = base + (i << SH);
+            n.ob = n.oa + (static_cast<unsigned>(W) << SH);
             // issued by every lane (idle lanes re-read point 0): a load behind a branch would make
             // the compiler drain the whole queue before the other set's evaluation
-            n.a = load_point(pts, n.ha ? n.oa : 0u);
-            n.b = load_point(pts, n.hb ? n.ob : 0u);
+            n.a = load_point<BIG>(pts, P.pts, n.ha ? n.oa : 0u);
+            n.b = load_point<BIG>(pts, P.pts, n.hb ? n.ob : 0u);
             i += n.ha ? 2u * W : 0u;
             more = (i < cnt) | (need != 0u);
         };
@@ -499,7 +509,7 @@ __global__ __launch_bounds__(64 * kIcpWavesPerBlock, SAGE_ICP_OCC) void k_icp(Ic
     constexpr unsigned kHome = 13u;
     if (FUSED) {
         const bool seeded = valid && !stale && prev.x != 0xFFFFFFFFu;
-        const Point4 pp = load_point(pts, seeded ? prev.y : 0u);
+        const Point4 pp = load_point<BIG>(pts, P.pts, seeded ? prev.y : 0u);
         scan(occ & (1u << kHome), &pp, seeded, prev.x, prev.y);
     } else {
         scan(occ & (1u << kHome), nullptr, false, 0u, 0u);
@@ -540,7 +550,7 @@ __global__ __launch_bounds__(64 * kIcpWavesPerBlock, SAGE_ICP_OCC) void k_icp(Ic
     }
 
     if (!FUSED) {
-        if (valid && ci == 0u) P.nn_idx[q] = found ? static_cast<int>(woff >> 5) : -1;
+        if (valid && ci == 0u) P.nn_idx[q] = found ? static_cast<int>(woff >> SH) : -1;
     } else {
         // ---- fused epilogue: acceptance + Gauss-Newton terms of this query's pair -----------------
         if (valid && ci == 0u) P.nn_prev[q] = make_uint4(found ? mkey : 0xFFFFFFFFu, woff, npairs, 0u);
@@ -549,7 +559,7 @@ __global__ __launch_bounds__(64 * kIcpWavesPerBlock, SAGE_ICP_OCC) void k_icp(Ic
         for (int c = 0; c < kCount; ++c) t[c] = 0.0;
         bool use = false;
         if (found && ci == 0u) {
-            const Point4 g = load_point(pts, woff);
+            const Point4 g = load_point<BIG>(pts, P.pts, woff);
             const double rx = s.x - g.x, ry = s.y - g.y, rz = s.z - g.z;
             const double r2 = rx * rx + (ry * ry + rz * rz);
             // (closest_neighboor - point).norm() < max_correspondance_distance (VoxelHashMap.cpp:111)
@@ -1056,10 +1066,14 @@ template <int LW>
 static void launch_icp_lw(const IcpParams &p, bool fused, hipStream_t s) {
     const int grid = icp_blocks_for(p.n, LW);
     const size_t lds = icp_lds_bytes(LW);
-    if (fused)
-        hipLaunchKernelGGL((k_icp<LW, true>), dim3(grid), dim3(64 * kIcpWavesPerBlock), lds, s, p);
-    else
-        hipLaunchKernelGGL((k_icp<LW, false>), dim3(grid), dim3(64 * kIcpWavesPerBlock), lds, s, p);
+    const dim3 g(grid), b(64 * kIcpWavesPerBlock);
+    if (p.big) {
+        if (fused) hipLaunchKernelGGL((k_icp<LW, true, true>), g, b, lds, s, p);
+        else hipLaunchKernelGGL((k_icp<LW, false, true>), g, b, lds, s, p);
+    } else {
+        if (fused) hipLaunchKernelGGL((k_icp<LW, true, false>), g, b, lds, s, p);
+        else hipLaunchKernelGGL((k_icp<LW, false, false>), g, b, lds, s, p);
+    }
 }
 void launch_icp(const IcpParams &p, int lw, bool fused, hipStream_t s) {
     if (p.n <= 0) return;

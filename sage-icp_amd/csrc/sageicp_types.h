@@ -26,7 +26,8 @@ constexpr uint32_t kEmptySlot = 0xFFFFFFFFu;
 constexpr uint32_t kTombstone = 0xFFFFFFFEu;
 constexpr int32_t kTombKey = 0x7F7F7F7F;
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
-constexpr int kMaxBlockBits = 23;   // block_index < 2^23
+constexpr int kMaxBlockBits = 24;   // block_index < 2^24 - 2 (the slot word keeps 8 bits for the count;
+                                    // the two top block numbers would collide with the empty / tombstone marks)
 constexpr int kMaxCap = 255;        // basic + critical points per voxel
 
 // Any hash works (the reference's 20-bit hash, VoxelHashMap.hpp:72-77, only shapes bucket

@@ -109,10 +109,10 @@ def test_c3_stream_200_frames_with_kitti_correction(tmp_path, gpu_sage, oracle):
     vel, lab = kitti_io.list_sequence(str(tmp_path))
     assert len(vel) == n_frames
     cfg = gpu_sage.make_pipeline_config()
-    a, b = gpu_sage.SageICP(cfg), oracle.Pipeline(cfg)
     # the oracle in full reference mode: robin_map emission order AND the erase-while-iterating
     # far-voxel sweep; the product reproduces the first, not the second (no effect on the poses)
     oracle.set_robin_order(3)
+    a, b = gpu_sage.SageICP(cfg), oracle.Pipeline(cfg)
     worst_t = worst_r = 0.0
     pb_all = []
     for v, l in zip(vel, lab):
