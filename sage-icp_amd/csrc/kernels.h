@@ -57,7 +57,10 @@ struct IcpParams {
     unsigned nwaves;          // waves that own queries: ceil(n / (64 >> lw))
 };
 
-constexpr int kIcpWavesPerBlock = 4;
+#ifndef SAGE_ICP_WAVES
+#define SAGE_ICP_WAVES 4
+#endif
+constexpr int kIcpWavesPerBlock = SAGE_ICP_WAVES;
 // lanes per query: a power of two 1..16 (lw = log2); few for frames that fill the chip (fewer
 // instructions per query), many for small frames / shards (shorter dependent chains per wave)
 int icp_blocks_for(int n, int lw);

@@ -257,7 +257,7 @@ __device__ unsigned long long g_nn_phase[8ull * kNnTimingSlots];   // per wave: 
 
 // per-workgroup LDS header (words): ws[4][16] fp64 sums | accepted pairs [4] | arrival counter
 constexpr unsigned kWgSums = 0, kWgPairs = 2u * 16u * kIcpWavesPerBlock, kWgArrive = kWgPairs + kIcpWavesPerBlock;
-constexpr unsigned kWgHeaderWords = 144;
+constexpr unsigned kWgHeaderWords = (kWgArrive + 1u + 15u) & ~15u;
 __host__ __device__ constexpr unsigned icp_wave_words(int lw) {
     // the rows of the wave's queries (kRowLdsStride words each); reused by the epilogue's
     // transposed reduction, 16 components x (queries + 2) fp64
@@ -688,26 +688,19 @@ __device__ __forceinline__ void reduce_partials(const double *partials, int npar
     const int t = static_cast<int>(threadIdx.x);
     const int pr = t % 10, sl = t / 10;
     if (sl < kFinSlices) {
-        // fixed summation order; loads are independent, 8 in flight per thread
+        // fixed summation order; the loads are independent: up to 24 in flight per thread (one
+        // memory round trip for up to 2,448 partials, the cold-L2 latency is what this kernel costs)
         double2 v = make_double2(0.0, 0.0);
         const double2 *src = reinterpret_cast<const double2 *>(partials) + pr;
-        int b = sl;
-        for (; b + 7 * kFinSlices < nparts; b += 8 * kFinSlices) {
-            double2 u[8];
+        for (int b = sl; b < nparts; b += 24 * kFinSlices) {
+            double2 u[24];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) u[k] = src[static_cast<size_t>(b + k * kFinSlices) * 10];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { v.x += u[k].x; v.y += u[k].y; }
-        }
-        {
-            double2 u[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < 24; ++k) {
                 const int bb = b + k * kFinSlices;
                 u[k] = bb < nparts ? src[static_cast<size_t>(bb) * 10] : make_double2(0.0, 0.0);
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { v.x += u[k].x; v.y += u[k].y; }
+            for (int k = 0; k < 24; ++k) { v.x += u[k].x; v.y += u[k].y; }
         }
         part[sl][2 * pr] = v.x;
         part[sl][2 * pr + 1] = v.y;
