@@ -7,7 +7,7 @@ SRC = ["sage-icp_amd/csrc/%s.hip" % n for n in ("kernels", "sort", "preprocess",
 FLAGS = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
 if "PHASE_LIB" not in os.environ:
     os.makedirs("gpurun_out", exist_ok=True)
-    for kind in ("NN",):
+    for kind in ("NN", "GN"):
         out = os.path.abspath("gpurun_out/libsageicp_t%s.so" % kind)
         subprocess.check_call(FLAGS + ["-DSAGE_%s_TIMING" % kind] + SRC + ["-o", out, "-ldl"])
         subprocess.call([sys.executable, __file__] + sys.argv[1:], env=dict(os.environ, PHASE_LIB=out, PHASE_KIND=kind))
@@ -43,8 +43,6 @@ for div in [int(a) for a in sys.argv[1:]] or [1, 8, 120]:
         run()
         L.sageicp_debug_gn_phases(buf, 0)
         v = list(buf); k = max(v[4], 1)
-        print("k_gn %d queries, last workgroup, %d launches" % (n, k))
-        for i, nm in enumerate(["pair loop", "block reduce + partial store", "release + ticket + acquire", "finish_iteration"]):
-            print("   %-32s %6.2f us" % (nm, v[i] / k / 100.0))
-        for i, nm in enumerate(["fin: reduce partials", "fin: assemble + LDLT", "fin: se3 exp", "fin: compose + norm + state"]):
-            print("   %-32s %6.2f us" % (nm, v[8 + i] / k / 100.0))
+        print("k_fin after %d queries, %d launches (100-MHz ticks -> us)" % (n, k))
+        for i, nm in enumerate(["reduce the partials", "assemble + LDLT", "se3 exp", "compose + norm + state + progress"]):
+            print("   %-36s %6.2f us" % (nm, v[8 + i] / k / 100.0))

@@ -860,8 +860,14 @@ __global__ __launch_bounds__(kFinThreads) void k_fin(FinParams P) {
     if (!P.standalone && P.st->done) return;
     __shared__ double S[kNumSums];
     IcpState *st = P.st;
+#ifdef SAGE_GN_TIMING
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#endif
     if (P.mode != 2) {
         reduce_partials(P.partials, P.nparts, S);
+#ifdef SAGE_GN_TIMING
+        if (threadIdx.x == 0) atomicAdd(&g_gn_phase[8], __builtin_amdgcn_s_memrealtime() - t_start);
+#endif
         if (threadIdx.x < kNumSums) st->sums[threadIdx.x] = S[threadIdx.x];
         if (P.mode == 1) return;
         if (P.mode == 3) {
