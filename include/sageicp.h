@@ -57,7 +57,7 @@ typedef struct sageicp_stats {
     double us_gn;               /* always 0 (the accumulation is part of k_icp) */
     double us_fin;              /* k_fin: reduction of the partials, solve, pose update */
     uint32_t nn_launches;       /* k_icp launches that were timed (us_nn / nn_launches = mean duration) */
-    uint32_t resorts;           /* re-sorts of the frame after the pose drifted (first sort excluded) */
+    uint32_t resorts;           /* always 0 (the frame is ordered once per call) */
     uint64_t sum_candidates;    /* sum over iterations and queries of C_q: map points stored in the
                                  * <=27 existing neighbour voxels of each query (this rank) */
     uint32_t n_corr_hist[64];   /* accepted correspondences of the first 64 iterations */

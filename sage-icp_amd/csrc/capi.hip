@@ -949,38 +949,20 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     ip.counters = stats ? sc.d_cand : nullptr;
     if (stats) HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * 2 * (ip.nwaves + 1), s));
 
-    // Spatial re-ordering of the frame: the loop runs on a copy sorted by map-frame voxel under
-    // the current pose, so that the queries of a wave share home voxels and neighbouring waves
-    // touch neighbouring voxel blocks (L1 / L2 hits, similar work per lane).  Every query's
-    // neighbourhood row is (re)built for the new order; inside the loop a row is redone only when
-    // its query crosses a voxel face.  The pose of a cold start travels metres; once it has
-    // carried the points half a voxel away from where they were sorted the order has decayed, and
-    // the copy is re-sorted from the pristine frame at the next check point.
-    const Point4 *d_pristine = d_frame;
-    double T_sorted[7];
-    for (int i = 0; i < 7; ++i) T_sorted[i] = init[i];
-    auto sort_now = [&]() -> int {
-        HIPCHK(sort_frame(d_pristine, sc.d_sorted, static_cast<int>(n), sc.d_state, true,
+    // Spatial ordering of the frame: the loop runs on a copy sorted by map-frame voxel under the
+    // initial guess, so that the queries of a wave share home voxels and neighbouring waves touch
+    // neighbouring voxel blocks (L1 / L2 hits, similar work per lane), and every query's
+    // neighbourhood row is built for that order; inside the loop a row is redone only when its
+    // query crosses a voxel face.  (Round 1 re-sorted when the pose had drifted half a voxel; with a
+    // lane per query that no longer pays for its ~90 us: 45.3 against 47.2 us per iteration on the
+    // c2 cold start, profiles/README.md.)
+    if (n > 0) {
+        HIPCHK(sort_frame(d_frame, sc.d_sorted, static_cast<int>(n), sc.d_state, true,
                           m->host.voxel_size, sc.d_keys, sc.d_vals, sc.d_sort_temp,
                           sc.sort_temp_bytes_, s));
         launch_rows(ip, s);
-        // the records of the last iteration were indexed by the old order
-        HIPCHK(hipMemsetAsync(sc.d_prev, 0xFF, n * sizeof(uint4), s));
-        return SAGEICP_OK;
-    };
-    // displacement bound of a point within the map range between two poses
-    auto drift = [&](const double a[7], const double b[7]) {
-        const double dt = std::sqrt((a[4] - b[4]) * (a[4] - b[4]) + (a[5] - b[5]) * (a[5] - b[5]) +
-                                    (a[6] - b[6]) * (a[6] - b[6]));
-        double dot = std::fabs(a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]);
-        if (dot > 1.0) dot = 1.0;
-        return dt + 2.0 * std::acos(dot) * m->host.max_distance;
-    };
-    // (a sort costs about as much as one iteration of a 40k-point frame saves over the rest of
-    // the loop: small frames keep their first order)
-    const double resort_drift = 0.01 * env_int("SAGEICP_RESORT_PCT", 50) * m->host.voxel_size;
-    const bool resort_on = n >= static_cast<uint64_t>(env_int("SAGEICP_RESORT_MIN_N", 40000));
-    if (n > 0 && (rc = sort_now())) return rc;
+        HIPCHK(hipMemsetAsync(sc.d_prev, 0xFF, n * sizeof(uint4), s));     // no previous answers yet
+    }
 
     FinParams fp{};
     fp.st = sc.d_state;
@@ -1000,7 +982,6 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     }
 
     double us_nn = 0, us_fin = 0;
-    uint32_t resorts = 0;
     uint32_t nn_launches = 0;
     // one iteration; `slot` indexes its 5 profiling events
     // Profiling level 1 brackets k_icp in one iteration out of 8 (two event records cost ~6 us of
@@ -1033,10 +1014,8 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         us_nn += 1e3 * a; us_fin += 1e3 * b;
         ++nn_launches;
     };
-    // Re-sorts are decided at fixed points of the enqueue sequence from the pose of a fixed
-    // iteration, and the sort runs on whatever pose the device holds when the stream reaches it:
-    // nothing depends on when the host happens to look (results are reproducible bit for bit).
-    // Checked before iterations 8, 16, ...: has the pose drifted half a voxel from the sorted order?
+    // (nothing the host does depends on WHEN it looks at the progress word: a call repeated gives
+    // the same bits)
     if (polled) {
         const int depth = std::min(8, std::max(1, env_int("SAGEICP_DEPTH", 4)));
         volatile unsigned long long *word = &sc.h_prog->word;
@@ -1047,18 +1026,6 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
             const int comp = static_cast<int>(w & 0xFFFFFFFFull);
             if (w >> 32) break;                                  // converged or out of iterations
             if (enq < kMaxIterations && enq - comp < depth) {
-                if (resort_on && enq >= 8 && (enq & 7) == 0) {
-                    const int j = std::max(1, enq - depth + 1);   // completed: comp > enq - depth
-                    volatile double *slot = sc.h_prog->T[j % kProgressRing];
-                    __atomic_thread_fence(__ATOMIC_ACQUIRE);
-                    double Tj[7];
-                    for (int i = 0; i < 7; ++i) Tj[i] = slot[i];
-                    if (slot[7] == static_cast<double>(j) && drift(Tj, T_sorted) > resort_drift) {
-                        if ((rc = sort_now())) return rc;
-                        for (int i = 0; i < 7; ++i) T_sorted[i] = Tj[i];
-                        ++resorts;
-                    }
-                }
                 if ((rc = enqueue_iteration(enq, enq))) return rc;
                 ++enq;
                 spins = 0;
@@ -1098,11 +1065,6 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
             }
             launched += todo;
             if (sc.h_state->done || launched >= kMaxIterations) break;
-            if (resort_on && drift(sc.h_state->T, T_sorted) > resort_drift) {
-                if ((rc = sort_now())) return rc;
-                for (int i = 0; i < 7; ++i) T_sorted[i] = sc.h_state->T[i];
-                ++resorts;
-            }
             chunk = std::min(kChunkMax, chunk * 2);   // 4, 8, 16, 16, ... : few syncs, bounded no-op tail
         }
     }
@@ -1129,7 +1091,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         stats->us_upload = us_upload;
         stats->us_nn = us_nn; stats->us_fin = us_fin;
         stats->nn_launches = nn_launches;
-        stats->resorts = resorts;
+        stats->resorts = 0;
         stats->sum_candidates = st.sum_candidates;
         stats->pairs_evaluated = st.sum_pairs;
         stats->lanes_per_query = 1u << lw;

@@ -752,14 +752,17 @@ __device__ __forceinline__ void solve_and_publish(IcpState *st, const double *S)
     if (lane != 0) return;
     quat_to_mat(Tn, st->R);
 
-    // ||log(exp(x))|| == ||x|| (principal branch, |omega| < pi, which a Gauss-Newton step of a
-    // converging registration always satisfies): the reference's estimation.log().norm()
-    // (Registration.cpp:137) without the atan2/sincos round trip on one serial lane.
+    // ||log(exp(x))|| == ||x|| on the principal branch up to a few ulps, so the reference's
+    // estimation.log().norm() (Registration.cpp:137) is taken from x without the atan2 / sincos
+    // round trip on one serial lane — except where those ulps could matter: a step within 1e-12
+    // (relative 1e-8; the two differ by ~1e-19 there) of the stop threshold, or |omega| >= 3,
+    // goes through the exact log so that the stop iteration is the reference's in every case.
     double nrm = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) nrm += x[i] * x[i];
     nrm = sqrt(nrm);
-    if (!(x[3] * x[3] + x[4] * x[4] + x[5] * x[5] < 9.0)) {   // |omega| >= 3: take the exact path
+    if (!(x[3] * x[3] + x[4] * x[4] + x[5] * x[5] < 9.0) ||
+        fabs(nrm - kEstimationThreshold) < 1e-12) {
         double lg[6];
         se3_log(est, lg);
         nrm = 0.0;
@@ -781,16 +784,9 @@ __device__ __forceinline__ void solve_and_publish(IcpState *st, const double *S)
     }
     if (st->done) done = 1;                    // e.g. stopped by a failed multi-GPU exchange
     if (IcpProgress *pg = st->progress) {
-        // host-mapped: the pose (tagged with its iteration) into its ring slot, then the progress
-        // word, as relaxed system-scope (write-through) stores; the host only steers its look-ahead
-        // and its re-sort decisions by these values and reads the final state through an ordinary
-        // copy after the loop
+        // host-mapped, a relaxed system-scope (write-through) store: the host only steers its
+        // look-ahead by this word and reads the final state through an ordinary copy after the loop
         const unsigned long long seq = static_cast<unsigned long long>(it + 1);
-        double *slot = pg->T[seq % kProgressRing];
-#pragma unroll
-        for (int i = 0; i < 7; ++i)
-            __hip_atomic_store(&slot[i], Tn[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&slot[7], static_cast<double>(seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&pg->word, (done << 32) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 #ifdef SAGE_GN_TIMING

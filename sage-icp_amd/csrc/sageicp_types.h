@@ -55,17 +55,13 @@ constexpr double kEstimationThreshold = 1e-4;  // Registration.cpp:97
 constexpr int kNumSums = 20;               // 16 closed-form GN sums + count + 3 pad
 constexpr int kHistory = 512;
 
-// Loop progress as the host sees it while the loop runs: a small block of pinned, host-mapped
-// memory the finishing lane writes after every iteration — the pose into slot (iteration % 16) of
-// a ring, then one 64-bit word (done << 32) | iterations, write-through stores — polled by run_icp
-// to keep a few iterations enqueued ahead of the GPU without a stream synchronisation per check.
-// The ring lets the host read the pose of a SPECIFIC iteration (the loop runs at most a handful of
-// iterations ahead of what the host has seen), so its re-sort decisions do not depend on timing.
-constexpr int kProgressRing = 16;
+// Loop progress as the host sees it while the loop runs: one 64-bit word (done << 32) | iterations
+// in pinned, host-mapped memory, written by the finishing lane after every iteration (a
+// write-through store) and polled by run_icp to keep a few iterations enqueued ahead of the GPU
+// without a stream synchronisation per check.
 struct IcpProgress {
     unsigned long long word;               // (done << 32) | iterations completed
-    unsigned long long pad_;
-    double T[kProgressRing][8];            // [it % 16]: cumulative pose after `it` iterations | it
+    unsigned long long pad_[7];
 };
 
 // Direct exchange of the Gauss-Newton sums between the GPUs of one node (multi-GPU, no RCCL

@@ -652,8 +652,7 @@ def test_c2_full_size_properties(gpu_sage, oracle):
                                    p["sem_th"])
     dt, dr = pose_error(oracle, opose, pose)
     assert dt < TOL_M and dr < TOL_RAD and st.iterations == ost.iterations
-    # re-sorts are decided at fixed points of the launch sequence: the same call again gives the
-    # same bits (the frame is large enough to be re-sorted during the loop)
+    # nothing in the loop depends on when the host looks: the same call again gives the same bits
     again, st_again = gpu_sage.register_frame(w["scan"], w["map"], gpu_sage.IDENTITY, p["max_dist"],
                                               p["kernel"], p["sem_th"], return_stats=True)
-    assert np.array_equal(again, pose) and st_again.resorts == st.resorts >= 1
+    assert np.array_equal(again, pose) and st_again.iterations == st.iterations
