@@ -1943,3 +1943,11 @@ int sageicp_metrics_absolute_trajectory_error(const double *poses_gt, const doub
 }
 
 }  // extern "C"
+
+#ifdef SAGE_NN_TIMING
+// probe: every query's record of the last iteration (sorted order): {key, offset, points handed out, -}
+extern "C" int sageicp_debug_prev(const sageicp_map *m, uint32_t *out, size_t n) {
+    if (!m || !m->sc.d_prev) return SAGEICP_ERR_INVALID;
+    return hipMemcpy(out, m->sc.d_prev, n * 16, hipMemcpyDeviceToHost) == hipSuccess ? SAGEICP_OK : SAGEICP_ERR_HIP;
+}
+#endif

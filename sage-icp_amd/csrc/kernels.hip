@@ -56,7 +56,7 @@
 #define SAGE_ICP_STRIPE 8      // workgroups of the sorted frame per XCD stripe
 #endif
 #ifndef SAGE_ICP_OCC
-#define SAGE_ICP_OCC 2         // workgroups of 4 waves per SIMD the register allocation aims for
+#define SAGE_ICP_OCC 7         // waves per SIMD the register allocation of k_icp is held to
 #endif
 
 #include "kernels.h"
@@ -151,6 +151,7 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 }
 
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
 
 // One map point.  Maps under 4 GiB go through the buffer path: `off` is the point's byte offset,
 // the resource carries the 64-bit base, so a load costs no 64-bit address arithmetic.  Bigger maps
@@ -250,6 +251,8 @@ __global__ __launch_bounds__(256) void k_rows(IcpParams P) {
 #ifdef SAGE_NN_TIMING
 constexpr unsigned kNnTimingSlots = 1u << 17;
 __device__ unsigned long long g_nn_phase[8ull * kNnTimingSlots];   // per wave: 5 phases, lifetime, realtime, count
+__device__ unsigned long long g_nn_span[4ull * kNnTimingSlots];    // per wave, iteration g_nn_span_iter: start, end (100-MHz ticks), HW_ID, pairs
+__device__ int g_nn_span_iter;
 #define NN_T(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); tph[i] += _t - tprev; tprev = _t; } while (0)
 #else
 #define NN_T(i) do { } while (0)
@@ -265,9 +268,18 @@ __host__ __device__ constexpr unsigned icp_wave_words(int lw) {
 }
 
 template <int LW, bool FUSED, bool BIG>
-__global__ __launch_bounds__(64 * kIcpWavesPerBlock, SAGE_ICP_OCC) void k_icp(IcpParams P) {
+__device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem);
+
+template <int LW, bool FUSED, bool BIG>
+__global__ __launch_bounds__(64 * kIcpWavesPerBlock) __attribute__((amdgpu_waves_per_eu(SAGE_ICP_OCC, 8)))
+void k_icp(IcpParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     if (P.check_done && P.st->done) return;
+    icp_body<LW, FUSED, BIG>(P, smem);
+}
+
+template <int LW, bool FUSED, bool BIG>
+__device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
     constexpr int W = 1 << LW;                 // lanes per query
     constexpr int QW = 64 >> LW;               // queries per wave
     constexpr int SH = BIG ? 0 : 5;            // points are addressed by byte offset, or by index (BIG)
@@ -426,14 +438,20 @@ __global__ __launch_bounds__(64 * kIcpWavesPerBlock, SAGE_ICP_OCC) void k_icp(Ic
     // travels as a kernel argument so that it sits in scalar registers
     double best = P.dist_init;                 // scaled squared distance
     unsigned bkey = 0xFFFFFFFFu;               // (voxel << 8) | slot: the enumeration order
-    unsigned boff = 0u;                        // offset of the point (bytes, or points when BIG)
     const int pli = static_cast<int>(s.l);
     const double th = P.sem_th;
     unsigned npairs = 0u;                      // points this query's lanes were handed
 
-    // voxel cursor of this lane: points i, i + W, ... of the open voxel
-    unsigned cnt = 0u, base = 0u, i = ci, khi = 0u;
-    auto evaluate = [&](const Point4 &nb, unsigned key, unsigned off) {
+    // voxel cursor of this lane: it takes points ci, ci + W, ... of the open voxel.  k = (voxel <<
+    // 8) | slot of its next point, kend = (voxel << 8) | points in the voxel, off = where point k
+    // lives (bytes, or points when BIG).  Only the key of the winner is tracked; its offset is
+    // rebuilt from the row once per query.
+    unsigned k = ci, kend = 0u, off = 0u;
+    // Branch-free: a lane that holds no point here (`on` false: it re-read point 0) turns its
+    // distance into a NaN, which loses every comparison.  With no branch around the evaluation the
+    // compiler keeps counted waits (vmcnt(4)) in the scan loop: the younger register set's loads
+    // stay in flight under every evaluation instead of the queue being drained at the joins.
+    auto evaluate = [&](const Point4 &nb, bool on, unsigned key) {
         const double dx = nb.x - s.x, dy = nb.y - s.y, dz = nb.z - s.z;
         double d = dx * dx + (dy * dy + dz * dz);
         // same label, or either side unlabelled (VoxelHashMap.cpp:87-88)
@@ -441,13 +459,13 @@ __global__ __launch_bounds__(64 * kIcpWavesPerBlock, SAGE_ICP_OCC) void k_icp(Ic
         const bool same = static_cast<int>(nb.l) == pli || fabs(nb.l * s.l) < 1.0;
         const double ds = d * th;
         d = same ? ds : d;
+        d = __hiloint2double(on ? __double2hiint(d) : 0x7FF80000, __double2loint(d));
         // lexicographic (d, key): the home voxel is visited first, out of enumeration order;
         // a NaN distance never wins
         const bool lt = d < best, eq = d == best, kl = key < bkey;
         const bool take = lt | (eq & kl);
         best = min_f64(best, d);
         bkey = take ? key : bkey;
-        boff = take ? off : boff;
     };
     // Per-lane state machine over the voxels in `need` (and the one already open).  A step handles
     // two points of the open voxel (i and i + W); two register sets alternate, so while one pair
@@ -455,46 +473,50 @@ __global__ __launch_bounds__(64 * kIcpWavesPerBlock, SAGE_ICP_OCC) void k_icp(Ic
     // edge: the wait before an evaluation leaves the younger loads outstanding).
     struct Pair {
         Point4 a, b;
-        unsigned ka, oa, ob;        // key / offset of a; b: key + W, offset ob
+        unsigned ka;                // key of a; b: key + W
         bool ha, hb;
     };
-    auto scan = [&](unsigned need, const Point4 *seed, bool seeded, unsigned seed_key, unsigned seed_off) {
+    auto scan = [&](unsigned need, const Point4 *seed, bool seeded, unsigned seed_key) {
         auto issue = [&](Pair &n, bool &more) {
-            while (i >= cnt && need) {         // open this lane's next voxel
+            while (k >= kend && need) {        // open this lane's next voxel
                 const unsigned v = static_cast<unsigned>(__builtin_ctz(need));
                 need &= need - 1u;
                 const uint32_t w = lrow[v];
-                cnt = w & 255u;
-                base = (w >> 8) * (BIG ? P.cap_points : P.cap_bytes);
-                khi = v << 8;
-                i = ci;
-                npairs += cnt;
+                kend = (v << 8) | (w & 255u);
+                k = (v << 8) | ci;
+                off = (w >> 8) * (BIG ? P.cap_points : P.cap_bytes) + (ci << SH);
+                npairs += w & 255u;
             }
-            n.ha = i < cnt;
-            n.hb = i + W < cnt;
-            n.ka = khi | i;
-            n.oa = base + (i << SH);
-            n.ob = n.oa + (static_cast<unsigned>(W) << SH);
+            n.ha = k < kend;
+            n.hb = k + W < kend;
+            n.ka = k;
             // issued by every lane (idle lanes re-read point 0): a load behind a branch would make
             // the compiler drain the whole queue before the other set's evaluation
-            n.a = load_point<BIG>(pts, P.pts, n.ha ? n.oa : 0u);
-            n.b = load_point<BIG>(pts, P.pts, n.hb ? n.ob : 0u);
-            i += n.ha ? 2u * W : 0u;
-            more = (i < cnt) | (need != 0u);
+            n.a = load_point<BIG>(pts, P.pts, n.ha ? off : 0u);
+            n.b = load_point<BIG>(pts, P.pts, n.hb ? off + (static_cast<unsigned>(W) << SH) : 0u);
+            // the evaluation of the other set stays below these loads (the scheduler would
+            // otherwise sink them under the arithmetic it believes is ready)
+            __builtin_amdgcn_sched_barrier(0);
+            k += n.ha ? 2u * W : 0u;
+            off += n.ha ? (2u * W) << SH : 0u;
+            more = (k < kend) | (need != 0u);
         };
         auto consume = [&](const Pair &n) {
-            if (n.ha) evaluate(n.a, n.ka, n.oa);
-            if (n.hb) evaluate(n.b, n.ka + W, n.ob);
+            evaluate(n.a, n.ha, n.ka);
+            evaluate(n.b, n.hb, n.ka + W);
         };
         Pair A, B;
         bool more = false;
         issue(A, more);
         // the seed's load is older than A's: waiting for it leaves A's loads in flight
-        if (seed && seeded) evaluate(*seed, seed_key, seed_off);
+        if (seed) evaluate(*seed, seeded, seed_key);
+        // One exit per double step: an exit between the two halves gives the loop header a
+        // predecessor with B's loads pending, and the compiler then drains the queue (vmcnt(0))
+        // before every issue(B) — the overlap this loop exists for.  A scan that ends after the
+        // first half pays one idle half step instead.
         for (;;) {
             issue(B, more);
             consume(A);
-            if (!__ballot(B.ha | more)) break;
             issue(A, more);
             consume(B);
             if (!__ballot(A.ha | more)) break;
@@ -510,9 +532,9 @@ __global__ __launch_bounds__(64 * kIcpWavesPerBlock, SAGE_ICP_OCC) void k_icp(Ic
     if (FUSED) {
         const bool seeded = valid && !stale && prev.x != 0xFFFFFFFFu;
         const Point4 pp = load_point<BIG>(pts, P.pts, seeded ? prev.y : 0u);
-        scan(occ & (1u << kHome), &pp, seeded, prev.x, prev.y);
+        scan(occ & (1u << kHome), &pp, seeded, prev.x);
     } else {
-        scan(occ & (1u << kHome), nullptr, false, 0u, 0u);
+        scan(occ & (1u << kHome), nullptr, false, 0u);
     }
     NN_T(2);
     // what the query holds after its home voxel bounds the rest of its search
@@ -524,16 +546,17 @@ __global__ __launch_bounds__(64 * kIcpWavesPerBlock, SAGE_ICP_OCC) void k_icp(Ic
         const double lb = gx[v / 9] + (gy[(v / 3) % 3] + gz[v % 3]);
         need |= (lb <= bound) ? (1u << v) : 0u;
     }
-    scan(need & occ & ~(1u << kHome), nullptr, false, 0u, 0u);
+    scan(need & occ & ~(1u << kHome), nullptr, false, 0u);
 
     // argmin over the W lanes of the query: first the minimum distance (never NaN: a NaN distance
-    // fails every comparison), then the smallest key among the lanes that hold it, then the
-    // winner's offset (keys are unique, so exactly one lane holds it)
+    // fails every comparison), then the smallest key among the lanes that hold it; the winner's
+    // offset follows from its key and the row
     const double m = seg_min_f64<W>(best);
     const unsigned mine = (best == m) ? bkey : 0xFFFFFFFFu;
     const unsigned mkey = seg_min_u32<W>(mine);
-    const unsigned woff = seg_min_u32<W>((mine == mkey) ? boff : 0xFFFFFFFFu);
     const bool found = valid && mkey != 0xFFFFFFFFu;       // else: empty neighbourhood (hazard H1)
+    const unsigned woff = (lrow[found ? mkey >> 8 : 0u] >> 8) * (BIG ? P.cap_points : P.cap_bytes) +
+                          ((mkey & 255u) << SH);
     NN_T(3);
 
     if (P.counters) {                          // C_q and pairs handed out, summed over the wave
@@ -627,12 +650,29 @@ __global__ __launch_bounds__(64 * kIcpWavesPerBlock, SAGE_ICP_OCC) void k_icp(Ic
 #ifdef SAGE_NN_TIMING
     // private slot per wave (no contended atomics: they would stall the very loads being timed)
     NN_T(4);
+    unsigned long long np_packed;
+    {   // points handed to the queries of this wave: max over the queries | sum
+        unsigned mx = valid ? npairs : 0u, sm = (valid && ci == 0u) ? npairs : 0u;
+        for (int d = 1; d < 64; d <<= 1) {
+            mx = max(mx, static_cast<unsigned>(__shfl_xor(mx, d, 64)));
+            sm += __shfl_xor(sm, d, 64);
+        }
+        np_packed = (static_cast<unsigned long long>(mx) << 32) | sm;
+    }
     if (lane == 0 && wave_id < kNnTimingSlots && wave_id < P.nwaves) {
         unsigned long long *tt = g_nn_phase + 8ull * wave_id;
         for (int k = 0; k < 5; ++k) tt[k] += tph[k];
         tt[5] += __builtin_amdgcn_s_memtime() - tstart;
         tt[6] += __builtin_amdgcn_s_memrealtime() - rstart;
         tt[7] += 1ull;
+        unsigned long long *sp = g_nn_span + 4ull * wave_id;
+        if (P.st->iter == g_nn_span_iter) {
+        sp[0] = rstart;
+        sp[1] = __builtin_amdgcn_s_memrealtime();
+        sp[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |   // HW_REG_HW_ID
+                (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11))) << 32);   // HW_REG_XCC_ID
+        sp[3] = np_packed;
+        }
     }
 #endif
 }
@@ -959,6 +999,19 @@ extern "C" void sageicp_debug_gn_phases(unsigned long long out[16], int reset) {
 }
 #endif
 #ifdef SAGE_NN_TIMING
+extern "C" void sageicp_debug_nn_spans(unsigned long long *out, unsigned nwaves, int next_iter) {
+    // raw {start, end, HW_ID, pairs of lane 0} of the first `nwaves` waves of the k_icp launch of
+    // the iteration chosen by the previous call; `next_iter` chooses the one the next loop records
+    if (nwaves > kNnTimingSlots) nwaves = kNnTimingSlots;
+    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_span), 4ull * nwaves * sizeof(unsigned long long));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_nn_span_iter), &next_iter, sizeof(int));
+}
+extern "C" void sageicp_debug_nn_raw(unsigned long long *out, unsigned nwaves) {
+    // per wave slot, summed over the launches since the last reset: 5 phases and the lifetime
+    // (shader cycles), the lifetime in 100-MHz ticks, launches
+    if (nwaves > kNnTimingSlots) nwaves = kNnTimingSlots;
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_phase), 8ull * nwaves * sizeof(unsigned long long));
+}
 extern "C" void sageicp_debug_nn_phases(unsigned long long out[16], int reset) {
     // out: [0..4] summed cycles of the five phases (loads, row, home scan, rest of the search,
     // epilogue), [5] summed wave lifetime (shader cycles), [6] the same in 100-MHz ticks, [7] waves,

@@ -4,8 +4,11 @@
 // fall into under the current pose, so that the queries of a k_icp wave are neighbours: they touch
 // the same voxel blocks (L1/L2 hits) and cost about the same.  run_icp re-sorts when the
 // pose has carried the points a fraction of a voxel away from the order they were sorted in.
-// (Ordering the queries by the work the previous iteration measured — heavy ones first, Morton
-// within a work class — was tried and is not kept: no gain on MI355X, profiles/README.md.)
+// (Re-ordering the queries by the work the previous iteration measured was tried in four forms —
+// frame-wide work classes; sorted, or dealt out evenly over the waves, inside chunks of 1024
+// consecutive queries; sorted inside one workgroup's 64 queries — and is not kept: the lockstep
+// efficiency of a wave rises from 0.42 to 0.96 and the kernel gets slower or stays where it was,
+// because the queries of a wave then no longer share cache lines; profiles/README.md.)
 // A stable sort keeps the result — and therefore the fp64 summation order of the Gauss-Newton
 // sums — bit-reproducible from run to run.
 #include <hip/hip_runtime.h>
