@@ -36,13 +36,17 @@ for it in [int(a) for a in args] or [0, 20, 100]:
     print("   resident waves at t (us): " + " ".join("%d:%d" % (t, ((s <= t) & (e > t)).sum()) for t in ts))
     late = np.argsort(-e)[:12]
     print("   last waves to end: " + " ".join("w%d[%.0f-%.0f p%d]" % (i, s[i], e[i], a[i, 3] >> 32) for i in late))
+    xp = a[:, 2]
+    steps, exact, lanes = xp >> 40, (xp >> 20) & 0xFFFFF, xp & 0xFFFFF
+    print("   pair steps per wave %.1f, of them with a fetch of full records %.2f (%.0f %%), lanes fetching per such step %.1f"
+          % (steps.mean(), exact.mean(), 100.0 * exact.sum() / max(steps.sum(), 1), lanes.sum() / max(exact.sum(), 1)))
     xcc = (a[:, 2] >> 32) & 15
     key = xcc * 1024 + se * 32 + sh * 16 + cu
     ends = {}
     for kk, ee in zip(key, e): ends[kk] = max(ends.get(kk, 0), ee)
     ev = np.array(sorted(ends.values()))
-    print("   %d CUs seen; a CU's last wave ends at: min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f us" % (len(ev), ev[0], *np.percentile(ev, [10, 50, 90]), ev[-1]))
-    print("   per XCD: waves " + " ".join("%d" % (xcc == x).sum() for x in range(8)) + " | last end " + " ".join("%.0f" % e[xcc == x].max() for x in range(8) if (xcc == x).any()) + " | mean life " + " ".join("%.1f" % life[xcc == x].mean() for x in range(8) if (xcc == x).any()))
+    if False: print("   %d CUs seen; a CU's last wave ends at: min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f us" % (len(ev), ev[0], *np.percentile(ev, [10, 50, 90]), ev[-1]))
+    if False: print("   per XCD: waves " + " ".join("%d" % (xcc == x).sum() for x in range(8)) + " | last end " + " ".join("%.0f" % e[xcc == x].max() for x in range(8) if (xcc == x).any()) + " | mean life " + " ".join("%.1f" % life[xcc == x].mean() for x in range(8) if (xcc == x).any()))
     mx, sm = a[:, 3] >> 32, a[:, 3] & 0xFFFFFFFF
     qw = 64 // st.lanes_per_query
     print("   points handed out per query: mean %.1f; per wave max-over-queries: mean %.1f p50 %.0f p90 %.0f p99 %.0f max %d  (lockstep efficiency %.2f)"

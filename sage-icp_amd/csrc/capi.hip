@@ -443,6 +443,12 @@ struct sageicp_map {
     mutable Point4 *d_pts = nullptr;
     mutable size_t d_blocks_cap = 0;     // blocks
     mutable bool mirror_stale_all = true;
+    // compact copy of d_pts for k_icp's scan (fp32 x, y, z, label), derived on the device whenever
+    // the HBM copy of the map has changed since the last search
+    mutable uint4 *d_cand = nullptr;
+    mutable size_t d_cand_slots = 0;     // point slots it holds
+    mutable uint32_t *d_cand_flags = nullptr;
+    mutable bool cand_stale = true;
     // pinned staging + device landing buffers for the scattered refresh of changed records
     mutable void *h_stage = nullptr;
     mutable void *d_stage = nullptr;
@@ -618,9 +624,39 @@ int sync_mirror(const sageicp_map *m) {
         HIPCHK(hipGetLastError());
         any = true;
     }
-    if (any) HIPCHK(hipStreamSynchronize(s));
+    if (any) {
+        HIPCHK(hipStreamSynchronize(s));
+        m->cand_stale = true;
+    }
     const_cast<HostMap &>(h).clear_dirty();
     m->mirror_stale_all = false;
+    return SAGEICP_OK;
+}
+
+// The compact copy the scan reads (kernels.hip, k_derive_cand): rebuilt from the HBM copy of the
+// map when that has changed (mirror refresh, device-side update, clone).  One pass over the hash
+// table and the live points; the ICP loop that follows reads the map ~150 times.
+int ensure_cand(const sageicp_map *m) {
+    hipStream_t s = m->sc.stream;
+    const size_t slots = m->d_blocks_cap * static_cast<size_t>(m->host.cap);
+    if (!m->d_cand_flags) {
+        HIPCHK(hipMalloc(&m->d_cand_flags, 16));
+        HIPCHK(hipMemsetAsync(m->d_cand_flags, 0, 16, s));
+    }
+    if (slots > m->d_cand_slots) {
+        if (m->d_cand) HIPCHK(hipFree(m->d_cand));
+        m->d_cand = nullptr; m->d_cand_slots = 0;
+        HIPCHK(hipMalloc(&m->d_cand, (slots + 1) * sizeof(uint4)));
+        m->d_cand_slots = slots;
+        m->cand_stale = true;
+    }
+    if (!m->cand_stale) return SAGEICP_OK;
+    HIPCHK(hipMemsetAsync(m->d_cand_flags, 0, 16, s));
+    if (m->d_table && m->d_pts && slots)
+        launch_derive_cand(m->d_table, static_cast<uint32_t>(m->d_table_cap), m->d_pts, m->d_cand,
+                           static_cast<uint32_t>(m->host.cap), slots, m->d_cand_flags, s);
+    HIPCHK(hipGetLastError());
+    m->cand_stale = false;
     return SAGEICP_OK;
 }
 
@@ -840,6 +876,7 @@ int device_update(sageicp_map *m, const double *xyzl, uint64_t n, const double p
     }
     m->ctr = *m->h_ctr;
     m->on_device = true;
+    m->cand_stale = true;
     const_cast<HostMap &>(h).clear_dirty();
     m->mirror_stale_all = false;
     return SAGEICP_OK;
@@ -888,6 +925,26 @@ IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, 
     const uint64_t pts_bytes = (static_cast<uint64_t>(m->d_blocks_cap) * m->host.cap + 1) * sizeof(Point4);
     ip.big = pts_bytes >= (1ull << 32) || env_int("SAGEICP_FORCE_BIG", 0);
     ip.pts_bytes = ip.big ? 0u : static_cast<uint32_t>(pts_bytes);
+    ip.cand = m->d_cand;
+    ip.cand_bytes = ip.big ? 0u : static_cast<uint32_t>(pts_bytes / 2);
+    ip.cand_flags = m->d_cand_flags;
+    // fp32 thresholds of the scan's filter (kernels.hip): off (infinite) for a negative or NaN
+    // sem_th, where a larger distance can scale to a smaller one
+    {
+        const double k1 = (1.0 + 1.0 / 1024.0) * (1.0 + 1e-6);
+        const double inf = std::numeric_limits<double>::infinity();
+        // worth it where scans are long and bytes are what the kernel is made of: frames of 40k+
+        // points against voxels holding 6+ points on average (c2: +6 %, c4: +10 %; c1, c5 and the
+        // streamed 24k-point frames lose 4-5 % with it; SAGEICP_FILTER=0/1 overrides)
+        const uint64_t mp = m->on_device ? m->ctr.total_points : m->host.total_points;
+        const uint64_t mv = m->on_device ? m->ctr.num_voxels : m->host.num_voxels;
+        const int want = env_int("SAGEICP_FILTER", (n >= 40000 && mp >= 6 * mv) ? 1 : 0);
+        const bool filt = sem_th >= 0.0 && want != 0 && env_int("SAGEICP_NO_FILTER", 0) == 0;
+        ip.filter = (sem_th >= 0.0 && want != 0) ? 1 : 0;
+        ip.filt_inv_diff = filt ? k1 : inf;
+        ip.filt_inv_same = filt ? (sem_th > 0.0 ? k1 / sem_th : inf) : inf;
+        ip.filt_slack = std::ldexp(1.0, -44) * 1025.0 * (1.0 + 1e-6);
+    }
     ip.cap_bytes = static_cast<uint32_t>(m->host.cap * sizeof(Point4));
     ip.cap_points = static_cast<uint32_t>(m->host.cap);
     ip.sem_th = sem_th;
@@ -939,6 +996,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
 
     const int lw = icp_lw(n);
     const int blocks = n ? icp_blocks_for(static_cast<int>(n), lw) : 1;
+    if ((rc = ensure_cand(m))) return rc;
     if ((rc = sc.reserve_sort(n))) return rc;
     if ((rc = sc.reserve_partials(static_cast<size_t>(blocks)))) return rc;
     IcpParams ip = icp_params(m, sc.d_sorted, n, sem_th, lw);
@@ -1321,6 +1379,8 @@ void sageicp_map_destroy(sageicp_map *m) {
         (void)hipStreamSynchronize(m->sc.stream);
         if (m->d_table) (void)hipFree(m->d_table);
         if (m->d_pts) (void)hipFree(m->d_pts);
+        if (m->d_cand) (void)hipFree(m->d_cand);
+        if (m->d_cand_flags) (void)hipFree(m->d_cand_flags);
         if (m->d_stage) (void)hipFree(m->d_stage);
         if (m->h_stage) (void)hipHostFree(m->h_stage);
         void *aux[] = {m->d_zeros, m->d_slot_of, m->d_free, m->d_ctr, m->up.raw, m->up.w, m->up.keys,
@@ -1507,6 +1567,7 @@ int sageicp_get_correspondences(const sageicp_map *m, const double *q, uint64_t 
                       m->host.voxel_size, sc.d_keys, sc.d_vals, sc.d_sort_temp, sc.sort_temp_bytes_,
                       s));
     const int lw = icp_lw(n);
+    if ((rc = ensure_cand(m))) return rc;
     const IcpParams ip = icp_params(m, sc.d_sorted, n, sem_th, lw);     // identity pose, no loop state
     launch_rows(ip, s);
     launch_icp(ip, lw, false, s);

@@ -33,6 +33,13 @@ struct IcpParams {
     const Point4 *pts;
     uint32_t pts_bytes;       // size of the point array when it is under 4 GiB (32-bit byte offsets
                               // through a buffer resource); bigger maps: `big`, 64-bit addresses
+    int filter;               // 1: the scan reads the compact copy and filters in fp32 (big frames, dense voxels)
+    const uint4 *cand;        // compact copy of pts (fp32 x, y, z, label; k_derive_cand), same indexing
+    uint32_t cand_bytes;      // its size when pts is under 4 GiB
+    const uint32_t *cand_flags;   // bit 0: some label of the map cannot be classified in fp32
+    double filt_inv_same;     // (1 / sem_th)(1 + 2^-10)(1 + 1e-6): fp32 threshold of the label class (inf: off)
+    double filt_inv_diff;     // (1 + 2^-10)(1 + 1e-6): of the other candidates (inf: off)
+    double filt_slack;        // 2^-44 (1 + 2^10)(1 + 1e-6): times sum (|q_a| + 4 voxel)^2
     uint32_t cap_bytes;       // bytes of one voxel block: (basic + critical) * 32
     uint32_t cap_points;      // basic + critical
     int big;                  // 1: the point array is 4 GiB or more
@@ -66,6 +73,9 @@ constexpr int kIcpWavesPerBlock = SAGE_ICP_WAVES;
 int icp_blocks_for(int n, int lw);
 size_t icp_lds_bytes(int lw);
 void launch_rows(const IcpParams &p, hipStream_t s);                     // (re)build every row
+// the compact copy of the map's points the scan reads (see kernels.hip)
+void launch_derive_cand(const Slot *table, uint32_t nslots, const Point4 *pts, uint4 *cand, uint32_t cap,
+                        uint64_t nslots_pts, uint32_t *flags, hipStream_t s);
 void launch_icp(const IcpParams &p, int lw, bool fused, hipStream_t s);
 
 struct GnParams {             // stand-alone AlignClouds on explicit pairs

@@ -35,6 +35,16 @@
 // synthetic street scenes 75-85 % of the (query, map point) pairs the reference evaluates are
 // never loaded.
 //
+// Compact candidates (exact).  What the kernel is made of is bytes through the eight L2s, so the
+// scan does not read the 32-B fp64 records: k_derive_cand keeps a 16-B copy of every map point
+// (fp32 x, y, z, label) and the scan evaluates THAT — fp32 distance, label class — against a
+// threshold that no point able to win or tie can exceed (the fp32 error is bounded per query; see
+// `set_thresholds`).  Only a candidate under the threshold is fetched as fp64 and goes through
+// the reference's comparison.  With the previous answer as seed almost nothing passes, so a
+// scanned point costs 16 bytes and ~11 fp32 instructions instead of 32 bytes and 22 fp64 ones,
+// and the decision — every comparison that can change the result is the fp64 one — is the
+// sequential scan's, index for index.
+//
 // Roofline: cache-gather bound integer/byte + fp64 compare work (~0.1 flop/B) — no MFMA (a 6x6
 // outer product sum is not a dense contraction).  What matters here: one 32-B record per lane
 // and step through a raw buffer resource (no address arithmetic), rows staged once in LDS with a
@@ -50,13 +60,14 @@
 #include <algorithm>
 #include <cfloat>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #ifndef SAGE_ICP_STRIPE
 #define SAGE_ICP_STRIPE 8      // workgroups of the sorted frame per XCD stripe
 #endif
 #ifndef SAGE_ICP_OCC
-#define SAGE_ICP_OCC 7         // waves per SIMD the register allocation of k_icp is held to
+#define SAGE_ICP_OCC 6         // waves per SIMD the register allocation of k_icp is held to
 #endif
 
 #include "kernels.h"
@@ -175,6 +186,48 @@ __device__ __forceinline__ Point4 load_point(__amdgpu_buffer_rsrc_t pts, const P
     return q;
 }
 
+// One compact candidate record (16 B): fp32 x, y, z, label.  `off` is its byte offset (index when
+// BIG).
+template <bool BIG>
+__device__ __forceinline__ uint4 load_cand(__amdgpu_buffer_rsrc_t cands, const uint4 *base, uint32_t off) {
+    v4u a;
+    if (BIG) a = *reinterpret_cast<const v4u *>(base + off);
+    else a = __builtin_amdgcn_raw_buffer_load_b128(cands, off, 0, 0);
+    return make_uint4(a.x, a.y, a.z, a.w);
+}
+
+// ------------------------------------------------------------------------------- k_derive_cand
+// The compact copy of the map: one thread per hash slot converts the points of its voxel.  A label
+// that is not an integer of magnitude < 2^24 cannot be classified in fp32: it is stored as a NaN
+// and raises bit 0 of *flags, which makes k_icp use the looser of its two thresholds everywhere.
+__global__ __launch_bounds__(256) void k_derive_cand(const Slot *table, uint32_t nslots, const Point4 *pts,
+                                                     uint4 *cand, uint32_t cap, uint64_t nslots_pts,
+                                                     uint32_t *flags) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nslots) return;
+    const uint32_t w = table[i].blk;
+    if (w == kEmptySlot || w == kTombstone) return;
+    const uint32_t cnt = w & 255u;
+    const uint64_t first = static_cast<uint64_t>(w >> 8) * cap;
+    bool inexact = false;
+    for (uint32_t j = 0; j < cnt && first + j < nslots_pts; ++j) {
+        const Point4 q = pts[first + j];
+        float lf = static_cast<float>(q.l);
+        if (!(static_cast<double>(lf) == q.l && q.l == trunc(q.l) && fabs(q.l) < 16777216.0)) {
+            lf = __uint_as_float(0x7FC00000u);
+            inexact = true;
+        }
+        cand[first + j] = make_uint4(__float_as_uint(static_cast<float>(q.x)), __float_as_uint(static_cast<float>(q.y)),
+                                     __float_as_uint(static_cast<float>(q.z)), __float_as_uint(lf));
+    }
+    if (inexact) atomicOr(flags, 1u);
+}
+void launch_derive_cand(const Slot *table, uint32_t nslots, const Point4 *pts, uint4 *cand, uint32_t cap,
+                        uint64_t nslots_pts, uint32_t *flags, hipStream_t s) {
+    if (nslots) hipLaunchKernelGGL(k_derive_cand, dim3((nslots + 255u) / 256u), dim3(256), 0, s, table, nslots,
+                                   pts, cand, cap, nslots_pts, flags);
+}
+
 // --------------------------------------------------------------------------------- hash probing
 // The GPU-resident open-addressed hash: linear probing, 16-B slots, load factor <= 0.25, one 16-B
 // load per step.  Returns the slot's packed word (block << 8) | count, or kEmptySlot.
@@ -267,18 +320,30 @@ __host__ __device__ constexpr unsigned icp_wave_words(int lw) {
     return static_cast<unsigned>(kRowLdsStride * (64 >> lw) + 64);
 }
 
-template <int LW, bool FUSED, bool BIG>
+template <int LW, bool FUSED, bool BIG, bool FILT>
 __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem);
 
-template <int LW, bool FUSED, bool BIG>
+// a pair of scanned points in flight: compact records (FILT) or full ones
+struct PairCompact {
+    uint4 a, b;
+    unsigned ka, oa;                // key / compact offset of a; b: key + W, offset + W records
+    bool ha, hb;
+};
+struct PairFull {
+    Point4 a, b;
+    unsigned ka;
+    bool ha, hb;
+};
+
+template <int LW, bool FUSED, bool BIG, bool FILT>
 __global__ __launch_bounds__(64 * kIcpWavesPerBlock) __attribute__((amdgpu_waves_per_eu(SAGE_ICP_OCC, 8)))
 void k_icp(IcpParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     if (P.check_done && P.st->done) return;
-    icp_body<LW, FUSED, BIG>(P, smem);
+    icp_body<LW, FUSED, BIG, FILT>(P, smem);
 }
 
-template <int LW, bool FUSED, bool BIG>
+template <int LW, bool FUSED, bool BIG, bool FILT>
 __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
     constexpr int W = 1 << LW;                 // lanes per query
     constexpr int QW = 64 >> LW;               // queries per wave
@@ -317,6 +382,10 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
     // raw buffer resource over the point array (bounds-checked, 32-bit byte offsets)
     const __amdgpu_buffer_rsrc_t pts = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<Point4 *>(P.pts), 0, static_cast<int>(P.pts_bytes), 0x00020000);
+
+    const __amdgpu_buffer_rsrc_t cands = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4 *>(P.cand), 0, static_cast<int>(P.cand_bytes), 0x00020000);
+    constexpr int SHC = BIG ? 0 : (FILT ? 4 : 5);   // the scan's records (compact or full): byte offset, or index (BIG)
 
     // ---- prologue: the query, its home voxel, its neighbourhood row ------------------------------
     // Everything the prologue needs is requested at once (one memory round trip): the row key, the
@@ -443,14 +512,12 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
     unsigned npairs = 0u;                      // points this query's lanes were handed
 
     // voxel cursor of this lane: it takes points ci, ci + W, ... of the open voxel.  k = (voxel <<
-    // 8) | slot of its next point, kend = (voxel << 8) | points in the voxel, off = where point k
-    // lives (bytes, or points when BIG).  Only the key of the winner is tracked; its offset is
-    // rebuilt from the row once per query.
+    // 8) | slot of its next point, kend = (voxel << 8) | points in the voxel, off = where the
+    // compact record of point k lives (bytes, or points when BIG).  Only the key of the winner is
+    // tracked; its offset is rebuilt from the row once per query.
     unsigned k = ci, kend = 0u, off = 0u;
-    // Branch-free: a lane that holds no point here (`on` false: it re-read point 0) turns its
-    // distance into a NaN, which loses every comparison.  With no branch around the evaluation the
-    // compiler keeps counted waits (vmcnt(4)) in the scan loop: the younger register set's loads
-    // stay in flight under every evaluation instead of the queue being drained at the joins.
+    // The reference's comparison, fp64, on a full record.  Branch-free: a lane that holds no
+    // candidate here (`on` false) turns its distance into a NaN, which loses every comparison.
     auto evaluate = [&](const Point4 &nb, bool on, unsigned key) {
         const double dx = nb.x - s.x, dy = nb.y - s.y, dz = nb.z - s.z;
         double d = dx * dx + (dy * dy + dz * dz);
@@ -467,15 +534,66 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
         best = min_f64(best, d);
         bkey = take ? key : bkey;
     };
-    // Per-lane state machine over the voxels in `need` (and the one already open).  A step handles
-    // two points of the open voxel (i and i + W); two register sets alternate, so while one pair
-    // is evaluated the loads of the next pair are in flight (no register copies across the loop
-    // edge: the wait before an evaluation leaves the younger loads outstanding).
-    struct Pair {
-        Point4 a, b;
-        unsigned ka;                // key of a; b: key + W
-        bool ha, hb;
+
+    // ---- the fp32 filter in front of it ------------------------------------------------------
+    // p, q: map point and query (fp64), p32, q32 their fp32 roundings, u = 2^-24.  Per axis
+    // |fl(p32 - q32) - (p - q)| <= u(|p| + |q| + |p - q|) <= 2u(|q| + |p - q|) <= E_a with
+    // E_a = 2^-22 (|q_a| + 4 voxel_size): a candidate lies within three voxels of the query.  The
+    // fp32 sum of squares D32 is within (1 + u)^4 of the exact one of the rounded differences, so
+    // |p - q| >= sqrt(D32 (1 - 5u)) - |E|.  A candidate whose scaled distance scale * |p - q|^2
+    // can be <= b (no worse than what is held: it could win or tie) therefore has
+    //     D32 <= (sqrt(b / scale) + |E|)^2 / (1 - 5u) <= (b / scale)(1 + 2^-10) k + |E|^2 (1 + 2^10) k
+    // (2xy <= e x^2 + y^2 / e), k = 1 + 1e-6; the right-hand side, rounded up to fp32, is the
+    // threshold: Ts for candidates of the query's label class (scale = sem_th), Td for the others
+    // (scale = 1).  Anything at or under it is fetched as fp64 and compared by `evaluate`.  A label
+    // that fp32 cannot classify (k_derive_cand's flag, or a query label that is no small integer)
+    // gets the looser of the two.  Pruning off (sem_th negative or NaN): both infinite.
+    // (FILT is off for small frames and sparse voxels, where a scan is a handful of points and the
+    // filter's set-up and its occasional extra round trip cost more than the bytes it saves: the
+    // scan then reads the full records and every point goes through `evaluate`.)
+    const float qx = static_cast<float>(s.x), qy = static_cast<float>(s.y), qz = static_cast<float>(s.z);
+    const float plab = static_cast<float>(pli);
+    const bool q_zero = pli == 0;              // an unlabelled query: every candidate is of its class
+    bool unknown = false;
+    double slack = 0.0;
+    if constexpr (FILT) {
+        const bool q_exact = s.l == trunc(s.l) && fabs(s.l) < 16777216.0;
+        unknown = !q_exact || (P.cand_flags[0] & 1u);
+        const double ex = fabs(s.x) + 4.0 * P.voxel_size, ey = fabs(s.y) + 4.0 * P.voxel_size,
+                     ez = fabs(s.z) + 4.0 * P.voxel_size;
+        slack = (ex * ex + (ey * ey + ez * ez)) * P.filt_slack;     // 2^-44 (1 + 2^10) k
+    }
+#ifdef SAGE_NN_TIMING
+    unsigned n_consume = 0u, n_exact = 0u, n_exact_lanes = 0u;
+#endif
+    double fb = best;                          // what the thresholds were derived from (>= the query's final best)
+    float Ts = 0.0f, Td = 0.0f;
+    auto round_up = [](double x) {             // the next fp32 above x (an infinity becomes a NaN:
+        return __uint_as_float(__float_as_uint(static_cast<float>(x)) + 1u);   // `D32 > NaN` is false, nothing is dropped)
     };
+    auto set_thresholds = [&]() {
+        if constexpr (!FILT) return;
+        float a = round_up(fb * P.filt_inv_same + slack), b = round_up(fb * P.filt_inv_diff + slack);
+        if (unknown) {                         // the looser one; a NaN stands for an infinity
+            float m = a > b ? a : b;
+            if (a != a || b != b) m = __uint_as_float(0x7FC00000u);
+            a = b = m;
+        }
+        Ts = a; Td = b;
+    };
+    auto passes = [&](const uint4 &c, bool on) {
+        const float dx = __uint_as_float(c.x) - qx, dy = __uint_as_float(c.y) - qy, dz = __uint_as_float(c.z) - qz;
+        const float d = dx * dx + (dy * dy + dz * dz);
+        const float lab = __uint_as_float(c.w);
+        const bool same = (lab == plab) | (lab == 0.0f) | q_zero;
+        return on & !(d > (same ? Ts : Td));
+    };
+
+    // Per-lane state machine over the voxels in `need` (and the one already open).  A step handles
+    // two points of the open voxel (k and k + W); two register sets alternate, so while one pair
+    // is filtered the loads of the next pair are in flight (no register copies across the loop
+    // edge: the wait before a pair leaves the younger loads outstanding).
+    using Pair = std::conditional_t<FILT, PairCompact, PairFull>;
     auto scan = [&](unsigned need, const Point4 *seed, bool seeded, unsigned seed_key) {
         auto issue = [&](Pair &n, bool &more) {
             while (k >= kend && need) {        // open this lane's next voxel
@@ -484,36 +602,72 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
                 const uint32_t w = lrow[v];
                 kend = (v << 8) | (w & 255u);
                 k = (v << 8) | ci;
-                off = (w >> 8) * (BIG ? P.cap_points : P.cap_bytes) + (ci << SH);
+                off = (((w >> 8) * P.cap_points) + ci) << SHC;
                 npairs += w & 255u;
             }
             n.ha = k < kend;
             n.hb = k + W < kend;
             n.ka = k;
-            // issued by every lane (idle lanes re-read point 0): a load behind a branch would make
-            // the compiler drain the whole queue before the other set's evaluation
-            n.a = load_point<BIG>(pts, P.pts, n.ha ? off : 0u);
-            n.b = load_point<BIG>(pts, P.pts, n.hb ? off + (static_cast<unsigned>(W) << SH) : 0u);
-            // the evaluation of the other set stays below these loads (the scheduler would
+            if constexpr (FILT) n.oa = off;
+            // issued by every lane (idle lanes re-read record 0): a load behind a branch would make
+            // the compiler drain the whole queue before the other set is looked at
+            const unsigned oa = n.ha ? off : 0u, ob = n.hb ? off + (static_cast<unsigned>(W) << SHC) : 0u;
+            if constexpr (FILT) {
+                n.a = load_cand<BIG>(cands, P.cand, oa);
+                n.b = load_cand<BIG>(cands, P.cand, ob);
+            } else {
+                n.a = load_point<BIG>(pts, P.pts, oa);
+                n.b = load_point<BIG>(pts, P.pts, ob);
+            }
+            // the filtering of the other set stays below these loads (the scheduler would
             // otherwise sink them under the arithmetic it believes is ready)
             __builtin_amdgcn_sched_barrier(0);
             k += n.ha ? 2u * W : 0u;
-            off += n.ha ? (2u * W) << SH : 0u;
+            off += n.ha ? (2u * W) << SHC : 0u;
             more = (k < kend) | (need != 0u);
         };
         auto consume = [&](const Pair &n) {
-            evaluate(n.a, n.ha, n.ka);
-            evaluate(n.b, n.hb, n.ka + W);
+            if constexpr (!FILT) {
+                evaluate(n.a, n.ha, n.ka);
+                evaluate(n.b, n.hb, n.ka + W);
+            } else {
+            // (the candidate already held — the seed met again in its voxel — needs no second look)
+            const bool pa = passes(n.a, n.ha) & (n.ka != bkey), pb = passes(n.b, n.hb) & (n.ka + W != bkey);
+#ifdef SAGE_NN_TIMING
+            ++n_consume;
+#endif
+            if (__ballot(pa | pb)) {
+                // rarer and rarer as the registration settles (a fifth of the pair steps at the
+                // start of a cold one, 2 % near convergence): the full records of the candidates
+                // that passed (a compact offset is half the byte offset of the full record).
+                // (Parking them and fetching in batches was tried: more registers, no fewer trips.)
+#ifdef SAGE_NN_TIMING
+                ++n_exact;
+                n_exact_lanes += static_cast<unsigned>(__popcll(__ballot(pa)) + __popcll(__ballot(pb)));
+#endif
+                const unsigned ob = n.oa + (static_cast<unsigned>(W) << SHC);
+                const Point4 ea = load_point<BIG>(pts, P.pts, pa ? (BIG ? n.oa : n.oa << 1) : 0u);
+                const Point4 eb = load_point<BIG>(pts, P.pts, pb ? (BIG ? ob : ob << 1) : 0u);
+                evaluate(ea, pa, n.ka);
+                evaluate(eb, pb, n.ka + W);
+                fb = min_f64(fb, best);
+                set_thresholds();
+            }
+            }
         };
         Pair A, B;
         bool more = false;
         issue(A, more);
         // the seed's load is older than A's: waiting for it leaves A's loads in flight
         if (seed) evaluate(*seed, seeded, seed_key);
+        fb = min_f64(fb, best);
+        set_thresholds();
         // One exit per double step: an exit between the two halves gives the loop header a
         // predecessor with B's loads pending, and the compiler then drains the queue (vmcnt(0))
         // before every issue(B) — the overlap this loop exists for.  A scan that ends after the
         // first half pays one idle half step instead.
+        // (Peeling short scans out of the loop — one pair step, or none — was tried: the extra
+        // paths cost 10 registers and spills, every workload lost 5-10 %.)
         for (;;) {
             issue(B, more);
             consume(A);
@@ -531,7 +685,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
     constexpr unsigned kHome = 13u;
     if (FUSED) {
         const bool seeded = valid && !stale && prev.x != 0xFFFFFFFFu;
-        const Point4 pp = load_point<BIG>(pts, P.pts, seeded ? prev.y : 0u);
+        const Point4 pp = load_point<BIG>(pts, P.pts, seeded ? prev.y : 0u);      // the full record
         scan(occ & (1u << kHome), &pp, seeded, prev.x);
     } else {
         scan(occ & (1u << kHome), nullptr, false, 0u);
@@ -539,6 +693,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
     NN_T(2);
     // what the query holds after its home voxel bounds the rest of its search
     const double bound = seg_min_f64<W>(best);
+    fb = bound;                                // (set_thresholds runs at the start of the scan)
     unsigned need = P.keep_all;
 #pragma unroll
     for (int v = 0; v < 27; ++v) {
@@ -650,7 +805,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
 #ifdef SAGE_NN_TIMING
     // private slot per wave (no contended atomics: they would stall the very loads being timed)
     NN_T(4);
-    unsigned long long np_packed;
+    unsigned long long np_packed, xp_packed;
     {   // points handed to the queries of this wave: max over the queries | sum
         unsigned mx = valid ? npairs : 0u, sm = (valid && ci == 0u) ? npairs : 0u;
         for (int d = 1; d < 64; d <<= 1) {
@@ -658,6 +813,8 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
             sm += __shfl_xor(sm, d, 64);
         }
         np_packed = (static_cast<unsigned long long>(mx) << 32) | sm;
+        // pair steps of this wave | of them with a fetch of full records | lanes that fetched
+        xp_packed = (static_cast<unsigned long long>(n_consume) << 40) | (static_cast<unsigned long long>(n_exact) << 20) | n_exact_lanes;
     }
     if (lane == 0 && wave_id < kNnTimingSlots && wave_id < P.nwaves) {
         unsigned long long *tt = g_nn_phase + 8ull * wave_id;
@@ -669,8 +826,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
         if (P.st->iter == g_nn_span_iter) {
         sp[0] = rstart;
         sp[1] = __builtin_amdgcn_s_memrealtime();
-        sp[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |   // HW_REG_HW_ID
-                (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11))) << 32);   // HW_REG_XCC_ID
+        sp[2] = xp_packed;
         sp[3] = np_packed;
         }
     }
@@ -722,7 +878,10 @@ __device__ unsigned long long g_gn_phase[16];
 constexpr int kFinThreads = 1024;
 constexpr int kFinSlices = 102;             // 10 fp64 pairs per partial x 102 slices = 1020 threads
 
-__device__ __forceinline__ void reduce_partials(const double *partials, int nparts, double *S /* LDS [kNumSums] */) {
+// Returns false (on every thread) when *done is set: the loop has finished and this launch is a
+// no-op.  The flag is fetched together with the partials — one memory round trip, not two.
+__device__ __forceinline__ bool reduce_partials(const double *partials, int nparts, double *S /* LDS [kNumSums] */,
+                                                const int32_t *done) {
     __shared__ double part[kFinSlices][kNumSums];
     __shared__ double part2[6][kNumSums];
     const int t = static_cast<int>(threadIdx.x);
@@ -732,6 +891,7 @@ __device__ __forceinline__ void reduce_partials(const double *partials, int npar
         // memory round trip for up to 2,448 partials, the cold-L2 latency is what this kernel costs)
         double2 v = make_double2(0.0, 0.0);
         const double2 *src = reinterpret_cast<const double2 *>(partials) + pr;
+        bool first = true;
         for (int b = sl; b < nparts; b += 24 * kFinSlices) {
             double2 u[24];
 #pragma unroll
@@ -739,11 +899,26 @@ __device__ __forceinline__ void reduce_partials(const double *partials, int npar
                 const int bb = b + k * kFinSlices;
                 u[k] = bb < nparts ? src[static_cast<size_t>(bb) * 10] : make_double2(0.0, 0.0);
             }
+            if (first && done) {
+                // a vector load like the ones above (the index is zero, but formally per lane), so
+                // that it travels with them: a scalar load would be waited for before the partials
+                // are even requested
+                const int32_t d = done[__builtin_amdgcn_mbcnt_lo(0u, 0u)];
+                if (__builtin_amdgcn_readfirstlane(d)) return false;
+                first = false;
+            }
 #pragma unroll
             for (int k = 0; k < 24; ++k) { v.x += u[k].x; v.y += u[k].y; }
         }
+        if (first && done) {                   // no partials at all (an empty frame)
+            const int32_t d = done[__builtin_amdgcn_mbcnt_lo(0u, 0u)];
+            if (__builtin_amdgcn_readfirstlane(d)) return false;
+        }
         part[sl][2 * pr] = v.x;
         part[sl][2 * pr + 1] = v.y;
+    } else if (done) {
+        const int32_t d = done[__builtin_amdgcn_mbcnt_lo(0u, 0u)];
+        if (__builtin_amdgcn_readfirstlane(d)) return false;
     }
     __syncthreads();
     if (t < 6 * kNumSums) {
@@ -761,6 +936,7 @@ __device__ __forceinline__ void reduce_partials(const double *partials, int npar
         S[t] = v;
     }
     __syncthreads();
+    return true;
 }
 
 // the solve: wave 0, all 64 lanes, uniform data (see WaveLanes); lane 0 / lane 1 publish the state
@@ -893,14 +1069,14 @@ __device__ __forceinline__ void exchange_sums(IcpState *st, const P2pParams &X) 
 
 // ------------------------------------------------------------------------------------ k_fin
 __global__ __launch_bounds__(kFinThreads) void k_fin(FinParams P) {
-    if (!P.standalone && P.st->done) return;
     __shared__ double S[kNumSums];
     IcpState *st = P.st;
+    if (P.mode == 2 && !P.standalone && st->done) return;
 #ifdef SAGE_GN_TIMING
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
 #endif
     if (P.mode != 2) {
-        reduce_partials(P.partials, P.nparts, S);
+        if (!reduce_partials(P.partials, P.nparts, S, P.standalone ? nullptr : &st->done)) return;
 #ifdef SAGE_GN_TIMING
         if (threadIdx.x == 0) atomicAdd(&g_gn_phase[8], __builtin_amdgcn_s_memrealtime() - t_start);
 #endif
@@ -1115,12 +1291,20 @@ static void launch_icp_lw(const IcpParams &p, bool fused, hipStream_t s) {
     const int grid = icp_blocks_for(p.n, LW);
     const size_t lds = icp_lds_bytes(LW);
     const dim3 g(grid), b(64 * kIcpWavesPerBlock);
-    if (p.big) {
-        if (fused) hipLaunchKernelGGL((k_icp<LW, true, true>), g, b, lds, s, p);
-        else hipLaunchKernelGGL((k_icp<LW, false, true>), g, b, lds, s, p);
+    if (p.filter) {
+        if (p.big) {
+            if (fused) hipLaunchKernelGGL((k_icp<LW, true, true, true>), g, b, lds, s, p);
+            else hipLaunchKernelGGL((k_icp<LW, false, true, true>), g, b, lds, s, p);
+        } else {
+            if (fused) hipLaunchKernelGGL((k_icp<LW, true, false, true>), g, b, lds, s, p);
+            else hipLaunchKernelGGL((k_icp<LW, false, false, true>), g, b, lds, s, p);
+        }
+    } else if (p.big) {
+        if (fused) hipLaunchKernelGGL((k_icp<LW, true, true, false>), g, b, lds, s, p);
+        else hipLaunchKernelGGL((k_icp<LW, false, true, false>), g, b, lds, s, p);
     } else {
-        if (fused) hipLaunchKernelGGL((k_icp<LW, true, false>), g, b, lds, s, p);
-        else hipLaunchKernelGGL((k_icp<LW, false, false>), g, b, lds, s, p);
+        if (fused) hipLaunchKernelGGL((k_icp<LW, true, false, false>), g, b, lds, s, p);
+        else hipLaunchKernelGGL((k_icp<LW, false, false, false>), g, b, lds, s, p);
     }
 }
 void launch_icp(const IcpParams &p, int lw, bool fused, hipStream_t s) {

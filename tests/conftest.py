@@ -61,3 +61,16 @@ def reference_emission_order(oracle):
     oracle.set_robin_order(1)
     yield
     oracle.set_robin_order(0)
+
+
+@pytest.fixture(params=["full", "compact"])
+def scan_form(request):
+    """k_icp scans either the full fp64 records or the compact fp32 copy behind its filter; the
+    library picks by frame size and voxel density, the tests force each form in turn."""
+    old = os.environ.get("SAGEICP_FILTER")
+    os.environ["SAGEICP_FILTER"] = "1" if request.param == "compact" else "0"
+    yield request.param
+    if old is None:
+        os.environ.pop("SAGEICP_FILTER", None)
+    else:
+        os.environ["SAGEICP_FILTER"] = old

@@ -46,7 +46,7 @@ def random_scene(seed, n_map=20000, n_q=3000, span=12.0, labels=(0, 40, 50, 70, 
     (1, 1.0, 20, 20, 0.4, 6.0), (2, 0.8, 20, 20, 0.05, 0.9), (3, 1.0, 20, 20, 1.0, 2.0),
     (4, 0.5, 3, 2, 0.8, 0.4), (5, 2.5, 60, 60, 0.4, 3.0), (6, 1.0, 1, 0, 0.4, 6.0),
     (7, 3.0, 128, 127, 0.2, 6.0)])
-def test_correspondences_index_exact(gpu_sage, oracle, seed, vs, basic, critical, th, md):
+def test_correspondences_index_exact(gpu_sage, oracle, seed, vs, basic, critical, th, md, scan_form):
     mp, q = random_scene(seed)
     a, b = both_maps(gpu_sage, oracle, mp, vs, 100.0, basic, critical)
     src, tgt, idx = a.GetCorrespondences(q, md, th, with_index=True)
@@ -57,7 +57,7 @@ def test_correspondences_index_exact(gpu_sage, oracle, seed, vs, basic, critical
 
 
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
-def test_golden_vectors(gpu_sage, oracle, path):
+def test_golden_vectors(gpu_sage, oracle, path, scan_form):
     g = np.load(path)
     vs, md, basic, critical, th, max_dist, kernel = g["params"]
     m = gpu_sage.VoxelHashMap(vs, md, int(basic), int(critical))
@@ -79,7 +79,7 @@ def test_golden_vectors(gpu_sage, oracle, path):
     assert [st.n_corr_first, st.n_corr_last] == list(g["reg_n_corr"])
 
 
-def test_edge_cases(gpu_sage, oracle):
+def test_edge_cases(gpu_sage, oracle, scan_form):
     sage = gpu_sage
     m = sage.VoxelHashMap(1.0, 100.0)
     m.AddPoints([[1.25, 0.5, 0.5, 7], [-0.25, 0.5, 0.5, 7]])
@@ -112,7 +112,7 @@ def test_edge_cases(gpu_sage, oracle):
     assert len(e.GetCorrespondences([[0.5, 0.5, 0.5, 40]], 6.0, 0.4)[0]) == 0
 
 
-def test_zero_straddle_and_negative_coordinates(gpu_sage, oracle):
+def test_zero_straddle_and_negative_coordinates(gpu_sage, oracle, scan_form):
     mp, q = random_scene(11, n_map=3000, n_q=2000, span=1.8)
     a, b = both_maps(gpu_sage, oracle, mp)
     _, tgt, idx = a.GetCorrespondences(q, 6.0, 0.4, with_index=True)
@@ -120,7 +120,7 @@ def test_zero_straddle_and_negative_coordinates(gpu_sage, oracle):
     assert np.array_equal(idx, oidx) and np.array_equal(tgt, otgt)
 
 
-def test_queries_exactly_on_voxel_faces(gpu_sage, oracle):
+def test_queries_exactly_on_voxel_faces(gpu_sage, oracle, scan_form):
     rng = np.random.default_rng(12)
     mp, _ = random_scene(12, n_map=8000, span=6.0)
     q = np.round(rng.uniform(-6, 6, size=(2000, 4)) / 0.8) * 0.8      # multiples of the voxel size
@@ -132,7 +132,7 @@ def test_queries_exactly_on_voxel_faces(gpu_sage, oracle):
 
 
 @pytest.mark.parametrize("n_q,box", [(5000, 1.6), (700, 4.0), (64, 0.4), (33, 0.9)])
-def test_dense_queries_share_voxels(gpu_sage, oracle, n_q, box):
+def test_dense_queries_share_voxels(gpu_sage, oracle, n_q, box, scan_form):
     """many queries per home voxel: exercises every (queries x candidates) lane split of k_nn"""
     rng = np.random.default_rng(14)
     mp, _ = random_scene(14, n_map=30000, span=5.0)
@@ -145,7 +145,7 @@ def test_dense_queries_share_voxels(gpu_sage, oracle, n_q, box):
     assert np.array_equal(idx, oidx) and np.array_equal(tgt, otgt)
 
 
-def test_near_ties_and_exotic_labels_stay_exact(gpu_sage, oracle):
+def test_near_ties_and_exotic_labels_stay_exact(gpu_sage, oracle, scan_form):
     """adversarial input for k_nn's f32 filter: clusters of candidates whose distances differ by
     far less than f32 resolution (many finalists / exact fallback), exact duplicates (index
     tie-break), far-from-origin coordinates, fractional and huge labels (generic-label path)"""
@@ -176,14 +176,14 @@ def test_near_ties_and_exotic_labels_stay_exact(gpu_sage, oracle):
             q2[::5, 3] = 0.25
             q2[::13, 3] = -7.0
         a, b = both_maps(gpu_sage, oracle, m2, vs=1.0)
-        for th in (0.4, 1.0, 2.5):
+        for th in (0.4, 1.0, 2.5, 0.0):
             _, tgt, idx = a.GetCorrespondences(q2, 3.0, th, with_index=True)
             _, otgt, oidx = b.get_correspondences(q2, 3.0, th, with_index=True)
             assert len(oidx) > 2000
             assert np.array_equal(idx, oidx) and np.array_equal(tgt, otgt), (labels, th)
 
 
-def test_mirror_refresh_after_updates(gpu_sage, oracle):
+def test_mirror_refresh_after_updates(gpu_sage, oracle, scan_form):
     """dirty-block / table refresh: search between successive map mutations stays exact"""
     rng = np.random.default_rng(13)
     a = gpu_sage.VoxelHashMap(1.0, 18.0)
@@ -249,7 +249,7 @@ def test_map_of_ten_million_voxels_beyond_4_gib(gpu_sage, oracle):
     assert a.size() == b.size() >= before
 
 
-def test_maximum_voxel_capacity(gpu_sage, oracle):
+def test_maximum_voxel_capacity(gpu_sage, oracle, scan_form):
     """255 points per voxel (the ABI's limit): 27 x 255 candidates per query; search and
     device-side update stay exact"""
     rng = np.random.default_rng(77)
@@ -318,7 +318,7 @@ def _workload(gpu_sage, oracle, name, scale):
 
 
 @pytest.mark.parametrize("params", ["cold", "steady"])
-def test_register_frame_pose_parity_c2_scaled(gpu_sage, oracle, params):
+def test_register_frame_pose_parity_c2_scaled(gpu_sage, oracle, params, scan_form):
     from sage_icp_amd import synthetic as syn
     w, om = _workload(gpu_sage, oracle, "c2", 0.1)
     p = syn.PARAMS[params]
@@ -340,7 +340,7 @@ def test_register_frame_pose_parity_c2_scaled(gpu_sage, oracle, params):
 
 
 @pytest.mark.parametrize("params", ["dense", "dense_nosem"])
-def test_register_frame_pose_parity_c5_scaled(gpu_sage, oracle, params):
+def test_register_frame_pose_parity_c5_scaled(gpu_sage, oracle, params, scan_form):
     """c5 (BASELINE configs[4]): dense scan vs a 0.1 m voxel map, semantic scaling on (0.8) / off (1.0)"""
     from sage_icp_amd import synthetic as syn
     w, om = _workload(gpu_sage, oracle, "c5", 0.1)
@@ -359,7 +359,7 @@ def test_register_frame_pose_parity_c5_scaled(gpu_sage, oracle, params):
     assert gt < 0.03 and gr < 1e-3                    # the planted centimetre offset is recovered
 
 
-def test_register_frame_pose_parity_c4_scaled(gpu_sage, oracle):
+def test_register_frame_pose_parity_c4_scaled(gpu_sage, oracle, scan_form):
     """c4 (BASELINE configs[3]: 500k-pt scan vs 10M-pt map, steady parameters) at one tenth of its
     size: pose, iteration count, correspondence counts and the exact C_q sum against the oracle"""
     from sage_icp_amd import synthetic as syn
@@ -427,7 +427,7 @@ def test_register_frame_c1_plumbing(gpu_sage, oracle):
     assert dt < 1e-7 and dr < 1e-7 and st.iterations == ost.iterations
 
 
-def test_register_frame_with_initial_guess_and_edge_inputs(gpu_sage, oracle):
+def test_register_frame_with_initial_guess_and_edge_inputs(gpu_sage, oracle, scan_form):
     mp, q = random_scene(40, n_map=30000, n_q=2500, span=15.0)
     a, b = both_maps(gpu_sage, oracle, mp)
     kept = a.Pointcloud()
@@ -450,7 +450,7 @@ def test_register_frame_with_initial_guess_and_edge_inputs(gpu_sage, oracle):
     assert st.iterations == 1 and st.n_corr_first == 0
 
 
-def test_streaming_frames_with_map_updates(gpu_sage, oracle):
+def test_streaming_frames_with_map_updates(gpu_sage, oracle, scan_form):
     """c3-style: register, update the map with the frame at the new pose, repeat — both
     backends restarted from the same state every frame."""
     from sage_icp_amd import synthetic as syn
