@@ -382,16 +382,19 @@ def main():
                     "avg_launch_us": round(avg_us, 2), "launches_timed": launches,
                     "launches": all_launches, "queries_per_launch": n_local,
                     "lanes_per_query": last.lanes_per_query,
+                    "scan_form": "compact 16-B records behind an exact fp32 filter" if last.compact_scan
+                                 else "full 32-B fp64 records",
                     "candidates_per_query": round(cands / all_launches / max(n_local, 1), 1),
                     "pairs_evaluated_frac": round(pairs / max(cands, 1), 4),
                     "note": "achieved = algorithmic bytes (SURVEY 8d fused form: 448 B/query + 16 B/"
                             "candidate + 32 B/correspondence) / mean k_icp duration (HIP events on the "
                             "launch stream, 1 launch in 8 of the timed region).  The kernel skips, by "
                             "an exact cell lower bound, most of the candidates the byte model charges "
-                            "(pairs_evaluated_frac) and the map stays in L2 / Infinity Cache, so this "
-                            "is an effective rate that can exceed the HBM peak; what bounds the kernel "
-                            "is in hbm_frac / valu_frac / useful_inst_frac (rocprofv3 counters of the "
-                            "same command, profiles/)"}
+                            "(pairs_evaluated_frac: the share it scans) and the map stays in L2 / "
+                            "Infinity Cache, so this is an effective rate that can exceed the HBM peak; "
+                            "what bounds the kernel is in hbm_frac (bytes from beyond the L2s / duration "
+                            "/ peak) / valu_frac / useful_inst_frac (rocprofv3 counters of the same "
+                            "command, profiles/)"}
         cpath = os.path.join(ROOT, "profiles", "icp_counters.json")
         if os.path.exists(cpath) and args.workload == "c2" and world == 1 and args.scale == 1.0:
             try:

@@ -64,7 +64,8 @@ typedef struct sageicp_stats {
     uint64_t pairs_evaluated;   /* (query, map point) pairs the search actually evaluated, all
                                  * iterations: sum_candidates minus what the cell lower bound pruned */
     uint32_t lanes_per_query;   /* lanes that shared one query in the search kernel (1..16) */
-    uint32_t reserved_;
+    uint32_t compact_scan;      /* 1: the search scanned the 16-B compact copy of the map behind its fp32
+                                 * filter (big frames, dense voxels); 0: the full fp64 records */
 } sageicp_stats;
 
 /* ---- library ------------------------------------------------------------------------ */
@@ -186,6 +187,11 @@ int sageicp_comm_p2p_enabled(const sageicp_comm *comm);
  * in input order (no host step, ~1 ms less per 120k-pt frame; the poses of a free-running stream
  * then differ from the reference's by centimetres at unchanged accuracy). */
 void sageicp_set_downsample_order(int reference_order);
+/* The replay itself (host code, no device needed): the iteration order of a tsl::robin_map v1.0.1
+ * (core/Preprocessing.cpp:50,76-82: default-constructed, the reference's 20-bit VoxelHash) after the
+ * n distinct voxels vox_xyz[3*i..] were inserted in this order; order_out[j] = insertion index of the
+ * j-th entry met by the map's iterator. */
+int sageicp_robin_iteration_order(const int32_t *vox_xyz, uint64_t n, uint32_t *order_out);
 int sageicp_preprocess(const double *frame_xyzl, uint64_t n, double max_range, double min_range,
                        double label_max_range, double *out_xyzl, uint64_t *n_out, int device);
 int sageicp_voxel_downsample(const double *frame_xyzl, uint64_t n, int n_groups,

@@ -49,8 +49,9 @@ out = {
     "valu_frac": round(valu * 4.0 / (1024.0 * cycles), 4) if valu else None,
     "lane_utilization": round(mean["SQ_THREAD_CYCLES_VALU"] / (mean["SQ_ACTIVE_INST_VALU"] * 64.0), 4)
                         if "SQ_THREAD_CYCLES_VALU" in mean and mean.get("SQ_ACTIVE_INST_VALU") else None,
-    # the 24 VALU instructions of one evaluated (query, map point) pair, 64 pairs per wave-instruction
-    "useful_inst_frac": round(pairs_per_launch / 64.0 * 24.0 / valu, 4) if valu else None,
+    # the VALU instructions spent on one scanned (query, map point) pair — 12 in the fp32 filter of
+    # the compact scan, 22 in the fp64 comparison of the full-record scan — 64 pairs per wave-instruction
+    "useful_inst_frac": round(pairs_per_launch / 64.0 * (12.0 if "compact" in rf.get("scan_form", "") else 22.0) / valu, 4) if valu else None,
     "l2_hit_rate": round(mean["TCC_HIT_sum"] / (mean["TCC_HIT_sum"] + mean["TCC_MISS_sum"]), 4)
                    if "TCC_HIT_sum" in mean else None,
 }

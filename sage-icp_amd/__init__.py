@@ -60,7 +60,7 @@ class Stats(C.Structure):
         ("n_corr_hist", C.c_uint32 * 64),
         ("pairs_evaluated", C.c_uint64),
         ("lanes_per_query", C.c_uint32),
-        ("reserved_", C.c_uint32),
+        ("compact_scan", C.c_uint32),
     ]
 
 
@@ -116,6 +116,7 @@ _SIGNATURES = [
     ("sageicp_device_count", C.c_int, []),
     ("sageicp_set_profiling", None, [C.c_int]),
     ("sageicp_set_downsample_order", None, [C.c_int]),
+    ("sageicp_robin_iteration_order", C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
     ("sageicp_map_create", C.c_void_p,
      [C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]),
     ("sageicp_map_destroy", None, [C.c_void_p]),

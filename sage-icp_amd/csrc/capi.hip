@@ -229,8 +229,10 @@ struct Prep {
     size_t sort_bytes = 0;
     unsigned long long *d_okeys = nullptr;   // survivors' voxel keys (reference-order emission)
     uint32_t *d_perm = nullptr;
-    std::vector<unsigned long long> h_keys;
-    std::vector<uint32_t> h_hash, h_perm;
+    unsigned long long *h_keys = nullptr;    // pinned
+    uint32_t *h_perm = nullptr;              // pinned
+    std::vector<uint32_t> h_hash;
+    RobinScratch rscratch[8];                // bucket arrays of the order replay, one pair per label group
     double us_order = 0;                // host time of the last run's order replays
     uint32_t *d_nkept = nullptr;        // [2]
     int *d_overflow = nullptr;
@@ -277,6 +279,11 @@ struct Prep {
         HIPCHK(hipMalloc(&d_winner, static_cast<size_t>(t) * sizeof(uint32_t)));
         HIPCHK(hipMalloc(&d_okeys, c * sizeof(unsigned long long)));
         HIPCHK(hipMalloc(&d_perm, c * sizeof(uint32_t)));
+        if (h_keys) (void)hipHostFree(h_keys);
+        if (h_perm) (void)hipHostFree(h_perm);
+        h_keys = nullptr; h_perm = nullptr;
+        HIPCHK(hipHostMalloc(&h_keys, c * sizeof(unsigned long long), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&h_perm, c * sizeof(uint32_t), hipHostMallocDefault));
         table_cap = t;
         sort_bytes = vds_sort_temp_bytes(static_cast<int>(c));
         HIPCHK(hipMalloc(&d_sort_temp, sort_bytes));
@@ -297,6 +304,9 @@ struct Prep {
         if (d_winner) (void)hipFree(d_winner);
         if (d_okeys) (void)hipFree(d_okeys);
         if (d_perm) (void)hipFree(d_perm);
+        if (h_keys) (void)hipHostFree(h_keys);
+        if (h_perm) (void)hipHostFree(h_perm);
+        h_keys = nullptr; h_perm = nullptr;
         d_okeys = nullptr; d_perm = nullptr;
         if (d_sort_temp) (void)hipFree(d_sort_temp);
         if (h_pin) (void)hipHostFree(h_pin);
@@ -368,48 +378,76 @@ struct Prep {
                 // the reference's emission order (Preprocessing.cpp:76-82): replay, group by
                 // group, the insertions into its robin_map and permute the survivors
                 const double t0 = now_us();
-                h_keys.resize(kept);
-                HIPCHK(hipMemcpyAsync(h_keys.data(), d_okeys, kept * sizeof(unsigned long long),
+                HIPCHK(hipMemcpyAsync(h_keys, d_okeys, kept * sizeof(unsigned long long),
                                       hipMemcpyDeviceToHost, stream));
                 HIPCHK(hipStreamSynchronize(stream));
+                const double t1 = now_us();
                 h_hash.resize(kept);
-                h_perm.clear();
-                h_perm.reserve(kept);
-                const long long B = 1ll << 19;
-                for (uint32_t i = 0; i < kept; ++i) {
-                    const unsigned long long k = h_keys[i];
-                    h_hash[i] = reference_voxel_hash(static_cast<int32_t>(static_cast<long long>((k >> 40) & 0xFFFFFu) - B),
-                                                     static_cast<int32_t>(static_cast<long long>((k >> 20) & 0xFFFFFu) - B),
-                                                     static_cast<int32_t>(static_cast<long long>(k & 0xFFFFFu) - B));
-                }
                 // survivors are grouped (stable sort by group); the groups' tables are independent:
-                // one host thread per group
+                // one host thread per group hashes and replays its run and writes its part of the
+                // permutation in place
                 std::vector<std::pair<uint32_t, uint32_t>> runs;
                 for (uint32_t a = 0; a < kept;) {
-                    uint32_t b = a;
-                    while (b < kept && (h_keys[b] >> 60) == (h_keys[a] >> 60)) ++b;
-                    runs.emplace_back(a, b);
-                    a = b;
+                    const unsigned long long g = h_keys[a] >> 60;
+                    uint32_t lo = a, hi = kept;            // first index of another group (binary search: the runs are long)
+                    while (hi - lo > 1) {
+                        const uint32_t mid = lo + (hi - lo) / 2;
+                        if ((h_keys[mid] >> 60) == g) lo = mid; else hi = mid;
+                    }
+                    runs.emplace_back(a, hi);
+                    a = hi;
                 }
-                std::vector<std::vector<uint32_t>> parts(runs.size());
+                const long long B = 1ll << 19;
                 auto replay = [&](size_t r) {
-                    parts[r].reserve(runs[r].second - runs[r].first);
-                    RobinOrderReplay::iteration_order(h_hash.data() + runs[r].first,
-                                                      runs[r].second - runs[r].first, runs[r].first, parts[r]);
+                    const uint32_t a = runs[r].first, b = runs[r].second;
+                    for (uint32_t i = a; i < b; ++i) {
+                        const unsigned long long k = h_keys[i];
+                        h_hash[i] = reference_voxel_hash(static_cast<int32_t>(static_cast<long long>((k >> 40) & 0xFFFFFu) - B),
+                                                         static_cast<int32_t>(static_cast<long long>((k >> 20) & 0xFFFFFu) - B),
+                                                         static_cast<int32_t>(static_cast<long long>(k & 0xFFFFFu) - B));
+                    }
+                    std::vector<uint32_t> part;
+                    part.reserve(b - a);
+                    RobinOrderReplay::iteration_order(h_hash.data() + a, b - a, a, part, &rscratch[r & 7]);
+                    std::memcpy(h_perm + a, part.data(), (b - a) * sizeof(uint32_t));
                 };
+                // The largest group (half of the survivors on street scenes) is the critical path: the
+                // calling thread takes it at once, at most two helpers share the others (largest
+                // first, each to the less loaded helper) — starting a thread costs tens of
+                // microseconds, a run of a few thousand keys no more than that.
+                std::vector<size_t> by_size(runs.size());
+                for (size_t r = 0; r < runs.size(); ++r) by_size[r] = r;
+                std::sort(by_size.begin(), by_size.end(), [&](size_t x, size_t y) {
+                    return runs[x].second - runs[x].first > runs[y].second - runs[y].first;
+                });
                 if (kept > 16384 && runs.size() > 1) {
+                    std::vector<size_t> share[2];
+                    size_t load[2] = {0, 0};
+                    for (size_t k = 1; k < by_size.size(); ++k) {
+                        const size_t w = load[1] < load[0] ? 1 : 0;
+                        share[w].push_back(by_size[k]);
+                        load[w] += runs[by_size[k]].second - runs[by_size[k]].first;
+                    }
                     std::vector<std::thread> th;
-                    for (size_t r = 1; r < runs.size(); ++r) th.emplace_back(replay, r);
-                    replay(0);
+                    for (int w = 0; w < 2; ++w)
+                        if (!share[w].empty())
+                            th.emplace_back([&, w] { for (size_t r : share[w]) replay(r); });
+                    replay(by_size[0]);
                     for (auto &t : th) t.join();
                 } else {
                     for (size_t r = 0; r < runs.size(); ++r) replay(r);
                 }
-                for (const auto &part : parts) h_perm.insert(h_perm.end(), part.begin(), part.end());
-                HIPCHK(hipMemcpyAsync(d_perm, h_perm.data(), kept * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+                const double t2 = now_us();
+                HIPCHK(hipMemcpyAsync(d_perm, h_perm, kept * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
                 launch_vds_permute(dst, d_perm, kept, d_tmp, stream);
                 HIPCHK(hipMemcpyAsync(dst, d_tmp, kept * sizeof(Point4), hipMemcpyDeviceToDevice, stream));
                 us_order += now_us() - t0;
+                if (env_int("SAGEICP_DEBUG_ORDER", 0)) {
+                    std::string rs;
+                    for (auto &r : runs) rs += " " + std::to_string(r.second - r.first);
+                    std::fprintf(stderr, "order level %d: kept %u, fetch keys %.0f us, replay %.0f us (runs:%s), rest %.0f us\n",
+                                 l, kept, t1 - t0, t2 - t1, rs.c_str(), now_us() - t2);
+                }
             }
             if (download) {       // otherwise the level's cloud stays in d_fd / d_src for the caller
                 char *hp = static_cast<char *>(h_pin) + static_cast<size_t>(1 + (l & 1)) * cap * sizeof(Point4);
@@ -1153,6 +1191,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         stats->sum_candidates = st.sum_candidates;
         stats->pairs_evaluated = st.sum_pairs;
         stats->lanes_per_query = 1u << lw;
+        stats->compact_scan = ip.filter ? 1u : 0u;
         for (int i = 0; i < 64 && i < st.iter; ++i) stats->n_corr_hist[i] = st.n_corr[i];
         stats->us_wall = now_us() - t_begin;
     }
@@ -1310,6 +1349,17 @@ int sageicp_device_count(void) {
 }
 void sageicp_set_profiling(int level) { g_profiling = level; }
 void sageicp_set_downsample_order(int reference_order) { g_reference_order = reference_order ? 1 : 0; }
+int sageicp_robin_iteration_order(const int32_t *vox_xyz, uint64_t n, uint32_t *order_out) {
+    if (n && (!vox_xyz || !order_out)) return fail(SAGEICP_ERR_INVALID, "null argument");
+    if (n >= (1ull << 28)) return fail(SAGEICP_ERR_INVALID, "too many voxels");
+    std::vector<uint32_t> h(n), order;
+    for (uint64_t i = 0; i < n; ++i) h[i] = reference_voxel_hash(vox_xyz[3 * i], vox_xyz[3 * i + 1], vox_xyz[3 * i + 2]);
+    order.reserve(n);
+    static thread_local RobinScratch scratch;      // (exercises the reuse of the bucket arrays across calls)
+    RobinOrderReplay::iteration_order(h.data(), n, 0u, order, &scratch);
+    std::memcpy(order_out, order.data(), n * sizeof(uint32_t));
+    return SAGEICP_OK;
+}
 
 // ---- map ----------------------------------------------------------------------------------
 sageicp_map *sageicp_map_create(double voxel_size, double max_distance, int basic, int critical,

@@ -148,3 +148,22 @@ def test_far_voxel_sweep_skips_what_shifts_into_the_erased_bucket(oracle):
     assert np.all(np.linalg.norm(pc0[:, :3], axis=1) <= 30.0 + 2.0)
     assert s1 < f1                                     # ... and takes (most of) them the next time
     assert sorted(map(tuple, pc0)) == sorted(map(tuple, pc1)) or s1 >= s0
+
+
+def test_product_replay_matches_independent_restatement(sage):
+    """the product's host replay (csrc/robin_order.hpp, through the C ABI; no device involved):
+    same iteration order as the Python restatement, on key sets from 0 to 40k voxels, called
+    back to back so that the reused bucket arrays are exercised with shrinking and growing sizes"""
+    L = sage.lib()
+    rng = np.random.default_rng(11)
+    for n, span in [(0, 3), (1, 3), (2, 3), (3, 3), (700, 6), (5000, 40), (40000, 300), (33, 2), (9000, 12), (2049, 4000)]:
+        keys = np.unique(rng.integers(-span, span, size=(max(n, 1) * 2, 3)), axis=0)
+        rng.shuffle(keys)
+        keys = np.ascontiguousarray(keys[:n].astype(np.int32))
+        n = len(keys)
+        out = np.zeros(max(n, 1), dtype=np.uint32)
+        assert L.sageicp_robin_iteration_order(keys.ctypes.data, n, out.ctypes.data) == 0
+        r = PyRobin()
+        for i, k in enumerate(keys):
+            r.insert(tuple(int(v) for v in k), i)
+        assert list(out[:n]) == r.order(), (n, span)
