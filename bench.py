@@ -379,6 +379,10 @@ def main():
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                     "algorithmic_bytes_per_launch": round(bytes_per_launch),
+                    # SURVEY 8d "compulsory" figure: every map point, query and hash slot once per
+                    # launch in the compact representation (16 B each)
+                    "compulsory_bytes_per_launch": int(16 * (vmap.size() + n_local + 4 * vmap.num_voxels())),
+                    "compulsory_gbs": round(16 * (vmap.size() + n_local + 4 * vmap.num_voxels()) / (avg_us * 1e-6) / 1e9, 1),
                     "avg_launch_us": round(avg_us, 2), "launches_timed": launches,
                     "launches": all_launches, "queries_per_launch": n_local,
                     "lanes_per_query": last.lanes_per_query,
