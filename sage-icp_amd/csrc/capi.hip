@@ -58,13 +58,17 @@ static int env_int(const char *name, int dflt) {
 // but gives a frame of n points only n / 64 waves with long dependent chains; small frames and
 // shards spread each query over more lanes.  Thresholds measured on MI355X (profiles/README.md);
 // SAGEICP_LW overrides for experiments.
-static int icp_lw(uint64_t n) {
+static int icp_lw(uint64_t n, bool sparse_voxels) {
     const int e = env_int("SAGEICP_LW", -1);
     if (e >= 0) return e > 4 ? 4 : e;
     if (n >= 50000) return 2;
+    // against voxels that hold a few points each a scan is two or three points per lane whatever
+    // the split: four lanes per query then beat eight from 4k queries on (c1: 632 vs 616 frames/s)
+    if (sparse_voxels && n >= 4096) return 2;
     if (n >= 10000) return 3;
     return 4;
 }
+
 
 static int fail(int code, const std::string &msg) {
     g_err = msg;
@@ -946,6 +950,13 @@ double accept_threshold(double max_dist) {
     return std::sqrt(x) < max_dist ? x : -1.0;
 }
 
+// fewer than six points per voxel on average
+static bool sparse_voxels(const sageicp_map *m) {
+    const uint64_t mp = m->on_device ? m->ctr.total_points : m->host.total_points;
+    const uint64_t mv = m->on_device ? m->ctr.num_voxels : m->host.num_voxels;
+    return mp < 6 * mv;
+}
+
 // k_icp's arguments for a search of `n` queries against the HBM copy of `m`
 IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, double sem_th, int lw) {
     const Scratch &sc = m->sc;
@@ -974,9 +985,7 @@ IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, 
         // worth it where scans are long and bytes are what the kernel is made of: frames of 40k+
         // points against voxels holding 6+ points on average (c2: +6 %, c4: +10 %; c1, c5 and the
         // streamed 24k-point frames lose 4-5 % with it; SAGEICP_FILTER=0/1 overrides)
-        const uint64_t mp = m->on_device ? m->ctr.total_points : m->host.total_points;
-        const uint64_t mv = m->on_device ? m->ctr.num_voxels : m->host.num_voxels;
-        const int want = env_int("SAGEICP_FILTER", (n >= 40000 && mp >= 6 * mv) ? 1 : 0);
+        const int want = env_int("SAGEICP_FILTER", (n >= 40000 && !sparse_voxels(m)) ? 1 : 0);
         const bool filt = sem_th >= 0.0 && want != 0 && env_int("SAGEICP_NO_FILTER", 0) == 0;
         ip.filter = (sem_th >= 0.0 && want != 0) ? 1 : 0;
         ip.filt_inv_diff = filt ? k1 : inf;
@@ -1032,7 +1041,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     }
     HIPCHK(hipMemcpyAsync(sc.d_state, sc.h_state, sizeof(IcpState), hipMemcpyHostToDevice, s));
 
-    const int lw = icp_lw(n);
+    const int lw = icp_lw(n, sparse_voxels(m));
     const int blocks = n ? icp_blocks_for(static_cast<int>(n), lw) : 1;
     if ((rc = ensure_cand(m))) return rc;
     if ((rc = sc.reserve_sort(n))) return rc;
@@ -1616,7 +1625,7 @@ int sageicp_get_correspondences(const sageicp_map *m, const double *q, uint64_t 
     HIPCHK(sort_frame(sc.d_frame, sc.d_sorted, static_cast<int>(n), sc.d_state, false,
                       m->host.voxel_size, sc.d_keys, sc.d_vals, sc.d_sort_temp, sc.sort_temp_bytes_,
                       s));
-    const int lw = icp_lw(n);
+    const int lw = icp_lw(n, sparse_voxels(m));
     if ((rc = ensure_cand(m))) return rc;
     const IcpParams ip = icp_params(m, sc.d_sorted, n, sem_th, lw);     // identity pose, no loop state
     launch_rows(ip, s);
