@@ -13,11 +13,10 @@ p = syn.PARAMS["cold"]
 n = len(w["scan"])
 f = sage.Frame(w["map"], w["scan"])
 pose, st = sage.register_frame(f, w["map"], sage.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"], return_stats=True)
-buf = (C.c_uint32 * (4 * n))()
-L.sageicp_debug_prev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
-rc = L.sageicp_debug_prev(w["map"]._h, buf, n)
-a = np.frombuffer(buf, dtype=np.uint32).reshape(n, 4)
-r = a[:, 2].astype(np.int64)
+buf = (C.c_uint32 * n)()
+L.sageicp_debug_work.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+rc = L.sageicp_debug_work(w["map"]._h, buf, n)
+r = np.frombuffer(buf, dtype=np.uint32).astype(np.int64)
 print("rc", rc, "queries", n, "points handed out per query: mean %.1f" % r.mean(), "quantiles 50/75/90/95/99/99.9/max:", *np.percentile(r, [50, 75, 90, 95, 99, 99.9]).round(0), r.max())
 for T in (48, 64, 96, 128, 192, 256):
     print("   > %3d points: %5.2f %% of the queries, %5.1f %% of the points" % (T, 100.0 * (r > T).mean(), 100.0 * r[r > T].sum() / r.sum()))

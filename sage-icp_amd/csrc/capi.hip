@@ -101,7 +101,8 @@ struct Scratch {
     void *d_sort_temp = nullptr; size_t sort_cap = 0; size_t sort_temp_bytes_ = 0;
     // per-call work buffers: the queries' cached neighbourhood rows, the workgroup partials
     uint32_t *d_rows = nullptr;
-    uint4 *d_prev = nullptr;       // every query's record of the previous iteration (kernels.h)
+    uint2 *d_prev = nullptr;       // every query's record of the previous iteration (kernels.h)
+    uint32_t *d_work = nullptr;    // instrumented builds: points handed to each query
     double *d_partials = nullptr; size_t partials_cap = 0;
     unsigned long long *d_cand = nullptr;      // per-wave counters of k_icp [2 x sort_cap]
     IcpState *d_state = nullptr;
@@ -166,7 +167,12 @@ struct Scratch {
         const size_t cap = n + n / 4 + 1024;
         HIPCHK(hipMalloc(&d_sorted, cap * sizeof(Point4)));
         HIPCHK(hipMalloc(&d_rows, cap * kRowWords * sizeof(uint32_t)));
-        HIPCHK(hipMalloc(&d_prev, cap * sizeof(uint4)));
+        HIPCHK(hipMalloc(&d_prev, cap * sizeof(uint2)));
+#ifdef SAGE_NN_TIMING
+        if (d_work) HIPCHK(hipFree(d_work));
+        d_work = nullptr;
+        HIPCHK(hipMalloc(&d_work, cap * sizeof(uint32_t)));
+#endif
         if (d_cand) HIPCHK(hipFree(d_cand));
         d_cand = nullptr;
         HIPCHK(hipMalloc(&d_cand, 2 * cap * sizeof(unsigned long long)));
@@ -209,6 +215,7 @@ struct Scratch {
         if (d_sort_temp) (void)hipFree(d_sort_temp);
         if (d_rows) (void)hipFree(d_rows);
         if (d_prev) (void)hipFree(d_prev);
+        if (d_work) (void)hipFree(d_work);
         if (d_partials) (void)hipFree(d_partials);
         if (d_state) (void)hipFree(d_state);
         if (d_cand) (void)hipFree(d_cand);
@@ -1005,6 +1012,7 @@ IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, 
     ip.kernel = 0.0;
     ip.accept_r2 = -1.0;
     ip.nn_prev = sc.d_prev;
+    ip.work = sc.d_work;
     ip.partials = sc.d_partials;
     ip.counters = nullptr;
     const uint64_t qw = 64u >> lw;
@@ -1066,7 +1074,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
                           m->host.voxel_size, sc.d_keys, sc.d_vals, sc.d_sort_temp,
                           sc.sort_temp_bytes_, s));
         launch_rows(ip, s);
-        HIPCHK(hipMemsetAsync(sc.d_prev, 0xFF, n * sizeof(uint4), s));     // no previous answers yet
+        HIPCHK(hipMemsetAsync(sc.d_prev, 0xFF, n * sizeof(uint2), s));     // no previous answers yet
     }
 
     FinParams fp{};
@@ -2065,9 +2073,9 @@ int sageicp_metrics_absolute_trajectory_error(const double *poses_gt, const doub
 }  // extern "C"
 
 #ifdef SAGE_NN_TIMING
-// probe: every query's record of the last iteration (sorted order): {key, offset, points handed out, -}
-extern "C" int sageicp_debug_prev(const sageicp_map *m, uint32_t *out, size_t n) {
-    if (!m || !m->sc.d_prev) return SAGEICP_ERR_INVALID;
-    return hipMemcpy(out, m->sc.d_prev, n * 16, hipMemcpyDeviceToHost) == hipSuccess ? SAGEICP_OK : SAGEICP_ERR_HIP;
+// probe: map points handed to every query in the last iteration (sorted order)
+extern "C" int sageicp_debug_work(const sageicp_map *m, uint32_t *out, size_t n) {
+    if (!m || !m->sc.d_work) return SAGEICP_ERR_INVALID;
+    return hipMemcpy(out, m->sc.d_work, n * 4, hipMemcpyDeviceToHost) == hipSuccess ? SAGEICP_OK : SAGEICP_ERR_HIP;
 }
 #endif

@@ -55,10 +55,11 @@ struct IcpParams {
     double kernel;            // robust kernel k: w = k^2 / (k + |r|^2)^2 (Registration.cpp:79)
     double accept_r2;         // largest r2 with sqrt(r2) < max_correspondence_distance (exact form
                               // of the acceptance test VoxelHashMap.cpp:111; -1: accept nothing)
-    uint4 *nn_prev;           // [n] in/out: every query's record of the previous iteration {key =
-                              // (voxel << 8) | slot of its nearest neighbour, its byte offset,
-                              // map points looked at, -}; key 0xFFFFFFFF: none (after a re-sort).
-                              // Seeds the next search with a tight bound.
+    uint2 *nn_prev;           // [n] in/out: every query's record of the previous iteration {key =
+                              // (voxel << 8) | slot of its nearest neighbour, its byte offset (index
+                              // when big)}; key 0xFFFFFFFF: none.  Seeds the next search with a
+                              // tight bound.
+    uint32_t *work;           // instrumented builds only: [n] map points handed to each query
     double *partials;         // out: [gridDim.x][kNumSums] one partial per workgroup
     unsigned long long *counters;  // optional: [2 x waves] running sums of {C_q, pairs evaluated}
     unsigned nwaves;          // waves that own queries: ceil(n / (64 >> lw))

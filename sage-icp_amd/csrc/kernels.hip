@@ -393,7 +393,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
     // checked — this lane's share of the cached row (words 0..27 in seven 16-B pieces).
     constexpr int NP = (7 + W - 1) / W;        // pieces per lane
     const uint4 rk = *reinterpret_cast<const uint4 *>(grow + kRowKey);     // key x, y, z | occupancy
-    uint4 prev = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);   // the previous iteration's record of this query
+    uint2 prev = make_uint2(0xFFFFFFFFu, 0u);     // the previous iteration's record of this query
     if (FUSED) prev = P.nn_prev[qc];
     const Point4 f = P.frame[qc];
     // (named registers, not an array: the compiler leaves a uint4 array in scratch memory)
@@ -731,7 +731,10 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
         if (valid && ci == 0u) P.nn_idx[q] = found ? static_cast<int>(woff >> SH) : -1;
     } else {
         // ---- fused epilogue: acceptance + Gauss-Newton terms of this query's pair -----------------
-        if (valid && ci == 0u) P.nn_prev[q] = make_uint4(found ? mkey : 0xFFFFFFFFu, woff, npairs, 0u);
+        if (valid && ci == 0u) P.nn_prev[q] = make_uint2(found ? mkey : 0xFFFFFFFFu, woff);
+#ifdef SAGE_NN_TIMING
+        if (valid && ci == 0u && P.work) P.work[q] = npairs;
+#endif
         double t[kCount];
 #pragma unroll
         for (int c = 0; c < kCount; ++c) t[c] = 0.0;
