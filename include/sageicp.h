@@ -72,7 +72,7 @@ typedef struct sageicp_stats {
 int sageicp_abi_version(void);
 const char *sageicp_last_error(void);
 int sageicp_device_count(void);               /* number of visible HIP devices (0: none) */
-void sageicp_set_profiling(int level);        /* 0 off; 1 HIP events around k_nn in one iteration
+void sageicp_set_profiling(int level);        /* 0 off; 1 HIP events around k_icp in one iteration
                                                * out of 8; 2 around every kernel of every iteration */
 
 /* ---- map: sage_icp::VoxelHashMap (core/VoxelHashMap.hpp:35-107) ------------------------ */

@@ -628,8 +628,8 @@ int sync_mirror(const sageicp_map *m) {
     if (blocks_cap > m->d_blocks_cap) {
         if (m->d_pts) HIPCHK(hipFree(m->d_pts));
         m->d_pts = nullptr; m->d_blocks_cap = 0;
-        // one extra point after the blocks: NaN coordinates, the target of the padding entries of
-        // k_nn's candidate lists (its distance to anything fails every comparison)
+        // (one extra point after the blocks, NaN coordinates: a harmless target for an offset of
+        // one past the end)
         HIPCHK(hipMalloc(&m->d_pts, blocks_cap * block_bytes + sizeof(Point4)));
         const double qnan = std::numeric_limits<double>::quiet_NaN();
         const Point4 pad{qnan, qnan, qnan, qnan};
