@@ -339,6 +339,27 @@ def test_register_frame_pose_parity_c2_scaled(gpu_sage, oracle, params, scan_for
     assert np.array_equal(pose, pose2)
 
 
+def test_wide_addressing_in_both_scan_forms(gpu_sage, oracle, scan_form, monkeypatch):
+    """the k_icp variant for point arrays of 4 GiB and more (64-bit addressed records, compact
+    and full), forced onto a small map: index-exact search and the same registration"""
+    from sage_icp_amd import synthetic as syn
+    monkeypatch.setenv("SAGEICP_FORCE_BIG", "1")
+    mp, q = random_scene(21)
+    a, b = both_maps(gpu_sage, oracle, mp)
+    for th in (0.4, 1.0):
+        _, tgt, idx = a.GetCorrespondences(q, 6.0, th, with_index=True)
+        _, otgt, oidx = b.get_correspondences(q, 6.0, th, with_index=True)
+        assert len(oidx) > 0 and np.array_equal(idx, oidx) and np.array_equal(tgt, otgt)
+    w, om = _workload(gpu_sage, oracle, "c2", 0.1)
+    p = syn.PARAMS["cold"]
+    pose, st = gpu_sage.register_frame(w["scan"], w["map"], gpu_sage.IDENTITY, p["max_dist"],
+                                       p["kernel"], p["sem_th"], return_stats=True)
+    opose, ost = om.register_frame(w["scan"], oracle.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"])
+    dt, dr = pose_error(oracle, opose, pose)
+    assert dt < 1e-7 and dr < 1e-7 and st.iterations == ost.iterations
+    assert st.compact_scan == (1 if scan_form == "compact" else 0)
+
+
 @pytest.mark.parametrize("params", ["dense", "dense_nosem"])
 def test_register_frame_pose_parity_c5_scaled(gpu_sage, oracle, params, scan_form):
     """c5 (BASELINE configs[4]): dense scan vs a 0.1 m voxel map, semantic scaling on (0.8) / off (1.0)"""
