@@ -230,6 +230,15 @@ void sageicp_pipeline_destroy(sageicp_pipeline *p);
 int sageicp_pipeline_register_frame(sageicp_pipeline *p, const double *frame_xyzl, uint64_t n,
                                     double pose_out[7], double *icp_seconds, double *total_seconds,
                                     uint64_t *n_source, sageicp_stats *stats /* optional */);
+/* Streams: announce the frame that FOLLOWS the next one registered.  Preprocess() + Voxelize()
+ * (pipeline/sageICP.cpp:57-67) read the raw frame only — not the pose, not the map — so
+ * sageicp_pipeline_register_frame() runs the announced frame's on a second set of device buffers
+ * (own stream, own host thread) under the ICP loop and the map update of the frame it was called
+ * for, and the call that later registers the announced frame (same pointer, same n) takes the
+ * prepared clouds instead of computing them.  Results are bit-identical with and without; a frame
+ * that was announced but not registered next is dropped.  The buffer must stay valid and
+ * unchanged until the call that registers it returns.  One frame ahead, no queue. */
+int sageicp_pipeline_prefetch(sageicp_pipeline *p, const double *next_frame_xyzl, uint64_t n);
 int sageicp_pipeline_reinitialize(sageicp_pipeline *p);          /* pipeline/sageICP.hpp:94-99 */
 uint64_t sageicp_pipeline_num_poses(const sageicp_pipeline *p);  /* poses().size() */
 int sageicp_pipeline_pose(const sageicp_pipeline *p, uint64_t index, double pose_out[7]);

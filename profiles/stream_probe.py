@@ -11,8 +11,13 @@ print("map update on", "device" if dev_update else "host")
 sage.set_profiling(2 if len(sys.argv) > 1 else 0)
 kt = []
 rows = []
+prefetch = os.environ.get("STREAM_PREFETCH", "0") == "1"
+print("next frame's preprocessing under this frame's ICP loop:", "on" if prefetch else "off")
+frames = [np.ascontiguousarray(f, dtype=np.float64) for f in frames]
 for k, f in enumerate(frames):
     t = time.perf_counter()
+    if prefetch and k + 1 < len(frames):
+        p.prefetch(frames[k + 1])
     pose, icp_s, tot_s, ns, st = p.RegisterFrame(f)
     wall = time.perf_counter() - t
     rows.append((wall, tot_s, icp_s, ns, st.iterations, st.us_upload))

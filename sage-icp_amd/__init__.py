@@ -163,6 +163,7 @@ _SIGNATURES = [
     ("sageicp_pipeline_destroy", None, [C.c_void_p]),
     ("sageicp_pipeline_register_frame", C.c_int,
      [C.c_void_p, _dp, C.c_uint64, _dp, _dp, _dp, _u64p, C.POINTER(Stats)]),
+    ("sageicp_pipeline_prefetch", C.c_int, [C.c_void_p, _dp, C.c_uint64]),
     ("sageicp_pipeline_reinitialize", C.c_int, [C.c_void_p]),
     ("sageicp_pipeline_num_poses", C.c_uint64, [C.c_void_p]),
     ("sageicp_pipeline_pose", C.c_int, [C.c_void_p, C.c_uint64, _dp]),
@@ -448,6 +449,17 @@ class SageICP:
                                                      out.ctypes.data_as(_dp), C.byref(icp),
                                                      C.byref(tot), C.byref(ns), C.byref(st)))
         return out, icp.value, tot.value, ns.value, st
+
+    def prefetch(self, next_frame):
+        """Announce the frame after the next one registered: its Preprocess() + Voxelize() then run
+        under that frame's ICP loop (sageicp_pipeline_prefetch).  Returns the array to pass to
+        RegisterFrame() later (the same buffer: it is matched by address) — keep it alive."""
+        pts, pp = _d(next_frame)
+        # keep the buffer alive until it has been registered (the one announced before it may
+        # still be waiting for its RegisterFrame)
+        self._announced = (getattr(self, "_announced", ()) + ((pts, pp),))[-2:]
+        _check(lib().sageicp_pipeline_prefetch(self._h, pp, pts.reshape(-1, 4).shape[0]))
+        return pts
 
     def reinitialize(self):
         _check(lib().sageicp_pipeline_reinitialize(self._h))

@@ -1967,10 +1967,40 @@ int sageicp_voxel_downsample(const double *frame, uint64_t n, int n_groups,
 // ---- pipeline counterpart -----------------------------------------------------------------------
 struct sageicp_pipeline {
     sageicp::Pipeline impl;
-    sageicp::Prep prep;
+    // Preprocess() + Voxelize() depend on the raw frame only (not on the pose, not on the map), so
+    // the next frame's can run while this one registers (sageicp_pipeline_prefetch): two sets of
+    // buffers and streams, `cur` the one the frame being registered lives in.
+    sageicp::Prep prep[2];
+    int cur = 0;
     int device;
+    std::thread worker;                  // runs the announced frame's voxelize on prep[cur ^ 1]
+    bool announced = false;              // _prefetch named the frame that follows the next one registered
+    const double *an_frame = nullptr;
+    uint64_t an_n = 0;
+    bool ready = false;                  // prep[cur ^ 1] holds (or the worker is filling it with) pf_frame
+    const double *pf_frame = nullptr;
+    uint64_t pf_n = 0;
+    int pf_rc = 0;
+    std::string pf_err;
     explicit sageicp_pipeline(const sageicp_pipeline_config &c) : impl(c), device(c.device) {}
-    ~sageicp_pipeline() { prep.destroy(); }
+    ~sageicp_pipeline() {
+        if (worker.joinable()) worker.join();
+        prep[0].destroy();
+        prep[1].destroy();
+    }
+    int voxelize_into(sageicp::Prep &pr, const double *f, uint64_t m) {
+        int rc = pr.init(device);
+        if (rc) return rc;
+        std::vector<int> counts, labels;
+        std::vector<double> vs;
+        impl.group_tables(counts, labels, vs);
+        const int crop[2] = {1, 0};
+        const double scales[2] = {0.5, 1.5};
+        std::vector<std::vector<double>> res;
+        return pr.run(f, m, impl.max_range_(), impl.min_range_(), impl.label_max_range_(),
+                      static_cast<int>(counts.size()), counts.data(), labels.data(), vs.data(),
+                      crop, scales, 2, res, false);
+    }
 };
 
 sageicp_pipeline *sageicp_pipeline_create(const sageicp_pipeline_config *c) {
@@ -1990,8 +2020,6 @@ int sageicp_pipeline_register_frame(sageicp_pipeline *p, const double *frame, ui
                                     double pose_out[7], double *icp_s, double *total_s,
                                     uint64_t *n_source, sageicp_stats *stats) {
     if (!p || !pose_out || (n && !frame)) return fail(SAGEICP_ERR_INVALID, "null argument");
-    int rc = p->prep.init(p->device);
-    if (rc) return rc;
     // Preprocess + Voxelize on the device (preprocess.hip): crop + scale 0.5, then scale 1.5.
     // Neither cloud comes back to the host: the source is registered and the down-sampled frame
     // inserted into the map from where the kernels left them (only a host-side map update
@@ -1999,40 +2027,67 @@ int sageicp_pipeline_register_frame(sageicp_pipeline *p, const double *frame, ui
     struct Backend {
         sageicp_pipeline *p;
         int voxelize(const double *f, uint64_t m, uint64_t &n_src) {
-            std::vector<int> counts, labels;
-            std::vector<double> vs;
-            p->impl.group_tables(counts, labels, vs);
-            const int crop[2] = {1, 0};
-            const double scales[2] = {0.5, 1.5};
-            std::vector<std::vector<double>> res;
-            int r = p->prep.run(f, m, p->impl.max_range_(), p->impl.min_range_(), p->impl.label_max_range_(),
-                                static_cast<int>(counts.size()), counts.data(), labels.data(), vs.data(),
-                                crop, scales, 2, res, false);
-            n_src = p->prep.kept_levels[1];
+            if (p->worker.joinable()) p->worker.join();
+            int r;
+            if (p->ready && p->pf_frame == f && p->pf_n == m) {      // prepared while the last frame registered
+                r = p->pf_rc ? fail(p->pf_rc, p->pf_err) : SAGEICP_OK;
+                p->cur ^= 1;
+            } else {                                                 // none, or another frame: dropped
+                r = p->voxelize_into(p->prep[p->cur], f, m);
+            }
+            p->ready = false;
+            n_src = p->prep[p->cur].kept_levels[1];
+            if (r == SAGEICP_OK && p->announced) {
+                // the frame after this one: its Preprocess() + Voxelize() run on the other set of
+                // buffers (own stream, own host thread) under this frame's ICP loop and map update
+                p->ready = true;
+                p->pf_frame = p->an_frame;
+                p->pf_n = p->an_n;
+                p->pf_rc = 0;
+                p->pf_err.clear();
+                sageicp_pipeline *q = p;
+                sageicp::Prep *dst = &p->prep[p->cur ^ 1];
+                const double *nf = p->an_frame;
+                const uint64_t nn = p->an_n;
+                p->worker = std::thread([q, dst, nf, nn] {
+                    (void)hipSetDevice(q->device);
+                    q->pf_rc = q->voxelize_into(*dst, nf, nn);
+                    if (q->pf_rc) q->pf_err = g_err;                 // the error text is per thread
+                });
+            }
+            p->announced = false;
             return r;
         }
         int register_source(const double guess[7], double max_dist, double kernel, double sem_th,
                             double pose[7], sageicp_stats *stats) {
             sageicp_frame view;                 // non-owning: the source cloud in the Prep buffers
             view.device = p->device;
-            view.d = p->prep.d_src;
-            view.n = p->prep.kept_levels[1];
+            view.d = p->prep[p->cur].d_src;
+            view.n = p->prep[p->cur].kept_levels[1];
             return sageicp_register_frame_resident(p->impl.map, &view, guess, max_dist, kernel, sem_th,
                                                    nullptr, pose, stats);
         }
         int update_map(const double pose[7]) {
-            const uint64_t n_fd = p->prep.kept_levels[0];
+            const sageicp::Prep &pr = p->prep[p->cur];
+            const uint64_t n_fd = pr.kept_levels[0];
             if (p->impl.map_update_on_device_())
-                return device_update_all(p->impl.map, nullptr, n_fd, pose, p->prep.d_fd);
+                return device_update_all(p->impl.map, nullptr, n_fd, pose, pr.d_fd);
             std::vector<double> fd(4 * n_fd);
             if (n_fd) {
                 HIPCHK(hipSetDevice(p->device));
-                HIPCHK(hipMemcpy(fd.data(), p->prep.d_fd, n_fd * sizeof(Point4), hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(fd.data(), pr.d_fd, n_fd * sizeof(Point4), hipMemcpyDeviceToHost));
             }
             return sageicp_map_update_pose(p->impl.map, fd.data(), n_fd, pose);
         }
     };
     return p->impl.register_frame(frame, n, pose_out, icp_s, total_s, n_source, stats, Backend{p});
+}
+int sageicp_pipeline_prefetch(sageicp_pipeline *p, const double *frame, uint64_t n) {
+    if (!p || (n && !frame)) return fail(SAGEICP_ERR_INVALID, "null argument");
+    p->announced = true;
+    p->an_frame = frame;
+    p->an_n = n;
+    return SAGEICP_OK;
 }
 int sageicp_pipeline_reinitialize(sageicp_pipeline *p) {
     if (!p) return fail(SAGEICP_ERR_INVALID, "null pipeline");

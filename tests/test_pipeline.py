@@ -93,6 +93,28 @@ def test_stream_pose_parity_restarted_and_free_running(gpu_sage, oracle, referen
     assert dt < 0.15 and dr < 0.01
 
 
+@pytest.mark.gpu
+def test_stream_with_prefetch_is_bit_identical(gpu_sage, reference_emission_order):
+    """sageicp_pipeline_prefetch: the next frame's Preprocess() + Voxelize() under this frame's ICP
+    loop.  Same poses to the bit, same source sizes, same map — also when an announced frame is not
+    the one registered next (dropped), and with frames of different sizes alternating."""
+    from sage_icp_amd import synthetic as syn
+    frames, _ = syn.make_stream(5, 10, points_per_frame=30000)
+    frames = [np.ascontiguousarray(f if k % 3 else f[: len(f) // 2], dtype=np.float64)
+              for k, f in enumerate(frames)]
+    cfg = gpu_sage.make_pipeline_config()
+    a, b = gpu_sage.SageICP(cfg), gpu_sage.SageICP(cfg)
+    for k, f in enumerate(frames):
+        pa, _, _, ns_a, st_a = a.RegisterFrame(f)
+        if k + 1 < len(frames):
+            # frame 4 announces a frame that never comes: the prepared clouds must be ignored
+            b.prefetch(frames[0] if k == 4 else frames[k + 1])
+        pb, _, _, ns_b, st_b = b.RegisterFrame(f)
+        assert ns_a == ns_b and st_a.iterations == st_b.iterations, "frame %d" % k
+        assert np.array_equal(pa, pb), "frame %d" % k
+    assert np.array_equal(a.LocalMap(), b.LocalMap())
+
+
 def _py_preprocess(frame, max_range, min_range, label_max_range):
     out = []
     for p in frame:

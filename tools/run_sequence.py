@@ -44,7 +44,16 @@ def main():
     pipe = sage.SageICP(sage.make_pipeline_config(sem_th=args.sem_th))
     t0 = time.time()
     icp = 0.0
-    for k, f in enumerate(frames):
+    # one frame of look-ahead: the file of frame k + 1 is read, and its crop + down-sampling run on
+    # the device (pipe.prefetch), while frame k registers
+    frames = iter(frames)
+    nxt = next(frames, None)
+    k = -1
+    while nxt is not None:
+        f, k = np.ascontiguousarray(nxt, dtype=np.float64), k + 1
+        nxt = next(frames, None)
+        if nxt is not None:
+            nxt = pipe.prefetch(nxt)
         pose, icp_s, tot_s, ns, st = pipe.RegisterFrame(f)
         icp += icp_s
         if k % 10 == 0:
