@@ -1,16 +1,18 @@
-"""Per-iteration time of one rank's share of the c2 frame (120k / N queries against the full map),
-without any exchange: the compute side of the strong-scaling curve."""
+"""Per-iteration time of one rank's share of the c2 (or, `shard_probe.py c4`, the c4) frame (the
+first 1/N of the queries against the full map), without any exchange: the compute side of the
+strong-scaling curve."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import sage_icp_amd as sage
 from sage_icp_amd import synthetic as syn
-w = syn.make_workload("c2", lambda: sage.VoxelHashMap(1.0, 100.0))
+wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
+w = syn.make_workload(wl, lambda: sage.VoxelHashMap(syn.WORKLOADS[wl]["voxel"], 100.0))
 p = syn.PARAMS["cold"]
 for N in (1, 2, 4, 8):
     n = len(w["scan"]) // N
     f = sage.Frame(w["map"], w["scan"][:n])
     for _ in range(3): sage.register_frame(f, w["map"], sage.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"])
-    t = time.perf_counter(); K = 20
+    t = time.perf_counter(); K = 20 if wl == "c2" else 6
     for _ in range(K): pose, st = sage.register_frame(f, w["map"], sage.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"], return_stats=True)
     dt = (time.perf_counter() - t) / K
     print("N=%d  %6d queries  %.3f ms/frame  %d iterations  %.1f us/iteration" % (N, n, 1e3 * dt, st.iterations, 1e6 * dt / st.iterations))
