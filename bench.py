@@ -9,7 +9,8 @@ already resident in HBM when the timed region starts.
           reference start-up parameters (sigma = 2.0 -> max_corr 6.0, kernel 2/3, sem_th 0.4).
   N > 1   the SAME frame, query-sharded in contiguous blocks over the N ranks (one process per
           GPU), map replicated, the 17 Gauss-Newton sums exchanged over xGMI each iteration
-          -> strong scaling.  (--workload c4 runs the 500k-vs-10M multi-GPU config.)
+          -> strong scaling.  (--workload c4 runs the 500k-vs-10M multi-GPU config;
+          --independent gives every rank a whole frame instead: throughput, weak scaling.)
           `python bench.py --gpus N` launches its own ranks (torch.distributed.run) when it was
           not started under a launcher.
 
@@ -47,6 +48,10 @@ def parse():
                     help="default: cold (c1, c2, c4), dense (c5)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--independent", action="store_true",
+                    help="N > 1: every rank registers a WHOLE frame against its own copy of the map "
+                         "(one stream per GPU, no exchange): the throughput curve of BASELINE config 5; "
+                         "value = frames of all ranks per second, scaling weak")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="CPU time budget of the cpu_baseline sample")
     ap.add_argument("--no-profile-events", action="store_true",
@@ -204,7 +209,7 @@ def main():
                           scale=args.scale)
     vmap, scan = w["map"], w["scan"]
     vmap.sync()                                    # map mirror resident before the timed region
-    lo, hi = shard_bounds(len(scan), rank, world)
+    lo, hi = (0, len(scan)) if args.independent else shard_bounds(len(scan), rank, world)
     frame = sage.Frame(vmap, scan[lo:hi])          # this rank's block of the scan, resident in HBM
     t_gen = time.time() - t_gen
 
@@ -220,7 +225,9 @@ def main():
 
     RCCL_TEXT = "RCCL all-reduce of 20 fp64 sums over %d ranks + solve launch" % world
 
-    if use_dist:
+    if use_dist and args.independent:
+        exchange = "none: independent frames, one per rank"
+    elif use_dist:
         have_rccl = backend == "nccl" and os.environ.get("SAGEICP_NO_RCCL", "0") != "1"
         if have_rccl:
             ids = [sage.Comm.unique_id() if rank == 0 else None]
@@ -412,7 +419,7 @@ def main():
             except Exception:
                 pass
 
-    fps = args.steps / elapsed
+    fps = args.steps / elapsed * (world if args.independent else 1)
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, w, wl, prm, scan, iters, fps)
@@ -438,7 +445,7 @@ def main():
         "ms_per_step": round(1e3 * elapsed / args.steps, 4),
         "ms_per_step_host_entry": None if host_entry_ms is None else round(host_entry_ms, 4),
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": "weak" if args.independent else "strong",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -447,7 +454,9 @@ def main():
                                "guess, full ICP loop to convergence"
                                % (args.workload, args.params, len(scan), vmap.size(), wl["voxel"],
                                   prm["max_dist"], prm["kernel"], prm["sem_th"]),
-                   "parallelism": "query-sharded x%d, map replicated, %s" % (world, exchange)
+                   "parallelism": ("independent frames x%d (one whole frame per rank and step), map "
+                                   "replicated, no exchange" % world) if use_dist and args.independent
+                                  else "query-sharded x%d, map replicated, %s" % (world, exchange)
                                   if use_dist else "single GPU",
                    "ranks": world,
                    "scan_points": len(scan), "map_points": vmap.size(),

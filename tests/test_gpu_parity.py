@@ -606,6 +606,33 @@ def test_direct_exchange_between_two_processes(gpu_sage, tmp_path):
     assert d2["config"]["converged"] and d2["config"]["pose_error_vs_planted"] == d1["config"]["pose_error_vs_planted"]
 
 
+def test_bench_independent_frames_mode(gpu_sage):
+    """bench.py --independent (the throughput curve of BASELINE config 5): two ranks on the one GPU
+    of the box, each registering the whole frame against its own map, no exchange: weak scaling,
+    the frames of all ranks counted, the same registration as one rank's"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SAGEICP_BENCH_DEVICE="0", SAGEICP_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    common = ["--workload", "c5", "--steps", "2", "--warmup", "1", "--scale", "0.1", "--no-cpu-baseline"]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                          "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29537",
+                          os.path.join(root, "bench.py"), "--gpus", "2", "--independent"] + common,
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    d2 = json.loads(two.stdout.strip().splitlines()[-1])
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common,
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads(one.stdout.strip().splitlines()[-1])
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "weak" and "independent frames x2" in d2["config"]["parallelism"]
+    assert abs(d2["value"] - 2 * 1e3 / d2["ms_per_step"]) < 1e-2 * d2["value"]
+    assert d2["config"]["iterations_per_frame"] == d1["config"]["iterations_per_frame"]
+    assert d2["config"]["pose_error_vs_planted"] == d1["config"]["pose_error_vs_planted"]
+    assert d2["roofline"]["queries_per_launch"] == d1["roofline"]["queries_per_launch"]
+
+
 def test_direct_exchange_timeout_is_reported_not_hung(gpu_sage):
     """a peer whose sums do not arrive in time stops the loop with an error on every rank"""
     import subprocess
