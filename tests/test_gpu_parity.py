@@ -9,10 +9,11 @@ import os
 
 import numpy as np
 import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
 
 pytestmark = pytest.mark.gpu
 
-GOLD = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "street_*.npz")))
 TOL_M = 1e-4
 TOL_RAD = 1e-4
 
@@ -54,6 +55,45 @@ def test_correspondences_index_exact(gpu_sage, oracle, seed, vs, basic, critical
     assert len(oidx) > 0
     assert np.array_equal(idx, oidx)
     assert np.array_equal(tgt, otgt) and np.array_equal(src, osrc)
+
+
+@settings(max_examples=30, deadline=None, suppress_health_check=list(HealthCheck))
+@given(seed=st.integers(0, 2**31 - 1), vs=st.sampled_from([0.1, 0.3, 0.8, 1.0, 2.5]),
+       th=st.sampled_from([0.05, 0.4, 1.0, 1.7]), md=st.sampled_from([0.2, 0.9, 2.0, 6.0]),
+       basic=st.integers(0, 24), critical=st.integers(1, 24), span=st.sampled_from([1.5, 6.0, 20.0]),
+       lw=st.integers(0, 4), compact=st.booleans(), n_q=st.sampled_from([1, 63, 700, 5000]))
+def test_get_correspondences_property(gpu_sage, oracle, seed, vs, th, md, basic, critical, span, lw,
+                                      compact, n_q):
+    """random clouds, voxel sizes, capacities, thresholds, query counts, clustered queries and
+    queries on voxel faces, in every kernel variant: the HIP search against the oracle, index for
+    index and bit for bit"""
+    old = {k: os.environ.get(k) for k in ("SAGEICP_LW", "SAGEICP_FILTER")}
+    os.environ["SAGEICP_LW"], os.environ["SAGEICP_FILTER"] = str(lw), "1" if compact else "0"
+    try:
+        rng = np.random.default_rng(seed)
+        labels = [0, 0, 10, 40, 44, 50, 70, 71, 80, 251]
+        mp = rng.uniform(-span, span, size=(6000, 4))
+        mp[:, 2] *= 0.2
+        mp[:, 3] = rng.choice(labels, size=len(mp))
+        q = rng.uniform(-span - vs, span + vs, size=(n_q, 4))
+        q[:, 2] *= 0.2
+        if seed % 4 == 1:                   # clustered queries: many share a home voxel
+            q[:, :3] = q[0, :3] + rng.normal(size=(n_q, 3)) * 0.3 * vs
+        q[:, 3] = rng.choice(labels, size=n_q)
+        if seed % 3 == 0:                   # queries exactly on voxel faces
+            q[:, :3] = np.round(q[:, :3] / vs) * vs
+        a, b = both_maps(gpu_sage, oracle, mp, vs, 100.0, basic, critical)
+        assert a.size() == b.size()
+        src, tgt, idx = a.GetCorrespondences(q, md, th, with_index=True)
+        osrc, otgt, oidx = b.get_correspondences(q, md, th, with_index=True)
+        assert np.array_equal(idx, oidx)
+        assert np.array_equal(tgt, otgt) and np.array_equal(src, osrc)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
@@ -337,6 +377,33 @@ def test_register_frame_pose_parity_c2_scaled(gpu_sage, oracle, params, scan_for
     pose2 = gpu_sage.register_frame(f, w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"],
                                     p["sem_th"])
     assert np.array_equal(pose, pose2)
+
+
+@pytest.mark.parametrize("lw", [0, 1, 2, 3, 4])
+def test_every_lanes_per_query_variant(gpu_sage, oracle, scan_form, lw, monkeypatch):
+    """k_icp is compiled for 1, 2, 4, 8 and 16 lanes per query and the library picks by frame size
+    and voxel density (capi.hip::icp_lw), so a given workload only ever reaches one or two of the
+    variants: each is forced in turn (SAGEICP_LW) in both scan forms — index-exact search, the same
+    registration as the oracle's, the same exact candidate count."""
+    from sage_icp_amd import synthetic as syn
+    monkeypatch.setenv("SAGEICP_LW", str(lw))
+    mp, q = random_scene(31 + lw)
+    a, b = both_maps(gpu_sage, oracle, mp)
+    for th, md in ((0.4, 6.0), (1.0, 2.0), (0.05, 0.9)):
+        _, tgt, idx = a.GetCorrespondences(q, md, th, with_index=True)
+        _, otgt, oidx = b.get_correspondences(q, md, th, with_index=True)
+        assert len(oidx) > 0 and np.array_equal(idx, oidx) and np.array_equal(tgt, otgt)
+    w, om = _workload(gpu_sage, oracle, "c2", 0.05)
+    p = syn.PARAMS["cold"]
+    pose, st = gpu_sage.register_frame(w["scan"], w["map"], gpu_sage.IDENTITY, p["max_dist"],
+                                       p["kernel"], p["sem_th"], return_stats=True)
+    opose, ost = om.register_frame(w["scan"], oracle.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"])
+    dt, dr = pose_error(oracle, opose, pose)
+    assert dt < 1e-7 and dr < 1e-7 and st.iterations == ost.iterations
+    assert st.n_corr_first == ost.n_corr_first and st.n_corr_last == ost.n_corr_last
+    assert st.sum_candidates == ost.sum_candidates_total
+    assert st.lanes_per_query == 1 << lw
+    assert st.compact_scan == (1 if scan_form == "compact" else 0)
 
 
 def test_wide_addressing_in_both_scan_forms(gpu_sage, oracle, scan_form, monkeypatch):
