@@ -57,7 +57,7 @@ def test_correspondences_index_exact(gpu_sage, oracle, seed, vs, basic, critical
     assert np.array_equal(tgt, otgt) and np.array_equal(src, osrc)
 
 
-@settings(max_examples=30, deadline=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=150, deadline=None, suppress_health_check=list(HealthCheck))
 @given(seed=st.integers(0, 2**31 - 1), vs=st.sampled_from([0.1, 0.3, 0.8, 1.0, 2.5]),
        th=st.sampled_from([0.05, 0.4, 1.0, 1.7]), md=st.sampled_from([0.2, 0.9, 2.0, 6.0]),
        basic=st.integers(0, 24), critical=st.integers(1, 24), span=st.sampled_from([1.5, 6.0, 20.0]),
@@ -536,6 +536,43 @@ def test_register_frame_with_initial_guess_and_edge_inputs(gpu_sage, oracle, sca
     far = np.array([[500.5, 0.5, 0.5, 1.0]])
     pose, st = gpu_sage.register_frame(far, a, gpu_sage.IDENTITY, 1.0, 0.3, 0.4, return_stats=True)
     assert st.iterations == 1 and st.n_corr_first == 0
+
+
+@settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+@given(seed=st.integers(0, 2**31 - 1), vs=st.sampled_from([0.3, 0.8, 1.0, 2.0]),
+       sigma=st.sampled_from([0.3, 1.0, 2.0]), th=st.sampled_from([0.05, 0.4, 1.0]),
+       lw=st.integers(0, 4), compact=st.booleans(), n_q=st.sampled_from([200, 3000, 12000]),
+       noise=st.sampled_from([0.0, 0.02]))
+def test_register_frame_property(gpu_sage, oracle, seed, vs, sigma, th, lw, compact, n_q, noise):
+    """RegisterFrame on random scenes (voxel size, thresholds as the adaptive sigma gives them:
+    max_corr 3 sigma, kernel sigma / 3; semantic threshold; frame size; a random planted motion and
+    a random initial guess near it; with and without noise) in every kernel variant: the same
+    iteration count, correspondence counts and pose as the oracle"""
+    old = {k: os.environ.get(k) for k in ("SAGEICP_LW", "SAGEICP_FILTER")}
+    os.environ["SAGEICP_LW"], os.environ["SAGEICP_FILTER"] = str(lw), "1" if compact else "0"
+    try:
+        rng = np.random.default_rng(seed)
+        mp, _ = random_scene(seed % 1000, n_map=30000, n_q=10, span=15.0)
+        a, b = both_maps(gpu_sage, oracle, mp, vs)
+        kept = a.Pointcloud()
+        T_gt = oracle.se3_exp(rng.normal(size=6) * np.array([0.2, 0.2, 0.05, 0.005, 0.005, 0.02]))
+        pick = kept[rng.choice(len(kept), min(n_q, len(kept)), replace=False)]
+        scan = oracle.transform_points(oracle.se3_inv(T_gt), pick)
+        scan[:, :3] += rng.normal(size=(len(scan), 3)) * noise
+        guess = oracle.se3_mul(T_gt, oracle.se3_exp(rng.normal(size=6) * np.array([0.05, 0.05, 0.02, 0.002, 0.002, 0.005])))
+        pose, s1 = gpu_sage.register_frame(scan, a, guess, 3.0 * sigma, sigma / 3.0, th, return_stats=True)
+        opose, s2 = b.register_frame(scan, guess, 3.0 * sigma, sigma / 3.0, th)
+        dt, dr = pose_error(oracle, opose, pose)
+        assert dt < 1e-7 and dr < 1e-7
+        assert s1.iterations == s2.iterations and s1.converged == s2.converged
+        assert s1.n_corr_first == s2.n_corr_first and s1.n_corr_last == s2.n_corr_last
+        assert s1.sum_candidates == s2.sum_candidates_total
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def test_streaming_frames_with_map_updates(gpu_sage, oracle, scan_form):
