@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c4", "c5"])
     ap.add_argument("--params", default=None, choices=["cold", "steady", "dense", "dense_nosem"],
-                    help="default: cold (c1, c2, c4), dense (c5)")
+                    help="default: cold (c1, c2), steady (c4: SURVEY 8d), dense (c5)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--independent", action="store_true",
@@ -71,6 +71,16 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def device_source_hash():
+    """sha256 over the sources whose build the profiler counters describe (profiles/collect.py)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("kernels.hip", "kernels.h", "sageicp_types.h", "capi.hip"):
+        with open(os.path.join(ROOT, "sage-icp_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def cpu_quota():
     """The container's CPU quota in cores (cgroup v2 cpu.max / v1 cfs quota), or None."""
     try:
@@ -86,8 +96,11 @@ def cpu_quota():
         return None
 
 
-def cpu_baseline(args, w, wl, prm, scan, iters, fps):
-    """The oracle (structure-faithful CPU port) on the same frame: reproducible protocol."""
+def cpu_baseline(args, w, wl, prm, scan, iters, fps, gpu_pose, gpu_stats):
+    """The oracle (structure-faithful CPU port) on the same frame: reproducible protocol.
+    Returns (cpu_baseline, parity): the second is the oracle's FULL registration of the frame the
+    timed region registered, compared with the pose and counts the timed region produced."""
+    import numpy as np
     import oracle                              # the checker / CPU port, timed as a baseline
     om = oracle.Map(wl["voxel"], 100.0)
     om.add_points(w["stream"])
@@ -124,20 +137,56 @@ def cpu_baseline(args, w, wl, prm, scan, iters, fps):
     reps.sort()
     per_iter = reps[2]
     cpu_fps = 1.0 / (per_iter * iters)
+    # parity of the headline workload itself: the oracle registers the whole frame once (every
+    # iteration, to convergence) and is compared with what the timed region returned
+    if per_iter * iters > 60.0:     # c4: minutes of oracle time; tests/test_gpu_parity.py covers it scaled
+        skipped = {"skipped": "the oracle needs ~%.0f s for this frame; parity of this workload is "
+                              "checked in tests/test_gpu_parity.py" % (per_iter * iters)}
+        return _cpu_dict(locals(), None), skipped
+    t = time.perf_counter()
+    opose, ofull = om.register_frame(scan, oracle.IDENTITY, prm["max_dist"], prm["kernel"], prm["sem_th"],
+                                     nthreads=threads)
+    t_full = time.perf_counter() - t
+    e = oracle.se3_log(oracle.se3_mul(oracle.se3_inv(opose), np.asarray(gpu_pose, dtype=np.float64)))
+    parity = {"against": "oracle (CPU restatement of the reference path; parity unpinned by the reference, "
+                         "DESIGN.md section 5), full registration of the frame of the timed region",
+              "pose_delta_m": float("%.3e" % np.linalg.norm(e[:3])),
+              "pose_delta_rad": float("%.3e" % np.linalg.norm(e[3:])),
+              "tolerance": {"m": 1e-4, "rad": 1e-4},
+              "iterations": [int(gpu_stats.iterations), int(ofull.iterations)],
+              "iterations_equal": bool(gpu_stats.iterations == ofull.iterations),
+              "n_corr_first_last": [[int(gpu_stats.n_corr_first), int(gpu_stats.n_corr_last)],
+                                    [int(ofull.n_corr_first), int(ofull.n_corr_last)]],
+              "n_corr_equal": bool(gpu_stats.n_corr_first == ofull.n_corr_first and
+                                   gpu_stats.n_corr_last == ofull.n_corr_last),
+              "candidates_equal": bool(gpu_stats.sum_candidates == ofull.sum_candidates_total),
+              "oracle_seconds": round(t_full, 2),
+              "ok": bool(np.linalg.norm(e[:3]) < 1e-4 and np.linalg.norm(e[3:]) < 1e-4 and
+                         gpu_stats.iterations == ofull.iterations)}
+    return _cpu_dict(locals(), 1.0 / t_full), parity
+
+
+def _cpu_dict(v, cpu_fps_full):
+    cpu_fps, reps, sweep, threads = v["cpu_fps"], v["reps"], v["sweep"], v["threads"]
+    args, iters, scan, ost = v["args"], v["iters"], v["scan"], v["ost"]
     return {"value": round(cpu_fps, 5), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": "median of 5 runs of the first %d of %d ICP iterations of the same %s frame "
                       "(%d queries) on %d OpenMP threads (OMP_PROC_BIND=close, OMP_PLACES=cores) after "
                       "a warm-up; per-iteration cost is constant, scaled to the %d iterations the "
-                      "frame takes" % (k, iters, args.workload, len(scan), threads, iters),
-            "seconds_per_iteration": round(per_iter, 5),
-            "seconds_per_iteration_runs": [round(v, 5) for v in reps],
-            "seconds_per_iteration_1_thread": round(t1, 4),
-            "frames_per_second_1_thread": round(1.0 / (t1 * iters), 6),
-            "threads_available": avail, "cpu_quota": cpu_quota(),
+                      "frame takes" % (v["k"], iters, args.workload, len(scan), threads, iters),
+            "seconds_per_iteration": round(v["per_iter"], 5),
+            "seconds_per_iteration_runs": [round(x, 5) for x in reps],
+            "seconds_per_iteration_1_thread": round(v["t1"], 4),
+            "frames_per_second_1_thread": round(1.0 / (v["t1"] * iters), 6),
+            "threads_available": v["avail"], "cpu_quota": cpu_quota(),
             "seconds_per_iteration_by_threads": {str(a): round(b, 5) for a, b in sorted(sweep.items())},
-            "sweep_vs_reported": round(sweep[threads] / per_iter, 3),
+            "sweep_vs_reported": round(sweep[threads] / v["per_iter"], 3),
             "candidates_per_query": round(ost.sum_candidates_total / max(ost.iterations, 1) / len(scan), 1),
-            "speedup_gpu_over_cpu": round(fps / cpu_fps, 1)}
+            "frames_per_second_whole_frame_once": None if cpu_fps_full is None else round(cpu_fps_full, 5),
+            "speedup_gpu_over_cpu": round(v["fps"] / cpu_fps, 1),
+            "speedup_note": "GPU frames/s / CPU frames/s, the CPU figure extrapolated from the sampled "
+                            "iterations to the frame's iteration count (frames_per_second_whole_frame_once: "
+                            "one un-sampled run of the whole frame, for comparison)"}
 
 
 def main():
@@ -201,7 +250,7 @@ def main():
 
     wl = syn.WORKLOADS[args.workload]
     if args.params is None:
-        args.params = "dense" if args.workload == "c5" else "cold"
+        args.params = {"c5": "dense", "c4": "steady"}.get(args.workload, "cold")
     prm = syn.PARAMS[args.params]
     t_gen = time.time()
     w = syn.make_workload(args.workload,
@@ -290,6 +339,7 @@ def main():
         exchange = RCCL_TEXT + " (" + why + ")"
 
     fence()          # every rank has its map and frame in HBM before the first exchange is waited for
+    cross_check = None
     if use_dist and use_p2p and have_rccl:
         # cross-check before trusting the direct exchange on this node: the same frame through
         # RCCL and through the mapped blocks must give the same pose (the summation order over
@@ -300,9 +350,12 @@ def main():
             comm.p2p_enable(True)
             pose_p2p, _ = step()
             same = bool(np.allclose(pose_rccl, pose_p2p, rtol=0.0, atol=1e-6))
+            cross_check = {"pose_rccl_vs_direct_max_abs": float("%.3e" % np.max(np.abs(pose_rccl - pose_p2p))),
+                           "same_within_1e-6": same}
         except sage.SageIcpError as e:
             sys.stderr.write("rank %d: exchange cross-check failed: %s\n" % (rank, e))
             same = False
+            cross_check = {"error": str(e), "same_within_1e-6": False}
         if not all_agree(same):
             fall_back("direct exchange failed its cross-check")
     ok = warm()
@@ -378,51 +431,75 @@ def main():
     roofline = None
     if launches:
         n_corr = 0.5 * (last.n_corr_first + last.n_corr_last) * n_local / max(len(scan), 1)
-        # SURVEY 8d, fused form: B_nn + B_gn - 8 N_q = 448 N_q + 16 sum C_q + 32 N_c
-        bytes_per_launch = 448.0 * n_local + 16.0 * cands / all_launches + 32.0 * n_corr
         avg_us = us_nn / launches
-        achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9       # GB/s
+        cand_per_launch = cands / all_launches
+        pairs_per_launch = pairs / all_launches
+        # Bytes the EXECUTED algorithm needs per launch, in SURVEY 8d's compact representation
+        # (fused form): 448 B per query (16 query + 27 x 16 hash slots) + 16 B per (query, map
+        # point) pair the search actually evaluates — counted by the kernel; the exact cell lower
+        # bound prunes the rest without loading them — + 32 B per accepted correspondence.
+        executed_bytes = 448.0 * n_local + 16.0 * pairs_per_launch + 32.0 * n_corr
+        achieved = executed_bytes / (avg_us * 1e-6) / 1e9          # GB/s
+        # SURVEY 8d's contractual figure charges EVERY candidate of the 27 voxels (what the
+        # reference's scan touches): an effective gather rate, not a bound on this kernel
+        survey_bytes = 448.0 * n_local + 16.0 * cand_per_launch + 32.0 * n_corr
+        compulsory = 16 * (vmap.size() + n_local + 4 * vmap.num_voxels())
         roofline = {"bound": "hbm", "kernel": "k_icp (correspondence search + Gauss-Newton sums)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "algorithmic_bytes_per_launch": round(bytes_per_launch),
+                    "algorithmic_bytes_per_launch": round(executed_bytes),
+                    "algorithmic_bytes_model": "448 B x queries + 16 B x (query, map point) pairs evaluated "
+                                               "(counted by the kernel) + 32 B x correspondences",
+                    "served_from": "mostly L2 / Infinity Cache (the 32-MB map and the 21 MB of per-query "
+                                   "streams fit the 256-MB Infinity Cache): see traffic / hbm_frac for "
+                                   "what crosses the L2s",
+                    "effective_gather_gbs": round(survey_bytes / (avg_us * 1e-6) / 1e9, 1),
+                    "effective_gather_bytes_per_launch": round(survey_bytes),
+                    "effective_gather_note": "SURVEY 8d's figure: every candidate of the 27 voxels charged "
+                                             "(what the reference scans); the kernel prunes most of them "
+                                             "exactly, so this rate is not bounded by the HBM peak",
                     # SURVEY 8d "compulsory" figure: every map point, query and hash slot once per
                     # launch in the compact representation (16 B each)
-                    "compulsory_bytes_per_launch": int(16 * (vmap.size() + n_local + 4 * vmap.num_voxels())),
-                    "compulsory_gbs": round(16 * (vmap.size() + n_local + 4 * vmap.num_voxels()) / (avg_us * 1e-6) / 1e9, 1),
+                    "compulsory_bytes_per_launch": int(compulsory),
+                    "compulsory_gbs": round(compulsory / (avg_us * 1e-6) / 1e9, 1),
                     "avg_launch_us": round(avg_us, 2), "launches_timed": launches,
                     "launches": all_launches, "queries_per_launch": n_local,
                     "lanes_per_query": last.lanes_per_query,
                     "scan_form": "compact 16-B records behind an exact fp32 filter" if last.compact_scan
                                  else "full 32-B fp64 records",
-                    "candidates_per_query": round(cands / all_launches / max(n_local, 1), 1),
+                    "candidates_per_query": round(cand_per_launch / max(n_local, 1), 1),
                     "pairs_evaluated_frac": round(pairs / max(cands, 1), 4),
-                    "note": "achieved = algorithmic bytes (SURVEY 8d fused form: 448 B/query + 16 B/"
-                            "candidate + 32 B/correspondence) / mean k_icp duration (HIP events on the "
-                            "launch stream, 1 launch in 8 of the timed region).  The kernel skips, by "
-                            "an exact cell lower bound, most of the candidates the byte model charges "
-                            "(pairs_evaluated_frac: the share it scans) and the map stays in L2 / "
-                            "Infinity Cache, so this is an effective rate that can exceed the HBM peak; "
-                            "what bounds the kernel is in hbm_frac (bytes from beyond the L2s / duration "
-                            "/ peak) / valu_frac / useful_inst_frac (rocprofv3 counters of the same "
-                            "command, profiles/)"}
+                    "timing": "mean k_icp duration from HIP events on the launch stream around 1 launch in 8 "
+                              "of the timed region (an event pair also brackets the launch gap: the "
+                              "rocprofv3 kernel-trace mean under profiles/ is ~3 us shorter)"}
+        # What bounds the kernel, from the rocprofv3 counter passes of this command
+        # (profiles/collect.py -> profiles/icp_counters.json).  They are measurements of a
+        # particular build: used only when the device code they were taken on is the code that ran.
         cpath = os.path.join(ROOT, "profiles", "icp_counters.json")
-        if os.path.exists(cpath) and args.workload == "c2" and world == 1 and args.scale == 1.0:
+        if os.path.exists(cpath) and world == 1 and args.scale == 1.0:
             try:
-                c = json.load(open(cpath))
-                roofline["traffic"] = c.get("hbm_bytes_per_launch")
-                if roofline["traffic"]:
-                    roofline["hbm_frac"] = round(roofline["traffic"] / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
-                for key in ("valu_frac", "useful_inst_frac", "lane_utilization", "counters_source"):
-                    if key in c:
-                        roofline[key] = c[key]
-            except Exception:
-                pass
+                c = json.load(open(cpath)).get("%s-%s" % (args.workload, args.params))
+                if c and c.get("source_sha256") != device_source_hash():
+                    roofline["counters"] = "stale: profiles/icp_counters.json was collected on another build " \
+                                           "of kernels.hip / capi.hip (re-run profiles/run_profiles.sh)"
+                elif c:
+                    roofline["counters"] = c.get("counters_source")
+                    roofline["traffic"] = c.get("hbm_bytes_per_launch")
+                    if roofline["traffic"]:
+                        # both from the profiled runs (bytes and duration of the same launches)
+                        roofline["hbm_frac"] = c.get("hbm_frac")
+                        roofline["traffic_over_algorithmic"] = round(roofline["traffic"] / executed_bytes, 3)
+                    for key in ("avg_launch_us_kernel_trace", "valu_frac", "useful_inst_frac",
+                                "lane_utilization", "l2_hit_rate"):
+                        if key in c:
+                            roofline[key] = c[key]
+            except Exception as e:      # noqa
+                roofline["counters"] = "unreadable: %s" % e
 
     fps = args.steps / elapsed * (world if args.independent else 1)
-    cpu = None
+    cpu = parity = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, w, wl, prm, scan, iters, fps)
+        cpu, parity = cpu_baseline(args, w, wl, prm, scan, iters, fps, pose, last)
 
     err = None
     try:
@@ -459,6 +536,13 @@ def main():
                                   else "query-sharded x%d, map replicated, %s" % (world, exchange)
                                   if use_dist else "single GPU",
                    "ranks": world,
+                   # what ran, without reading stderr: the exchange form of the timed region, the ranks
+                   # RCCL itself reports for the communicator (ncclCommCount; None: no communicator),
+                   # and the pose of one frame registered through both forms before the timed region
+                   "exchange": ("none" if comm is None else "direct" if use_p2p else "rccl"),
+                   "rccl_ranks": None if comm is None else comm.describe()["rccl_ranks"],
+                   "comm": None if comm is None else comm.describe(),
+                   "exchange_cross_check": cross_check,
                    "scan_points": len(scan), "map_points": vmap.size(),
                    "map_voxels": vmap.num_voxels(), "iterations_per_frame": iters,
                    "correspondences_first_last": [last.n_corr_first, last.n_corr_last],
@@ -466,6 +550,7 @@ def main():
                    "pose_error_vs_planted": err, "setup_seconds": round(t_gen, 1)},
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "parity": parity,
     }
     sys.stdout.flush()
     os.dup2(real_stdout, 1)

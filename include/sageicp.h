@@ -40,6 +40,14 @@ typedef struct sageicp_map sageicp_map;       /* opaque: host map + device mirro
 typedef struct sageicp_frame sageicp_frame;   /* opaque: a scan resident in HBM */
 typedef struct sageicp_comm sageicp_comm;     /* opaque: RCCL communicator for query sharding */
 
+/* Version of this header's ABI; sageicp_abi_version() returns the library's.  A binding must refuse
+ * a library whose version differs (the header shim and the Python loader do): struct layouts
+ * below are part of it.   2: sageicp_stats without the three fields that had become constant
+ * zeros (us_group, us_gn, resorts), with pairs_evaluated / lanes_per_query / compact_scan;
+ * capacity limits 2^24 voxels / 2^31 point slots / |voxel index| < 2^20 (SAGEICP_ERR_CAPACITY);
+ * sageicp_comm_describe, sageicp_map_pointcloud served from the HBM copy. */
+#define SAGEICP_ABI_VERSION 2
+
 /* Filled by sageicp_register_frame*.  Times are microseconds. */
 typedef struct sageicp_stats {
     int32_t iterations;         /* ICP iterations executed (<= 500, Registration.cpp:96) */
@@ -52,12 +60,10 @@ typedef struct sageicp_stats {
     double us_upload;           /* frame H2D + lazy map-mirror refresh inside the call */
     /* device time per kernel summed over the executed iterations (HIP events on the launch
      * stream); filled only when profiling is enabled with sageicp_set_profiling(). */
-    double us_group;            /* always 0 */
     double us_nn;               /* k_icp: pose apply + correspondence search + Gauss-Newton sums */
-    double us_gn;               /* always 0 (the accumulation is part of k_icp) */
     double us_fin;              /* k_fin: reduction of the partials, solve, pose update */
     uint32_t nn_launches;       /* k_icp launches that were timed (us_nn / nn_launches = mean duration) */
-    uint32_t resorts;           /* always 0 (the frame is ordered once per call) */
+    uint32_t reserved0;
     uint64_t sum_candidates;    /* sum over iterations and queries of C_q: map points stored in the
                                  * <=27 existing neighbour voxels of each query (this rank) */
     uint32_t n_corr_hist[64];   /* accepted correspondences of the first 64 iterations */
@@ -113,8 +119,13 @@ int sageicp_map_update_pose(sageicp_map *map, const double *xyzl, uint64_t n,
 int sageicp_map_update_pose_device(sageicp_map *map, const double *xyzl, uint64_t n,
                                    const double pose[7]);
 /* Pointcloud(), VoxelHashMap.cpp:132-142.  Returns the number of points the map holds; writes
- * at most `cap` of them. */
+ * at most `cap` of them (block-pool order; the reference's is its hash map's bucket order).  While
+ * the HBM copy is the authority (after a device-side update) the points are packed on the device
+ * and only they cross PCIe: the map stays resident, the next RegisterFrame uploads nothing. */
 uint64_t sageicp_map_pointcloud(const sageicp_map *map, double *out_xyzl, uint64_t cap);
+/* 1 while the HBM copy of the map is the authority (device-side updates; Pointcloud() and
+ * RegisterFrame keep it so), 0 while the host copy is (AddPoints / Update on the host, Clear). */
+int sageicp_map_resident(const sageicp_map *map);
 /* Push pending host-side changes to the HBM mirror now (otherwise done lazily by the next
  * search).  Lets a caller keep the refresh out of a timed region. */
 int sageicp_map_sync(const sageicp_map *map);
@@ -172,6 +183,20 @@ int sageicp_comm_p2p_export(sageicp_comm *comm, uint8_t handle_out[SAGEICP_P2P_H
 int sageicp_comm_p2p_connect(sageicp_comm *comm, const uint8_t *handles /* nranks x 64 B */);
 int sageicp_comm_p2p_enable(sageicp_comm *comm, int on);   /* fall back to RCCL with on = 0 */
 int sageicp_comm_p2p_enabled(const sageicp_comm *comm);
+/* What a communicator is made of, for logs and the bench line: the ranks as given at creation,
+ * the ranks RCCL itself reports (ncclCommCount / ncclCommUserRank; -1 without an RCCL side), and the
+ * state of the direct exchange. */
+typedef struct sageicp_comm_info {
+    int32_t rank, nranks, device;
+    int32_t has_rccl;        /* 1: created by sageicp_comm_create (an ncclComm_t exists) */
+    int32_t rccl_ranks;      /* ncclCommCount, -1: no RCCL side */
+    int32_t rccl_rank;       /* ncclCommUserRank, -1: no RCCL side */
+    int32_t p2p_connected;   /* every peer's exchange block is mapped */
+    int32_t p2p_enabled;     /* the next registration uses the direct exchange */
+    int32_t p2p_poisoned;    /* an exchange timed out: the blocks must not be used again */
+    int32_t reserved[7];
+} sageicp_comm_info;
+int sageicp_comm_describe(const sageicp_comm *comm, sageicp_comm_info *out);
 
 /* ---- Preprocess / VoxelDownsample (core/Preprocessing.hpp:33-45) on the device ------------------
  * sageicp_preprocess: core/Preprocessing.cpp:173-187 (dynamic_vehicle_filter == false): keep points

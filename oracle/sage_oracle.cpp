@@ -69,6 +69,22 @@
 
 #ifdef _OPENMP
 #include <omp.h>
+
+// Association of the three-term sum behind every Vector3d squaredNorm() / norm() of the path
+// (VoxelHashMap.cpp:87,111,178; Registration.cpp:79).  Which one Eigen 3.4's unrolled reduction
+// takes cannot be checked here (Eigen is not in this image); the nearest-neighbour decision is a
+// strict `<` on such sums, so the choice matters for exact near-ties only.  The same switch, with
+// the same name and meaning, selects it in the product (sage-icp_amd/csrc/sageicp_types.h); build
+// both with SAGE_SQNORM3_ORDER=1 in the environment to take the other order.
+//   0 (default)  x^2 + (y^2 + z^2)        1  (x^2 + y^2) + z^2
+#ifndef SAGE_SQNORM3_ORDER
+#define SAGE_SQNORM3_ORDER 0
+#endif
+#if SAGE_SQNORM3_ORDER == 0
+#define SAGE_SQNORM3(xx, yy, zz) ((xx) + ((yy) + (zz)))
+#else
+#define SAGE_SQNORM3(xx, yy, zz) (((xx) + (yy)) + (zz))
+#endif
 #endif
 
 namespace {
@@ -477,8 +493,8 @@ inline bool closest_neighbor(const Map &m, const Vec4 &point, double th, Vec4 &o
     double closest_distance2 = std::numeric_limits<double>::max();
     for (const auto &nb : neighboors) {
         const double dx = nb[0] - point[0], dy = nb[1] - point[1], dz = nb[2] - point[2];
-        // Eigen's unrolled 3-vector reduction: x^2 + (y^2 + z^2)
-        double distance = dx * dx + (dy * dy + dz * dz);
+        // (v3neighbor - v3point).squaredNorm(): the order of Eigen's 3-term reduction is a build switch
+        double distance = SAGE_SQNORM3(dx * dx, dy * dy, dz * dz);
         if (static_cast<int>(nb[3]) == static_cast<int>(point[3]) ||
             static_cast<int>(nb[3] * point[3]) == 0)
             distance = distance * th;
@@ -579,7 +595,7 @@ void sgo_map_remove_far(void *h, const double origin[3]) {
     auto is_far = [&](const Voxel &v) {
         const Vec4 &pt = m.map.find(v)->second.points.front();
         const double dx = pt[0] - origin[0], dy = pt[1] - origin[1], dz = pt[2] - origin[2];
-        return dx * dx + (dy * dy + dz * dz) > max_distance2;
+        return SAGE_SQNORM3(dx * dx, dy * dy, dz * dz) > max_distance2;
     };
     if ((g_robin_order & 2) && m.track_order) {
         m.order.sweep_erase([&](const Voxel &v, size_t) { return is_far(v); },
@@ -657,7 +673,7 @@ int sgo_get_correspondences(const void *h, const double *q_xyzl, uint64_t n, dou
             cand += c;
             if (!found) continue;  // D1
             const double dx = nn[0] - point[0], dy = nn[1] - point[1], dz = nn[2] - point[2];
-            if (std::sqrt(dx * dx + (dy * dy + dz * dz)) < max_dist) {
+            if (std::sqrt(SAGE_SQNORM3(dx * dx, dy * dy, dz * dz)) < max_dist) {
                 src.emplace_back(point);
                 tgt.emplace_back(nn);
                 if (idx_out) idx_t[t].push_back(static_cast<int64_t>(i));
@@ -703,7 +719,7 @@ void sgo_align_clouds(const double *src, const double *tgt, uint64_t n, double t
             double J[3][6] = {{1, 0, 0, 0, s[2], -s[1]},
                               {0, 1, 0, -s[2], 0, s[0]},
                               {0, 0, 1, s[1], -s[0], 0}};
-            const double r2 = r[0] * r[0] + (r[1] * r[1] + r[2] * r[2]);
+            const double r2 = SAGE_SQNORM3(r[0] * r[0], r[1] * r[1], r[2] * r[2]);
             const double w = (th * th) / ((th + r2) * (th + r2));
             for (int a = 0; a < 6; ++a) {
                 for (int b = 0; b < 6; ++b) {

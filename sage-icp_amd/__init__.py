@@ -20,13 +20,17 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsageicp_hip.so")
+# SAGE_SQNORM3_ORDER=1 in the environment loads the build with the other association of the 3-term
+# squared norms (csrc/sageicp_types.h): libsageicp_hip.n1.so, built by build.py next to the default
+SQNORM3_ORDER = 1 if os.environ.get("SAGE_SQNORM3_ORDER", "0") == "1" else 0
+LIB_PATH = os.path.join(_HERE, "libsageicp_hip.n1.so" if SQNORM3_ORDER else "libsageicp_hip.so")
 
 _dp = C.POINTER(C.c_double)
 _u64p = C.POINTER(C.c_uint64)
 _i64p = C.POINTER(C.c_int64)
 _u8p = C.POINTER(C.c_uint8)
 
+ABI_VERSION = 2          # SAGEICP_ABI_VERSION of include/sageicp.h
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_RCCL, ERR_CAPACITY = -1, -2, -3, -4, -5
 UNIQUE_ID_BYTES = 128
 P2P_HANDLE_BYTES = 64
@@ -50,18 +54,24 @@ class Stats(C.Structure):
         ("last_step_norm", C.c_double),
         ("us_wall", C.c_double),
         ("us_upload", C.c_double),
-        ("us_group", C.c_double),
         ("us_nn", C.c_double),
-        ("us_gn", C.c_double),
         ("us_fin", C.c_double),
         ("nn_launches", C.c_uint32),
-        ("resorts", C.c_uint32),
+        ("reserved0", C.c_uint32),
         ("sum_candidates", C.c_uint64),
         ("n_corr_hist", C.c_uint32 * 64),
         ("pairs_evaluated", C.c_uint64),
         ("lanes_per_query", C.c_uint32),
         ("compact_scan", C.c_uint32),
     ]
+
+
+class CommInfo(C.Structure):
+    """sageicp_comm_info"""
+    _fields_ = [("rank", C.c_int32), ("nranks", C.c_int32), ("device", C.c_int32),
+                ("has_rccl", C.c_int32), ("rccl_ranks", C.c_int32), ("rccl_rank", C.c_int32),
+                ("p2p_connected", C.c_int32), ("p2p_enabled", C.c_int32), ("p2p_poisoned", C.c_int32),
+                ("reserved", C.c_int32 * 7)]
 
 
 class PipelineConfig(C.Structure):
@@ -133,6 +143,7 @@ _SIGNATURES = [
     ("sageicp_map_update_pose", C.c_int, [C.c_void_p, _dp, C.c_uint64, _dp]),
     ("sageicp_map_update_pose_device", C.c_int, [C.c_void_p, _dp, C.c_uint64, _dp]),
     ("sageicp_map_pointcloud", C.c_uint64, [C.c_void_p, _dp, C.c_uint64]),
+    ("sageicp_map_resident", C.c_int, [C.c_void_p]),
     ("sageicp_map_sync", C.c_int, [C.c_void_p]),
     ("sageicp_get_correspondences", C.c_int,
      [C.c_void_p, _dp, C.c_uint64, C.c_double, C.c_double, _dp, _dp, _u64p, _i64p]),
@@ -153,6 +164,7 @@ _SIGNATURES = [
     ("sageicp_comm_p2p_connect", C.c_int, [C.c_void_p, C.POINTER(C.c_uint8)]),
     ("sageicp_comm_p2p_enable", C.c_int, [C.c_void_p, C.c_int]),
     ("sageicp_comm_p2p_enabled", C.c_int, [C.c_void_p]),
+    ("sageicp_comm_describe", C.c_int, [C.c_void_p, C.POINTER(CommInfo)]),
     ("sageicp_comm_destroy", None, [C.c_void_p]),
     ("sageicp_preprocess", C.c_int,
      [_dp, C.c_uint64, C.c_double, C.c_double, C.c_double, _dp, _u64p, C.c_int]),
@@ -187,6 +199,10 @@ def lib():
                 "%s is missing: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
         L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        L.sageicp_abi_version.restype = C.c_int
+        if L.sageicp_abi_version() != ABI_VERSION:      # struct layouts are part of the ABI
+            raise ImportError("%s speaks ABI version %d, this binding %d: rebuild it"
+                              % (LIB_PATH, L.sageicp_abi_version(), ABI_VERSION))
         for name, res, args in _SIGNATURES:
             fn = getattr(L, name)
             fn.restype = res
@@ -267,6 +283,13 @@ class Comm:
     @property
     def p2p_enabled(self):
         return bool(lib().sageicp_comm_p2p_enabled(self._h))
+
+    def describe(self):
+        """dict: the ranks as created, the ranks RCCL itself reports (-1 without an RCCL side), the
+        state of the direct exchange"""
+        info = CommInfo()
+        _check(lib().sageicp_comm_describe(self._h, C.byref(info)))
+        return {k: int(getattr(info, k)) for k, _ in CommInfo._fields_ if k != "reserved"}
 
     @staticmethod
     def unique_id():
@@ -365,6 +388,10 @@ class VoxelHashMap:
         out = np.empty((n, 4))
         lib().sageicp_map_pointcloud(self._h, out.ctypes.data_as(_dp), n)
         return out
+
+    def resident(self):
+        """True while the HBM copy of the map is the authority (after a device-side update)"""
+        return bool(lib().sageicp_map_resident(self._h))
 
     def sync(self):
         _check(lib().sageicp_map_sync(self._h))

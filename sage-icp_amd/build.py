@@ -1,4 +1,10 @@
-"""In-tree build of libsageicp_hip.so with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""In-tree build of libsageicp_hip.so with hipcc for gfx950 (cross-compiles without a GPU).
+
+Every .hip file is its own translation unit (no device code is called across files), so the
+objects are compiled in parallel, kept under build/ next to this file (git-ignored) and only
+redone when their source, a header or the flags changed; the link takes a second."""
+import concurrent.futures
+import hashlib
 import os
 import subprocess
 
@@ -8,11 +14,20 @@ SOURCES = ["csrc/kernels.hip", "csrc/sort.hip", "csrc/preprocess.hip", "csrc/map
 HEADERS = ["csrc/kernels.h", "csrc/sageicp_types.h", "csrc/se3_math.h", "csrc/host_map.hpp", "csrc/pipeline.hpp", "csrc/map_update.h", "csrc/metrics.hpp", "csrc/robin_order.hpp",
            "../include/sageicp.h"]
 OUT = os.path.join(HERE, "libsageicp_hip.so")
+OBJ_DIR = os.path.join(HERE, "build")
 
 # -ffp-contract=off: fp64 distances are the plain IEEE mul/add sequence the CPU evaluates, so the
 # device argmin is index-exact against the oracle (see kernels.hip header).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wall", "-Wextra"]
+
+
+def _stamp(extra):
+    h = hashlib.sha1(" ".join(FLAGS + list(extra)).encode())
+    for f in HEADERS:
+        with open(os.path.join(HERE, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def needs_build():
@@ -22,16 +37,50 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(HERE, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return OUT
+def build(force=False, verbose=False, out=OUT, defines=(), jobs=None):
+    """defines: extra -D flags (instrumented probe builds keep their objects apart)."""
+    if not force and out == OUT and not defines and not needs_build():
+        return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + [os.path.join(HERE, s) for s in SOURCES] + ["-o", OUT, "-ldl", "-lpthread"]
+    extra = ["-D" + d for d in defines]
+    tag = _stamp(extra)
+    odir = os.path.join(OBJ_DIR, tag)
+    os.makedirs(odir, exist_ok=True)
+
+    def compile_one(src):
+        path = os.path.join(HERE, src)
+        obj = os.path.join(odir, os.path.basename(src) + ".o")
+        if os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(path):
+            return obj
+        cmd = [hipcc] + FLAGS + extra + ["-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return obj
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=jobs or min(len(SOURCES), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out, "-ldl", "-lpthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return OUT
+    return out
+
+
+def build_sqnorm3_variant(force=False, verbose=False):
+    """libsageicp_hip.n1.so: the same library with SAGE_SQNORM3_ORDER=1 (sageicp_types.h) — the other
+    association of the 3-term squared norms; `SAGE_SQNORM3_ORDER=1 pytest tests` runs the suite on
+    it against the oracle built the same way."""
+    out = os.path.join(HERE, "libsageicp_hip.n1.so")
+    if not force and os.path.exists(out):
+        t = os.path.getmtime(out)
+        if not any(os.path.getmtime(os.path.join(HERE, f)) > t for f in SOURCES + HEADERS):
+            return out
+    return build(force=True, verbose=verbose, out=out, defines=("SAGE_SQNORM3_ORDER=1",))
 
 
 if __name__ == "__main__":
-    build(force=True, verbose=True)
+    import sys
+    defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
+    outs = [a for a in sys.argv[1:] if not a.startswith("-D")]
+    build(force=True, verbose=True, out=os.path.abspath(outs[0]) if outs else OUT, defines=defs)

@@ -518,6 +518,9 @@ struct sageicp_map {
     mutable MapCounters ctr{};
     mutable UpdateScratch up{};
     mutable size_t up_n = 0, up_nb = 0;
+    // Pointcloud() served from the HBM copy: the packed points before they cross PCIe
+    mutable Point4 *d_pc = nullptr;
+    mutable size_t d_pc_cap = 0;
     // Single-process multi-GPU mode (SAGEICP_DEVICES / sageicp_map_set_devices): one more complete
     // copy of the map per extra device.  Every mutation is applied to all of them, RegisterFrame
     // shards the frame over them (one host thread and one stream per device) and the ranks'
@@ -555,6 +558,8 @@ struct Rccl {
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
                               hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;        // optional: what RCCL itself reports
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
 };
 Rccl g_rccl;
 std::mutex g_rccl_mu;
@@ -582,6 +587,8 @@ int load_rccl() {
     g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(h, "ncclAllReduce"));
     g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    g_rccl.CommCount = reinterpret_cast<decltype(g_rccl.CommCount)>(dlsym(h, "ncclCommCount"));
+    g_rccl.CommUserRank = reinterpret_cast<decltype(g_rccl.CommUserRank)>(dlsym(h, "ncclCommUserRank"));
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce)
         return fail(SAGEICP_ERR_RCCL, "librccl lacks a required symbol");
     g_rccl.h = h;
@@ -1017,6 +1024,9 @@ IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, 
     ip.counters = nullptr;
     const uint64_t qw = 64u >> lw;
     ip.nwaves = static_cast<unsigned>((n + qw - 1) / qw);
+#ifdef SAGE_ICP_DELAY_PROBE
+    ip.dbg_delay = static_cast<unsigned>(env_int("SAGEICP_DBG_DELAY", 0));
+#endif
     return ip;
 }
 
@@ -1088,8 +1098,10 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         fp.p2p.rank = comm->rank;
         for (int r = 0; r < comm->nranks; ++r) fp.p2p.block[r] = comm->blocks[r];
         fp.p2p.exchanges = comm->d_exchanges;
+        // a peer's sums normally arrive within microseconds; one second of in-kernel waiting is
+        // already a failure (SAGEICP_P2P_TIMEOUT_S overrides, e.g. under a debugger)
         fp.p2p.timeout_ticks = 100000000ull * static_cast<unsigned long long>(
-                                   std::max(1, env_int("SAGEICP_P2P_TIMEOUT_S", 10)));
+                                   std::max(1, env_int("SAGEICP_P2P_TIMEOUT_S", 1)));
         if (const int ticks = env_int("SAGEICP_P2P_TIMEOUT_TICKS", 0))      // tests: provoke a timeout
             fp.p2p.timeout_ticks = static_cast<unsigned long long>(ticks);
     }
@@ -1204,7 +1216,6 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         stats->us_upload = us_upload;
         stats->us_nn = us_nn; stats->us_fin = us_fin;
         stats->nn_launches = nn_launches;
-        stats->resorts = 0;
         stats->sum_candidates = st.sum_candidates;
         stats->pairs_evaluated = st.sum_pairs;
         stats->lanes_per_query = 1u << lw;
@@ -1357,7 +1368,7 @@ int register_sharded(const sageicp_map *m, const double *h_frame, const Point4 *
 // =============================================================================================
 extern "C" {
 
-int sageicp_abi_version(void) { return 1; }
+int sageicp_abi_version(void) { return SAGEICP_ABI_VERSION; }
 const char *sageicp_last_error(void) { return g_err.c_str(); }
 int sageicp_device_count(void) {
     int c = 0;
@@ -1456,6 +1467,7 @@ void sageicp_map_destroy(sageicp_map *m) {
         for (void *q : aux)
             if (q) (void)hipFree(q);
         if (m->h_ctr) (void)hipHostFree(m->h_ctr);
+        if (m->d_pc) (void)hipFree(m->d_pc);
     }
     m->sc.destroy();
     delete m;
@@ -1592,11 +1604,47 @@ int sageicp_map_update_pose_device(sageicp_map *m, const double *xyzl, uint64_t 
     return device_update_all(m, xyzl, n, pose, nullptr);
 }
 
+// Pointcloud() while the HBM copy is the authority: packed on the device (block counts -> prefix
+// sum -> gather, block-pool order like the host's), only size() x 32 B cross PCIe, and the map
+// stays where it is — the node's per-frame LocalMap() (ros/ros2/OdometryServer.cpp:211-220 under
+// publish_frame, the launch files' default) costs the copy of the live points and nothing else:
+// no table rebuild, no re-upload before the next RegisterFrame.
+static int pointcloud_from_device(const sageicp_map *m, double *out, uint64_t cap, uint64_t *n_out) {
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t s = m->sc.stream;
+    const uint64_t total = m->ctr.total_points;
+    *n_out = total;
+    const uint64_t want = out ? std::min(cap, total) : 0;
+    if (!want) return SAGEICP_OK;
+    int rc = reserve_update_scratch(m, 0, static_cast<size_t>(m->ctr.blocks_hi) + 1);
+    if (rc) return rc;
+    if (total > m->d_pc_cap) {
+        if (m->d_pc) HIPCHK(hipFree(m->d_pc));
+        m->d_pc = nullptr; m->d_pc_cap = 0;
+        const size_t c = total + total / 4 + 1024;
+        HIPCHK(hipMalloc(&m->d_pc, c * sizeof(Point4)));
+        m->d_pc_cap = c;
+    }
+    const DevMap dm{m->d_table, static_cast<uint32_t>(m->d_table_cap - 1), m->d_pts, m->host.cap, m->d_zeros,
+                    m->d_slot_of, m->d_free, m->d_ctr};
+    HIPCHK(map_pointcloud_device(dm, m->ctr.blocks_hi, m->up.far_flag, m->up.far_sel, m->up.temp,
+                                 m->up.temp_bytes, m->d_pc, s));
+    HIPCHK(hipMemcpyAsync(out, m->d_pc, want * sizeof(Point4), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return SAGEICP_OK;
+}
+
 uint64_t sageicp_map_pointcloud(const sageicp_map *m, double *out, uint64_t cap) {
     if (!m) return 0;
-    if (ensure_host(m)) return 0;
+    if (m->on_device) {
+        uint64_t n = 0;
+        if (pointcloud_from_device(m, out, cap, &n)) return 0;
+        return n;
+    }
     return m->host.pointcloud(out, out ? cap : 0);
 }
+
+int sageicp_map_resident(const sageicp_map *m) { return (m && m->on_device) ? 1 : 0; }
 
 int sageicp_map_sync(const sageicp_map *m) {
     if (!m) return fail(SAGEICP_ERR_INVALID, "null map");
@@ -1653,7 +1701,7 @@ int sageicp_get_correspondences(const sageicp_map *m, const double *q, uint64_t 
         // acceptance on the unscaled distance: (nn - point).norm() < max (VoxelHashMap.cpp:111)
         const Point4 &t = m->host.pts[by_query[i]];
         const double dx = t.x - q[4 * i], dy = t.y - q[4 * i + 1], dz = t.z - q[4 * i + 2];
-        if (!(std::sqrt(dx * dx + (dy * dy + dz * dz)) < max_dist)) continue;
+        if (!(std::sqrt(SAGE_SQNORM3(dx * dx, dy * dy, dz * dz)) < max_dist)) continue;
         std::memcpy(src_out + 4 * k, q + 4 * i, 32);
         std::memcpy(tgt_out + 4 * k, &t, 32);
         if (query_idx_out) query_idx_out[k] = static_cast<int64_t>(i);
@@ -1912,6 +1960,29 @@ int sageicp_comm_p2p_enable(sageicp_comm *c, int on) {
 }
 
 int sageicp_comm_p2p_enabled(const sageicp_comm *c) { return c && c->p2p ? 1 : 0; }
+
+int sageicp_comm_describe(const sageicp_comm *c, sageicp_comm_info *out) {
+    if (!c || !out) return fail(SAGEICP_ERR_INVALID, "null argument");
+    std::memset(out, 0, sizeof(*out));
+    out->rank = c->rank;
+    out->nranks = c->nranks;
+    out->device = c->device;
+    out->rccl_ranks = out->rccl_rank = -1;
+    if (c->comm) {
+        out->has_rccl = 1;
+        int v = -1;
+        if (g_rccl.CommCount && g_rccl.CommCount(c->comm, &v) == ncclSuccess) out->rccl_ranks = v;
+        v = -1;
+        if (g_rccl.CommUserRank && g_rccl.CommUserRank(c->comm, &v) == ncclSuccess) out->rccl_rank = v;
+    }
+    out->p2p_connected = 1;
+    for (int r = 0; r < c->nranks && r < kMaxRanks; ++r)
+        if (!c->blocks[r]) out->p2p_connected = 0;
+    if (c->nranks > kMaxRanks) out->p2p_connected = 0;
+    out->p2p_enabled = c->p2p ? 1 : 0;
+    out->p2p_poisoned = c->poisoned ? 1 : 0;
+    return SAGEICP_OK;
+}
 
 void sageicp_comm_destroy(sageicp_comm *c) {
     if (!c) return;

@@ -63,6 +63,9 @@ struct IcpParams {
     double *partials;         // out: [gridDim.x][kNumSums] one partial per workgroup
     unsigned long long *counters;  // optional: [2 x waves] running sums of {C_q, pairs evaluated}
     unsigned nwaves;          // waves that own queries: ceil(n / (64 >> lw))
+#ifdef SAGE_ICP_DELAY_PROBE
+    unsigned dbg_delay;       // probe builds: ticks (100 MHz) a wave waits for "the pose" after its start
+#endif
 };
 
 #ifndef SAGE_ICP_WAVES

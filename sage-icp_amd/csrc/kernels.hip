@@ -53,7 +53,8 @@
 // hardware dispatch of many small workgroups in XCD-aware stripes of the spatially sorted frame.
 //
 // Built with -ffp-contract=off: distances are the plain IEEE sequence
-// dx*dx + (dy*dy + dz*dz) the CPU evaluates, so the argmin is index-exact against the oracle.
+// SAGE_SQNORM3(dx*dx, dy*dy, dz*dz) (sageicp_types.h) the CPU evaluates, so the argmin is
+// index-exact against the oracle.
 
 #include <hip/hip_runtime.h>
 
@@ -354,6 +355,9 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
     const unsigned long long tstart = tprev;
     const unsigned long long rstart = __builtin_amdgcn_s_memrealtime();
 #endif
+#ifdef SAGE_ICP_DELAY_PROBE
+    const unsigned long long probe_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int lane = static_cast<int>(threadIdx.x & 63u);
     const int wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     if (FUSED) {
@@ -408,6 +412,15 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
     if (NP > 4) pc4 = row_piece(4);
     if (NP > 5) pc5 = row_piece(5);
     if (NP > 6) pc6 = row_piece(6);
+#ifdef SAGE_ICP_DELAY_PROBE
+    // probe: the pose becomes available `dbg_delay` ticks (100 MHz) after this wave started, with
+    // the prologue loads above already in flight — what hiding k_fin under the prologue would cost
+    if (P.dbg_delay) {
+        __builtin_amdgcn_sched_barrier(0);
+        while (__builtin_amdgcn_s_memrealtime() - probe_t0 < P.dbg_delay) __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
     const Query s = make_query(f, P.st, P.apply_pose, P.voxel_size);
     const bool stale = valid && (static_cast<uint32_t>(s.kx) != rk.x || static_cast<uint32_t>(s.ky) != rk.y ||
                                  static_cast<uint32_t>(s.kz) != rk.z);
@@ -520,7 +533,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
     // candidate here (`on` false) turns its distance into a NaN, which loses every comparison.
     auto evaluate = [&](const Point4 &nb, bool on, unsigned key) {
         const double dx = nb.x - s.x, dy = nb.y - s.y, dz = nb.z - s.z;
-        double d = dx * dx + (dy * dy + dz * dz);
+        double d = SAGE_SQNORM3(dx * dx, dy * dy, dz * dz);
         // same label, or either side unlabelled (VoxelHashMap.cpp:87-88)
         // ((int)(a * b) == 0  <=>  |a * b| < 1 under truncation toward zero)
         const bool same = static_cast<int>(nb.l) == pli || fabs(nb.l * s.l) < 1.0;
@@ -583,7 +596,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
     };
     auto passes = [&](const uint4 &c, bool on) {
         const float dx = __uint_as_float(c.x) - qx, dy = __uint_as_float(c.y) - qy, dz = __uint_as_float(c.z) - qz;
-        const float d = dx * dx + (dy * dy + dz * dz);
+        const float d = SAGE_SQNORM3(dx * dx, dy * dy, dz * dz);
         const float lab = __uint_as_float(c.w);
         const bool same = (lab == plab) | (lab == 0.0f) | q_zero;
         return on & !(d > (same ? Ts : Td));
@@ -742,7 +755,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
         if (found && ci == 0u) {
             const Point4 g = load_point<BIG>(pts, P.pts, woff);
             const double rx = s.x - g.x, ry = s.y - g.y, rz = s.z - g.z;
-            const double r2 = rx * rx + (ry * ry + rz * rz);
+            const double r2 = SAGE_SQNORM3(rx * rx, ry * ry, rz * rz);
             // (closest_neighboor - point).norm() < max_correspondance_distance (VoxelHashMap.cpp:111)
             use = r2 <= P.accept_r2;
             if (use) {
@@ -1116,7 +1129,7 @@ __global__ __launch_bounds__(256) void k_gn(GnParams P) {
         const Point4 s = P.src[q], g = P.tgt[q];
         const double sx = s.x, sy = s.y, sz = s.z;
         const double rx = sx - g.x, ry = sy - g.y, rz = sz - g.z;
-        const double r2 = rx * rx + (ry * ry + rz * rz);
+        const double r2 = SAGE_SQNORM3(rx * rx, ry * ry, rz * rz);
         const double den = k + r2;
         const double w = k2 / (den * den);   // square(th) / square(th + residual2)
         const double wsx = w * sx, wsy = w * sy, wsz = w * sz;

@@ -70,6 +70,12 @@ size_t map_update_temp_bytes(int n, int nb);
 hipError_t map_update_device(const DevMap &M, const UpdatePolicy &P, const UpdateScratch &S, int n,
                              const double pose[7], uint32_t blocks_hi_bound, hipStream_t s);
 
+// Pointcloud() of the HBM copy: the live points of blocks [0, blocks_hi) packed into `out` in
+// block-pool order (what HostMap::pointcloud emits).  counts / offsets: [blocks_hi + 1] scratch;
+// offsets[blocks_hi] is the number of points written.
+hipError_t map_pointcloud_device(const DevMap &M, uint32_t blocks_hi, uint32_t *counts, uint32_t *offsets,
+                                 void *temp, size_t temp_bytes, Point4 *out, hipStream_t s);
+
 // Re-insert every live voxel into a fresh (larger or tombstone-free) table.
 hipError_t map_rebuild_table(const DevMap &M, Slot *new_table, uint32_t new_mask,
                              uint32_t blocks_hi_bound, hipStream_t s);

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_far_flags(DevMap M, UpdatePolicy P, dou
     if (!M.ctr->overflow && b < M.ctr->blocks_hi && M.slot_of[b] != kNoSlot) {
         const Point4 p = M.pts[static_cast<size_t>(b) * M.cap];
         const double dx = p.x - ox, dy = p.y - oy, dz = p.z - oz;
-        far = (dx * dx + (dy * dy + dz * dz) > P.max_dist2) ? 1u : 0u;
+        far = (SAGE_SQNORM3(dx * dx, dy * dy, dz * dz) > P.max_dist2) ? 1u : 0u;
     }
     far_flag[b] = far;
 }
@@ -252,6 +252,29 @@ __global__ __launch_bounds__(256) void k_rebuild(DevMap M, Slot *nt, uint32_t nm
     M.slot_of[b] = d;
 }
 
+// ---- Pointcloud() from the HBM copy (VoxelHashMap.cpp:132-142) --------------------------------
+// points held by block b (its voxel's slot word carries the count; a free block holds none)
+__global__ __launch_bounds__(256) void k_pc_counts(DevMap M, uint32_t blocks_hi, uint32_t *counts) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b > blocks_hi) return;
+    uint32_t c = 0;
+    if (b < blocks_hi) {
+        const uint32_t s = M.slot_of[b];
+        if (s != kNoSlot) c = M.table[s].blk & 255u;
+    }
+    counts[b] = c;                 // counts[blocks_hi] = 0: its scan entry is the total
+}
+// lane per point slot: the live points of block b land at offsets[b] in block-pool order, the
+// order HostMap::pointcloud emits (host_map.hpp)
+__global__ __launch_bounds__(256) void k_pc_gather(const Point4 *pts, uint32_t cap, uint64_t nslots,
+                                                   const uint32_t *counts, const uint32_t *offsets,
+                                                   Point4 *out) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= nslots) return;
+    const uint32_t b = static_cast<uint32_t>(i / cap), j = static_cast<uint32_t>(i % cap);
+    if (j < counts[b]) out[static_cast<size_t>(offsets[b]) + j] = pts[i];
+}
+
 __global__ void k_rebuild_after(MapCounters *ctr) {
     if (threadIdx.x || blockIdx.x) return;
     ctr->used_slots = ctr->num_voxels;
@@ -267,7 +290,9 @@ size_t map_update_temp_bytes(int n, int nb) {
     (void)rocprim::exclusive_scan(nullptr, b, v, v, 0u, static_cast<size_t>(n) + 1, rocprim::plus<uint32_t>());
     (void)rocprim::select(nullptr, c, rocprim::counting_iterator<uint32_t>(0), v, v, v,
                           static_cast<size_t>(nb));
-    return std::max(a, std::max(b, c)) + 256;
+    size_t d = 0;                  // map_pointcloud_device scans nb + 1 block counts
+    (void)rocprim::exclusive_scan(nullptr, d, v, v, 0u, static_cast<size_t>(nb) + 1, rocprim::plus<uint32_t>());
+    return std::max(std::max(a, d), std::max(b, c)) + 256;
 }
 
 hipError_t map_update_device(const DevMap &M, const UpdatePolicy &P, const UpdateScratch &S, int n,
@@ -312,6 +337,21 @@ hipError_t map_update_device(const DevMap &M, const UpdatePolicy &P, const Updat
         hipLaunchKernelGGL(k_far_apply, dim3(gb), dim3(256), 0, s, M, S.far_sel, S.n_sel, blocks_hi_bound);
         hipLaunchKernelGGL(k_far_after, dim3(1), dim3(64), 0, s, M.ctr, S.n_sel);
     }
+    return hipGetLastError();
+}
+
+hipError_t map_pointcloud_device(const DevMap &M, uint32_t blocks_hi, uint32_t *counts, uint32_t *offsets,
+                                 void *temp, size_t temp_bytes, Point4 *out, hipStream_t s) {
+    if (blocks_hi == 0) return hipSuccess;
+    const int gb = static_cast<int>((blocks_hi + 1u + 255u) / 256u);
+    hipLaunchKernelGGL(k_pc_counts, dim3(gb), dim3(256), 0, s, M, blocks_hi, counts);
+    size_t tb = temp_bytes;
+    hipError_t e = rocprim::exclusive_scan(temp, tb, counts, offsets, 0u, static_cast<size_t>(blocks_hi) + 1,
+                                           rocprim::plus<uint32_t>(), s);
+    if (e != hipSuccess) return e;
+    const uint64_t nslots = static_cast<uint64_t>(blocks_hi) * static_cast<uint64_t>(M.cap);
+    hipLaunchKernelGGL(k_pc_gather, dim3(static_cast<unsigned>((nslots + 255) / 256)), dim3(256), 0, s, M.pts,
+                       static_cast<uint32_t>(M.cap), nslots, counts, offsets, out);
     return hipGetLastError();
 }
 

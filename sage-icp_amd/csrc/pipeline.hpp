@@ -12,8 +12,10 @@
 //   core/Preprocessing.cpp:173-187 Preprocess, dynamic_vehicle_filter == false branch
 // Not reproduced: the PCL Euclidean-clustering "dynamic vehicle filter" (Preprocessing.cpp:95-172;
 // PCL is not available and every pre-labelled configuration runs with it off) and deskewing
-// (off in every launch file).  Order of the down-sampled points is insertion order per label
-// group; the reference emits tsl::robin_map bucket order (deviation D3 in DESIGN.md).
+// (off in every launch file).  The down-sampled clouds come from the backend in the reference's
+// emission order (the bucket order of its tsl::robin_map, Preprocessing.cpp:76-82, replayed by
+// csrc/robin_order.hpp) unless sageicp_set_downsample_order(0) selected arrival order per label
+// group.
 #pragma once
 
 #include <algorithm>

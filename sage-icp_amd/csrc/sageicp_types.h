@@ -11,6 +11,26 @@
 #define SAGE_HD
 #endif
 
+// Every squared norm of a 3-vector on the path — (v3neighbor - v3point).squaredNorm()
+// (VoxelHashMap.cpp:87), (closest - point).head<3>().norm() (:111), residual.squaredNorm()
+// (Registration.cpp:79), (pt - origin).squaredNorm() (VoxelHashMap.cpp:178) — is a three-term sum
+// whose association Eigen chooses, and the nearest-neighbour decision is a strict `<` on such
+// sums: 1 ulp decides exact near-ties.  Eigen cannot be compiled in this image, so which of the
+// two orders its unrolled reduction takes is not verified; ONE switch, shared in name and meaning
+// with the CPU checker the tests compare against, selects it for the whole path (the variant
+// libsageicp_hip.n1.so is built by build.py's build_sqnorm3_variant(); SAGE_SQNORM3_ORDER=1 in the
+// environment makes the loader and the test-suite use it):
+//   0 (default)  x^2 + (y^2 + z^2)
+//   1            (x^2 + y^2) + z^2
+#ifndef SAGE_SQNORM3_ORDER
+#define SAGE_SQNORM3_ORDER 0
+#endif
+#if SAGE_SQNORM3_ORDER == 0
+#define SAGE_SQNORM3(xx, yy, zz) ((xx) + ((yy) + (zz)))
+#else
+#define SAGE_SQNORM3(xx, yy, zz) (((xx) + (yy)) + (zz))
+#endif
+
 namespace sageicp {
 
 // One open-addressed hash slot, 16 B.  `blk` packs (block_index << 8) | point_count so a probe

@@ -113,6 +113,16 @@ struct VoxelHashMap {
     // HIP device ordinal for maps created by this process (one process per GPU); set it before
     // the first map is constructed, e.g. from LOCAL_RANK.
     static int &Device() {
+        // the library this process loaded must speak the ABI this header was written against
+        // (struct layouts are part of it): checked once, before the first map exists
+        static const bool abi_ok = [] {
+            if (sageicp_abi_version() != SAGEICP_ABI_VERSION)
+                throw std::runtime_error("libsageicp_hip.so speaks ABI version " +
+                                         std::to_string(sageicp_abi_version()) + ", the header shim " +
+                                         std::to_string(SAGEICP_ABI_VERSION));
+            return true;
+        }();
+        (void)abi_ok;
         static int device = 0;
         return device;
     }

@@ -24,12 +24,24 @@ def test_library_exports_every_declared_symbol(sage):
     for n in names:
         assert hasattr(L, n), "libsageicp_hip.so does not export %s" % n
     assert sorted(sage.EXPORTED_SYMBOLS) == names, "python binding and header disagree"
-    assert L.sageicp_abi_version() == 1
+    assert L.sageicp_abi_version() == sage.ABI_VERSION == 2
 
 
 def test_stats_struct_layout_matches_header(sage):
-    # 2*i32 + 3*u64 + 7*f64 + 2*u32 + u64 + 64*u32 + u64 + 2*u32
-    assert ctypes.sizeof(sage.Stats) == 8 + 24 + 56 + 8 + 8 + 256 + 8 + 8
+    # 2*i32 + 3*u64 + 5*f64 + 2*u32 + u64 + 64*u32 + u64 + 2*u32   (ABI version 2)
+    assert ctypes.sizeof(sage.Stats) == 8 + 24 + 40 + 8 + 8 + 256 + 8 + 8
+    # the struct the C compiler lays out from the header, field by field
+    import subprocess, tempfile
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "sageicp.h"\nint main(void){printf("%zu", sizeof(sageicp_stats));' + \
+          "".join('printf(" %%zu", offsetof(sageicp_stats, %s));' % f for f, _ in sage.Stats._fields_) + \
+          'printf(" %zu %d", sizeof(sageicp_comm_info), SAGEICP_ABI_VERSION);return 0;}'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        got = [int(x) for x in subprocess.check_output([os.path.join(d, "t")]).split()]
+    assert got[0] == ctypes.sizeof(sage.Stats)
+    assert got[1:-2] == [getattr(sage.Stats, f).offset for f, _ in sage.Stats._fields_]
+    assert got[-2] == ctypes.sizeof(sage.CommInfo) and got[-1] == sage.ABI_VERSION
 
 
 def test_no_oracle_in_product():

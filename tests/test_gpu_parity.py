@@ -624,6 +624,38 @@ def test_register_frame_through_rccl_comm_world1(gpu_sage, oracle):
     assert np.array_equal(ref, got)
 
 
+def test_chunked_rccl_loop_equals_polled_loop(gpu_sage, oracle, monkeypatch):
+    """the loop form every N > 1 RCCL run uses (fixed chunks of 4, 8, 16, ... iterations, one
+    synchronisation per chunk, every rank enqueuing the same number of all-reduces) against the
+    host-polled loop of one GPU: same bits, same iteration count — through a one-rank RCCL
+    communicator, and for the plain single-GPU call forced into chunks (SAGEICP_CHUNKED=1)"""
+    from sage_icp_amd import synthetic as syn
+    w, om = _workload(gpu_sage, oracle, "c2", 0.05)
+    f = gpu_sage.Frame(w["map"], w["scan"])
+    for prm in ("cold", "steady"):
+        p = syn.PARAMS[prm]
+        args = (f, w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"])
+        ref, rst = gpu_sage.register_frame(*args, return_stats=True)
+        comm = gpu_sage.Comm(gpu_sage.Comm.unique_id(), 0, 1, 0)
+        info = comm.describe()
+        assert info["has_rccl"] == 1 and info["rccl_ranks"] == 1 and info["rccl_rank"] == 0
+        assert info["p2p_enabled"] == 0 and info["nranks"] == 1
+        got, gst = gpu_sage.register_frame(*args, comm=comm, return_stats=True)     # chunked: RCCL
+        assert np.array_equal(ref, got) and gst.iterations == rst.iterations
+        assert gst.n_corr_last == rst.n_corr_last and gst.sum_candidates == rst.sum_candidates
+        monkeypatch.setenv("SAGEICP_CHUNKED", "1")
+        try:
+            again, ast_ = gpu_sage.register_frame(*args, return_stats=True)         # chunked: no comm
+            direct = gpu_sage.Comm(None, 0, 1, 0)
+            direct.p2p_connect([direct.p2p_export()])
+            d, dst = gpu_sage.register_frame(*args, comm=direct, return_stats=True)  # chunked: direct exchange
+        finally:
+            monkeypatch.delenv("SAGEICP_CHUNKED")
+        assert np.array_equal(ref, again) and ast_.iterations == rst.iterations
+        assert np.array_equal(ref, d) and dst.iterations == rst.iterations
+        assert direct.describe()["rccl_ranks"] == -1 and direct.describe()["p2p_enabled"] == 1
+
+
 def test_register_frame_through_direct_exchange_world1(gpu_sage, oracle):
     """the direct exchange path (reduce -> stores into the mapped blocks -> tags -> solve, all inside k_fin)
     with a one-rank communicator that has no RCCL side; the RCCL communicator can switch to it
@@ -776,15 +808,17 @@ def test_profiling_stats(gpu_sage, oracle):
 
 
 # ------------------------------------------------------------------ full-size properties
-def test_c2_full_size_properties(gpu_sage, oracle):
-    """BASELINE c2 at full size (120k scan vs 1M map): size-independent properties —
-    idempotence (re-registering from the answer is a fixed point), agreement of the accepted
-    correspondence count with the oracle's search at the converged pose, and shard additivity
-    (two half frames give the same normal equations as the whole)."""
+@pytest.mark.parametrize("params", ["cold", "steady"])
+def test_c2_full_size_properties(gpu_sage, oracle, params):
+    """BASELINE c2 at full size (120k scan vs 1M map) at both parameter points of SURVEY 8(d) —
+    `cold` is the workload bench.py times: size-independent properties (idempotence:
+    re-registering from the answer is a fixed point; index-exact correspondences against the
+    oracle's search at the converged pose; bit-reproducibility) and the oracle's full
+    registration of the same frame (same iteration and correspondence counts, pose within 1e-7)."""
     from sage_icp_amd import synthetic as syn
     w, om = _workload(gpu_sage, oracle, "c2", 1.0)
     assert w["map"].size() == 1_000_000 and len(w["scan"]) == 120_000
-    p = syn.PARAMS["steady"]
+    p = syn.PARAMS[params]
     pose, st = gpu_sage.register_frame(w["scan"], w["map"], gpu_sage.IDENTITY, p["max_dist"],
                                        p["kernel"], p["sem_th"], return_stats=True)
     assert st.converged == 1
@@ -804,7 +838,45 @@ def test_c2_full_size_properties(gpu_sage, oracle):
                                    p["sem_th"])
     dt, dr = pose_error(oracle, opose, pose)
     assert dt < TOL_M and dr < TOL_RAD and st.iterations == ost.iterations
+    assert dt < 1e-7 and dr < 1e-7
+    assert st.n_corr_first == ost.n_corr_first and st.n_corr_last == ost.n_corr_last
+    assert st.sum_candidates == ost.sum_candidates_total
     # nothing in the loop depends on when the host looks: the same call again gives the same bits
     again, st_again = gpu_sage.register_frame(w["scan"], w["map"], gpu_sage.IDENTITY, p["max_dist"],
                                               p["kernel"], p["sem_th"], return_stats=True)
     assert np.array_equal(again, pose) and st_again.iterations == st.iterations
+
+
+@pytest.mark.parametrize("params", ["dense", "dense_nosem"])
+def test_c5_full_size_properties(gpu_sage, oracle, params):
+    """BASELINE c5 at full size (200k-pt dense scan vs the 3M-pt-stream map at 0.1 m voxels, semantic
+    scaling on / off): convergence to the planted centimetre offset, idempotence,
+    bit-reproducibility, index-exact correspondences against the oracle's search at the converged
+    pose, and the oracle's full registration of the same frame (31 candidates per query: it takes
+    the oracle seconds)."""
+    from sage_icp_amd import synthetic as syn
+    w, om = _workload(gpu_sage, oracle, "c5", 1.0)
+    assert len(w["scan"]) == 200_000 and w["map"].num_voxels() > 1_000_000
+    p = syn.PARAMS[params]
+    f = gpu_sage.Frame(w["map"], w["scan"])
+    pose, st = gpu_sage.register_frame(f, w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"],
+                                       p["sem_th"], return_stats=True)
+    assert st.converged == 1 and 0 < st.n_corr_last < len(w["scan"])
+    gt, gr = pose_error(oracle, w["T_gt"], pose)
+    assert gt < 0.03 and gr < 1e-3
+    pose2, st2 = gpu_sage.register_frame(f, w["map"], pose, p["max_dist"], p["kernel"], p["sem_th"],
+                                         return_stats=True)
+    dt, dr = pose_error(oracle, pose, pose2)
+    assert st2.iterations <= 3 and dt < 2e-4 and dr < 2e-4
+    again, st3 = gpu_sage.register_frame(f, w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"],
+                                         p["sem_th"], return_stats=True)
+    assert np.array_equal(again, pose) and st3.iterations == st.iterations
+    q = oracle.transform_points(pose, w["scan"])
+    _, tgt, idx = w["map"].GetCorrespondences(q, p["max_dist"], p["sem_th"], with_index=True)
+    _, otgt, oidx = om.get_correspondences(q, p["max_dist"], p["sem_th"], with_index=True)
+    assert np.array_equal(idx, oidx) and np.array_equal(tgt, otgt)
+    opose, ost = om.register_frame(w["scan"], oracle.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"])
+    dt, dr = pose_error(oracle, opose, pose)
+    assert dt < 1e-7 and dr < 1e-7 and st.iterations == ost.iterations
+    assert st.n_corr_first == ost.n_corr_first and st.n_corr_last == ost.n_corr_last
+    assert st.sum_candidates == ost.sum_candidates_total

@@ -156,3 +156,37 @@ def test_device_update_property(gpu_sage, vs, basic, critical, md, n_pts, frames
         host.Update(p, pose)
         assert dev.size() == host.size() and dev.num_voxels() == host.num_voxels()
     assert np.array_equal(dev.Pointcloud(), host.Pointcloud())
+
+
+def test_pointcloud_of_a_resident_map_keeps_it_resident(gpu_sage, oracle):
+    """Pointcloud() while the HBM copy is the authority (the node's LocalMap() every frame,
+    OdometryServer.cpp:211-220): packed on the device in block-pool order — byte-identical to the
+    host map's — and the map stays where it is: no download of the blocks, no table rebuild, the
+    next RegisterFrame / Update find it resident and upload nothing"""
+    sage = gpu_sage
+    import ctypes as C
+    dev, host, _ = _maps(sage, oracle, 1.0, 40.0, 20, 20)
+    fr = _frames(31, 7, 15000, 25.0, 3.0)
+    scan, pose = fr[-1]
+    for k, (p, T) in enumerate(fr):
+        dev.UpdateOnDevice(p, T)
+        host.Update(p, T)
+        assert dev.resident() and not host.resident()
+        cloud = dev.Pointcloud()                       # every frame, like the node
+        assert dev.resident(), "Pointcloud() must not hand the authority back to the host"
+        assert np.array_equal(cloud, host.Pointcloud()), "frame %d" % k
+        Ta, sa = sage.register_frame(scan[:6000], dev, T, 3.0, 0.5, 0.4, return_stats=True)
+        Tb, sb = sage.register_frame(scan[:6000], host, T, 3.0, 0.5, 0.4, return_stats=True)
+        assert dev.resident() and np.array_equal(Ta, Tb) and sa.iterations == sb.iterations
+    # a short buffer takes the first `cap` points, the return value is the map's size
+    n = dev.size()
+    part = np.full((100, 4), -7.0)
+    got = sage.lib().sageicp_map_pointcloud(dev._h, part.ctypes.data_as(C.POINTER(C.c_double)), 100)
+    assert got == n and np.array_equal(part, host.Pointcloud()[:100])
+    assert sage.lib().sageicp_map_pointcloud(dev._h, None, 0) == n and dev.resident()
+    # host-side entries still move the authority (and Pointcloud() follows)
+    dev.AddPoints(scan[:50] + 1000.0)
+    host.AddPoints(scan[:50] + 1000.0)
+    assert not dev.resident() and np.array_equal(dev.Pointcloud(), host.Pointcloud())
+    dev.Clear()
+    assert dev.Pointcloud().shape == (0, 4)
