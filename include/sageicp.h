@@ -215,7 +215,12 @@ void sageicp_set_downsample_order(int reference_order);
 /* The replay itself (host code, no device needed): the iteration order of a tsl::robin_map v1.0.1
  * (core/Preprocessing.cpp:50,76-82: default-constructed, the reference's 20-bit VoxelHash) after the
  * n distinct voxels vox_xyz[3*i..] were inserted in this order; order_out[j] = insertion index of the
- * j-th entry met by the map's iterator. */
+ * j-th entry met by the map's iterator.
+ * Limits: n < 2^27; SAGEICP_ERR_CAPACITY when an insertion's probe distance reaches 128 — beyond its
+ * DIST_FROM_IDEAL_BUCKET_LIMIT tsl::robin_map forces a growth the replay does not model (with the
+ * reference's 20-bit hash: at the latest from ~2^19 voxels of one label group; street scenes stay
+ * below 40).  Inside sageicp_voxel_downsample / the pipeline such a group is emitted in arrival
+ * order and a warning goes to stderr once. */
 int sageicp_robin_iteration_order(const int32_t *vox_xyz, uint64_t n, uint32_t *order_out);
 int sageicp_preprocess(const double *frame_xyzl, uint64_t n, double max_range, double min_range,
                        double label_max_range, double *out_xyzl, uint64_t *n_out, int device);
@@ -261,9 +266,17 @@ int sageicp_pipeline_register_frame(sageicp_pipeline *p, const double *frame_xyz
  * (own stream, own host thread) under the ICP loop and the map update of the frame it was called
  * for, and the call that later registers the announced frame (same pointer, same n) takes the
  * prepared clouds instead of computing them.  Results are bit-identical with and without; a frame
- * that was announced but not registered next is dropped.  The buffer must stay valid and
- * unchanged until the call that registers it returns.  One frame ahead, no queue. */
+ * that was announced but not registered next is dropped.  One frame ahead, no queue.
+ * Lifetime: a helper thread reads the announced buffer from inside the NEXT
+ * sageicp_pipeline_register_frame() call on; it has finished when the register call after that one,
+ * sageicp_pipeline_prefetch_cancel() or sageicp_pipeline_destroy() returns — until then the buffer
+ * must stay valid and unchanged, also when the announced frame ends up not being registered.
+ * A frame is recognised by pointer, size AND a fingerprint of its content taken here: a buffer
+ * refilled with other data after the announcement is registered as the new frame it is. */
 int sageicp_pipeline_prefetch(sageicp_pipeline *p, const double *next_frame_xyzl, uint64_t n);
+/* Drop an announcement / a prepared frame and wait for the helper thread: afterwards nothing
+ * reads any announced buffer. */
+int sageicp_pipeline_prefetch_cancel(sageicp_pipeline *p);
 int sageicp_pipeline_reinitialize(sageicp_pipeline *p);          /* pipeline/sageICP.hpp:94-99 */
 uint64_t sageicp_pipeline_num_poses(const sageicp_pipeline *p);  /* poses().size() */
 int sageicp_pipeline_pose(const sageicp_pipeline *p, uint64_t index, double pose_out[7]);

@@ -176,6 +176,7 @@ _SIGNATURES = [
     ("sageicp_pipeline_register_frame", C.c_int,
      [C.c_void_p, _dp, C.c_uint64, _dp, _dp, _dp, _u64p, C.POINTER(Stats)]),
     ("sageicp_pipeline_prefetch", C.c_int, [C.c_void_p, _dp, C.c_uint64]),
+    ("sageicp_pipeline_prefetch_cancel", C.c_int, [C.c_void_p]),
     ("sageicp_pipeline_reinitialize", C.c_int, [C.c_void_p]),
     ("sageicp_pipeline_num_poses", C.c_uint64, [C.c_void_p]),
     ("sageicp_pipeline_pose", C.c_int, [C.c_void_p, C.c_uint64, _dp]),
@@ -231,7 +232,8 @@ def set_downsample_order(reference_order=True):
 
 
 def set_profiling(level):
-    """0 off; 1 (or True) HIP events around k_nn only; 2 around every kernel of the loop"""
+    """0 off; 1 (or True) HIP events around k_icp in one iteration out of 8 (what bench.py times
+    with); 2 around every kernel of every iteration"""
     lib().sageicp_set_profiling(int(level))
 
 
@@ -487,6 +489,11 @@ class SageICP:
         self._announced = (getattr(self, "_announced", ()) + ((pts, pp),))[-2:]
         _check(lib().sageicp_pipeline_prefetch(self._h, pp, pts.reshape(-1, 4).shape[0]))
         return pts
+
+    def prefetch_cancel(self):
+        """drop an announced / prepared frame and wait for the helper thread"""
+        _check(lib().sageicp_pipeline_prefetch_cancel(self._h))
+        self._announced = ()
 
     def reinitialize(self):
         _check(lib().sageicp_pipeline_reinitialize(self._h))

@@ -15,12 +15,16 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <cfloat>
 #include <limits>
+#include <memory>
 #include <cstring>
 #include <mutex>
 #include <array>
@@ -104,6 +108,7 @@ struct Scratch {
     uint2 *d_prev = nullptr;       // every query's record of the previous iteration (kernels.h)
     uint32_t *d_work = nullptr;    // instrumented builds: points handed to each query
     double *d_partials = nullptr; size_t partials_cap = 0;
+    double *d_partials2 = nullptr; size_t partials2_cap = 0;   // second stage of the reduction (k_red, big frames)
     unsigned long long *d_cand = nullptr;      // per-wave counters of k_icp [2 x sort_cap]
     IcpState *d_state = nullptr;
     IcpState *h_state = nullptr;   // pinned
@@ -192,6 +197,15 @@ struct Scratch {
         partials_cap = cap;
         return SAGEICP_OK;
     }
+    int reserve_partials2(size_t rows) {
+        if (rows <= partials2_cap) return SAGEICP_OK;
+        if (d_partials2) HIPCHK(hipFree(d_partials2));
+        d_partials2 = nullptr; partials2_cap = 0;
+        const size_t cap = rows + rows / 4 + 64;
+        HIPCHK(hipMalloc(&d_partials2, cap * kNumSums * sizeof(double)));
+        partials2_cap = cap;
+        return SAGEICP_OK;
+    }
     int reserve_events(size_t iterations) {
         while (events.size() < 5 * iterations) {
             hipEvent_t e;
@@ -217,6 +231,7 @@ struct Scratch {
         if (d_prev) (void)hipFree(d_prev);
         if (d_work) (void)hipFree(d_work);
         if (d_partials) (void)hipFree(d_partials);
+        if (d_partials2) (void)hipFree(d_partials2);
         if (d_state) (void)hipFree(d_state);
         if (d_cand) (void)hipFree(d_cand);
         if (h_state) (void)hipHostFree(h_state);
@@ -226,6 +241,74 @@ struct Scratch {
     }
 };
 
+
+// A few parked host threads for the order replays of one Prep (one per label group at most): a
+// replay of a few thousand keys costs no more than starting a thread does, and the replays of a
+// level are the critical path of a streamed frame.  run(count, f) executes f(0..count-1), each index
+// once, on the workers and the calling thread; indices are handed out in order (largest job first
+// if the caller sorted them so).
+class ReplayPool {
+public:
+    ~ReplayPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    void run(size_t count, const std::function<void(size_t)> &f, size_t want_threads) {
+        if (count <= 1 || want_threads <= 1) {
+            for (size_t i = 0; i < count; ++i) f(i);
+            return;
+        }
+        while (th_.size() + 1 < std::min(want_threads, count)) th_.emplace_back([this] { worker(); });
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            job_ = &f;
+            total_ = count;
+            next_.store(0, std::memory_order_relaxed);
+            pending_ = count;
+            ++epoch_;
+        }
+        cv_.notify_all();
+        drain();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+
+private:
+    void drain() {
+        for (;;) {
+            const size_t i = next_.fetch_add(1, std::memory_order_relaxed);
+            if (i >= total_) return;
+            (*job_)(i);
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+    void worker() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || (epoch_ != seen && job_); });
+                if (stop_) return;
+                seen = epoch_;
+            }
+            drain();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(size_t)> *job_ = nullptr;
+    size_t total_ = 0, pending_ = 0;
+    std::atomic<size_t> next_{0};
+    uint64_t epoch_ = 0;
+    bool stop_ = false;
+};
 
 // ---- device preprocessing (preprocess.hip): buffers of one pipeline ------------------------------
 struct Prep {
@@ -244,7 +327,12 @@ struct Prep {
     uint32_t *h_perm = nullptr;              // pinned
     std::vector<uint32_t> h_hash;
     RobinScratch rscratch[8];                // bucket arrays of the order replay, one pair per label group
+    std::unique_ptr<ReplayPool> pool;        // parked helper threads of the order replays
     double us_order = 0;                // host time of the last run's order replays
+    // levels whose survivors are emitted in arrival order even under g_reference_order (bit l): the
+    // pipeline's second level — its cloud is only registered, and registration sorts its frame
+    // spatially first, so its emission order reaches nothing but the order of fp64 summation
+    unsigned arrival_order_levels = 0;
     uint32_t *d_nkept = nullptr;        // [2]
     int *d_overflow = nullptr;
     int *d_gcounts = nullptr, *d_glabels = nullptr;
@@ -377,7 +465,7 @@ struct Prep {
             P.keys = d_keys; P.winner = d_winner; P.mask = table_cap - 1;
             P.tmp = d_tmp; P.slot_of = d_slot; P.sort_key = d_skey; P.sort_val = d_sval;
             P.overflow = d_overflow;
-            const bool reorder = g_reference_order && P.n_groups > 0;
+            const bool reorder = g_reference_order && P.n_groups > 0 && !((arrival_order_levels >> l) & 1u);
             P.out_keys = reorder ? d_okeys : nullptr;
             Point4 *dst = outs[l & 1];
             HIPCHK(voxel_downsample_device(P, d_sort_temp, sort_bytes, d_nkept + (l & 1), dst, stream));
@@ -419,32 +507,34 @@ struct Prep {
                     }
                     std::vector<uint32_t> part;
                     part.reserve(b - a);
-                    RobinOrderReplay::iteration_order(h_hash.data() + a, b - a, a, part, &rscratch[r & 7]);
+                    if (!RobinOrderReplay::iteration_order(h_hash.data() + a, b - a, a, part, &rscratch[r & 7])) {
+                        // a probe distance the replay does not model (robin_order.hpp): this group keeps
+                        // its arrival order — said once, loudly, because the poses of a stream then
+                        // differ from the reference's by centimetres
+                        static std::atomic<bool> told{false};
+                        if (!told.exchange(true))
+                            std::fprintf(stderr, "sageicp: VoxelDownsample: a label group of %u voxels exceeds the probe "
+                                                 "distance the tsl::robin_map replay models; it is emitted in arrival order\n",
+                                         b - a);
+                        part.resize(b - a);
+                        for (uint32_t i = a; i < b; ++i) part[i - a] = i;
+                    }
                     std::memcpy(h_perm + a, part.data(), (b - a) * sizeof(uint32_t));
                 };
-                // The largest group (half of the survivors on street scenes) is the critical path: the
-                // calling thread takes it at once, at most two helpers share the others (largest
-                // first, each to the less loaded helper) — starting a thread costs tens of
-                // microseconds, a run of a few thousand keys no more than that.
+                // The groups' replays are independent and the largest (half of the survivors on street
+                // scenes) is the critical path: every group gets its own thread — parked helpers of
+                // this Prep, woken per level (starting threads costs what a small replay does) —
+                // largest first, the calling thread takes part.
                 std::vector<size_t> by_size(runs.size());
                 for (size_t r = 0; r < runs.size(); ++r) by_size[r] = r;
                 std::sort(by_size.begin(), by_size.end(), [&](size_t x, size_t y) {
                     return runs[x].second - runs[x].first > runs[y].second - runs[y].first;
                 });
-                if (kept > 16384 && runs.size() > 1) {
-                    std::vector<size_t> share[2];
-                    size_t load[2] = {0, 0};
-                    for (size_t k = 1; k < by_size.size(); ++k) {
-                        const size_t w = load[1] < load[0] ? 1 : 0;
-                        share[w].push_back(by_size[k]);
-                        load[w] += runs[by_size[k]].second - runs[by_size[k]].first;
-                    }
-                    std::vector<std::thread> th;
-                    for (int w = 0; w < 2; ++w)
-                        if (!share[w].empty())
-                            th.emplace_back([&, w] { for (size_t r : share[w]) replay(r); });
-                    replay(by_size[0]);
-                    for (auto &t : th) t.join();
+                if (kept > 8192 && runs.size() > 1) {
+                    if (!pool) pool.reset(new ReplayPool);
+                    const size_t hw = std::max(1u, std::thread::hardware_concurrency());
+                    pool->run(runs.size(), [&](size_t k) { replay(by_size[k]); },
+                              std::min<size_t>(hw, static_cast<size_t>(std::max(1, env_int("SAGEICP_REPLAY_THREADS", 8)))));
                 } else {
                     for (size_t r = 0; r < runs.size(); ++r) replay(r);
                 }
@@ -527,6 +617,10 @@ struct sageicp_map {
     // Gauss-Newton sums meet in peer-mapped exchange blocks.  `this` is rank 0.
     std::vector<sageicp_map *> replicas;
     mutable std::vector<struct sageicp_comm *> ranks;   // created at the first sharded registration
+    // a mutation reached some copies of the map but not all (a device ran out of memory, ...): the
+    // ranks would sum Gauss-Newton terms computed against different maps, so every later entry
+    // refuses the handle until Clear() has emptied all copies
+    bool replicas_diverged = false;
 };
 
 struct sageicp_frame {
@@ -1087,10 +1181,14 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         HIPCHK(hipMemsetAsync(sc.d_prev, 0xFF, n * sizeof(uint2), s));     // no previous answers yet
     }
 
+    // big frames: k_red folds the workgroup partials into a few rows first (kernels.h)
+    const int red_rows = n ? red_rows_for(blocks) : 0;
+    if (red_rows && (rc = sc.reserve_partials2(static_cast<size_t>(red_rows)))) return rc;
+    RedParams rp{sc.d_partials, blocks, sc.d_partials2, &sc.d_state->done};
     FinParams fp{};
     fp.st = sc.d_state;
-    fp.partials = sc.d_partials;
-    fp.nparts = n ? blocks : 0;
+    fp.partials = red_rows ? sc.d_partials2 : sc.d_partials;
+    fp.nparts = n ? (red_rows ? red_rows : blocks) : 0;
     fp.mode = p2p ? 3 : (comm ? 1 : 0);
     fp.standalone = 0;
     if (p2p) {
@@ -1118,6 +1216,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         if (ev) HIPCHK(hipEventRecord(sc.events[5 * slot + 1], s));
         launch_icp(ip, lw, true, s);
         if (ev) HIPCHK(hipEventRecord(sc.events[5 * slot + 2], s));
+        if (red_rows) launch_red(rp, s);
         launch_fin(fp, s);
         if (comm && !p2p) {     // k_fin left the local sums in state->sums
             ncclResult_t r = g_rccl.AllReduce(sc.d_state->sums, sc.d_state->sums, kNumSums,
@@ -1231,8 +1330,10 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
 // Update(points, pose) on every copy of the map.  `d_points` (optional) lives on rank 0's device.
 int device_update_all(sageicp_map *m, const double *xyzl, uint64_t n, const double pose[7],
                       const Point4 *d_points) {
+    if (m->replicas_diverged)
+        return fail(SAGEICP_ERR_INVALID, "the copies of this multi-device map diverged in an earlier failed update: Clear() it");
     int rc = device_update(m, xyzl, n, pose, d_points);
-    if (rc || m->replicas.empty()) return rc;
+    if (rc || m->replicas.empty()) return rc;       // (a failed device update changes nothing on its device)
     std::vector<double> host;
     if (d_points) {                               // the other devices take the points from the host
         host.resize(4 * n);
@@ -1241,7 +1342,11 @@ int device_update_all(sageicp_map *m, const double *xyzl, uint64_t n, const doub
         xyzl = host.data();
     }
     for (sageicp_map *r : m->replicas)
-        if ((rc = device_update(r, xyzl, n, pose))) return rc;
+        if ((rc = device_update(r, xyzl, n, pose))) {
+            m->replicas_diverged = true;            // rank 0 (and maybe others) took the update, this copy did not
+            const std::string why = g_err;
+            return fail(rc, "update reached only some devices of the map (" + why + "); the map must be cleared");
+        }
     return SAGEICP_OK;
 }
 
@@ -1306,6 +1411,8 @@ int create_ranks(const sageicp_map *m) {
 int register_sharded(const sageicp_map *m, const double *h_frame, const Point4 *d_frame, uint64_t n,
                      const double init[7], double max_dist, double kernel, double sem_th,
                      double pose_out[7], sageicp_stats *stats, double t0) {
+    if (m->replicas_diverged)
+        return fail(SAGEICP_ERR_INVALID, "the copies of this multi-device map diverged in an earlier failed update: Clear() it");
     int rc = create_ranks(m);
     if (rc) return rc;
     const int N = 1 + static_cast<int>(m->replicas.size());
@@ -1317,16 +1424,28 @@ int register_sharded(const sageicp_map *m, const double *h_frame, const Point4 *
     std::vector<std::string> errors(N);
     std::vector<std::array<double, 7>> poses(N);
     std::vector<sageicp_stats> st(N);
+    // Everything that can fail before the loop (mirror refresh, buffers, the copy of the shard) is
+    // done by every rank first; the ranks meet, and enter the loop only if all of them are ready —
+    // a rank that failed alone would leave the others waiting in k_fin for sums that never come.
+    std::mutex gate_mu;
+    std::condition_variable gate_cv;
+    int gate_arrived = 0;
+    bool gate_ok = true;
     auto work = [&](int k) {
         const sageicp_map *mk = maps[k];
         const uint64_t lo = std::min<uint64_t>(n, k * per), cnt = std::min<uint64_t>(n, lo + per) - lo;
-        auto body = [&]() -> int {
+        const Point4 *mine = nullptr;
+        auto setup = [&]() -> int {
             HIPCHK(hipSetDevice(mk->device));
             int r = sync_mirror(mk);
             if (r) return r;
             Scratch &sc = mk->sc;
             if ((r = sc.reserve_frame(cnt))) return r;
-            const Point4 *mine = sc.d_frame;
+            const int lw = icp_lw(cnt, sparse_voxels(mk));
+            if ((r = ensure_cand(mk))) return r;
+            if ((r = sc.reserve_sort(cnt))) return r;
+            if ((r = sc.reserve_partials(static_cast<size_t>(cnt ? icp_blocks_for(static_cast<int>(cnt), lw) : 1)))) return r;
+            mine = sc.d_frame;
             if (cnt) {
                 if (h_frame)
                     HIPCHK(hipMemcpyAsync(sc.d_frame, h_frame + 4 * lo, cnt * sizeof(Point4),
@@ -1336,18 +1455,37 @@ int register_sharded(const sageicp_map *m, const double *h_frame, const Point4 *
                 else
                     HIPCHK(hipMemcpyPeerAsync(sc.d_frame, mk->device, d_frame + lo, m->device,
                                               cnt * sizeof(Point4), sc.stream));
+                HIPCHK(hipStreamSynchronize(sc.stream));     // the shard has arrived (or the copy failed: here, not in the loop)
             }
-            return run_icp(mk, mine, cnt, init, max_dist, kernel, sem_th, m->ranks[k], poses[k].data(),
-                           &st[k], now_us() - t0, t0);
+            return SAGEICP_OK;
         };
-        codes[k] = body();
+        codes[k] = setup();
         if (codes[k]) errors[k] = g_err;          // g_err is per thread
+        {
+            std::unique_lock<std::mutex> lk(gate_mu);
+            if (codes[k]) gate_ok = false;
+            if (++gate_arrived == N) gate_cv.notify_all();
+            else gate_cv.wait(lk, [&] { return gate_arrived == N; });
+            if (!gate_ok) {
+                if (!codes[k]) {
+                    codes[k] = SAGEICP_ERR_HIP;
+                    errors[k] = "not started: another device rank failed its set-up";
+                }
+                return;
+            }
+        }
+        codes[k] = run_icp(mk, mine, cnt, init, max_dist, kernel, sem_th, m->ranks[k], poses[k].data(),
+                           &st[k], now_us() - t0, t0);
+        if (codes[k]) errors[k] = g_err;
     };
     std::vector<std::thread> th;
     for (int k = 1; k < N; ++k) th.emplace_back(work, k);
     work(0);
     for (auto &t : th) t.join();
     (void)hipSetDevice(m->device);
+    for (int k = 0; k < N; ++k)        // the rank that failed on its own first, then the ones it stopped
+        if (codes[k] && errors[k].rfind("not started", 0) != 0)
+            return fail(codes[k], "device rank " + std::to_string(k) + ": " + errors[k]);
     for (int k = 0; k < N; ++k)
         if (codes[k]) return fail(codes[k], "device rank " + std::to_string(k) + ": " + errors[k]);
     std::memcpy(pose_out, poses[0].data(), 56);
@@ -1379,12 +1517,16 @@ void sageicp_set_profiling(int level) { g_profiling = level; }
 void sageicp_set_downsample_order(int reference_order) { g_reference_order = reference_order ? 1 : 0; }
 int sageicp_robin_iteration_order(const int32_t *vox_xyz, uint64_t n, uint32_t *order_out) {
     if (n && (!vox_xyz || !order_out)) return fail(SAGEICP_ERR_INVALID, "null argument");
-    if (n >= (1ull << 28)) return fail(SAGEICP_ERR_INVALID, "too many voxels");
+    if (n >= (1ull << 27)) return fail(SAGEICP_ERR_INVALID, "too many voxels (2^27 max)");
     std::vector<uint32_t> h(n), order;
     for (uint64_t i = 0; i < n; ++i) h[i] = reference_voxel_hash(vox_xyz[3 * i], vox_xyz[3 * i + 1], vox_xyz[3 * i + 2]);
     order.reserve(n);
     static thread_local RobinScratch scratch;      // (exercises the reuse of the bucket arrays across calls)
-    RobinOrderReplay::iteration_order(h.data(), n, 0u, order, &scratch);
+    uint32_t max_probe = 0;
+    if (!RobinOrderReplay::iteration_order(h.data(), n, 0u, order, &scratch, &max_probe))
+        return fail(SAGEICP_ERR_CAPACITY, "a probe distance of " + std::to_string(max_probe) + " or more: beyond it "
+                    "tsl::robin_map forces a growth this replay does not model (the reference's 20-bit hash: at "
+                    "the latest from ~2^19 voxels)");
     std::memcpy(order_out, order.data(), n * sizeof(uint32_t));
     return SAGEICP_OK;
 }
@@ -1543,6 +1685,7 @@ int sageicp_map_clear(sageicp_map *m) {
     m->host.clear();
     m->mirror_stale_all = true;
     for (sageicp_map *r : m->replicas) sageicp_map_clear(r);
+    m->replicas_diverged = false;         // every copy is empty again
     return SAGEICP_OK;
 }
 int sageicp_map_empty(const sageicp_map *m) { return (!m || map_is_empty(m)) ? 1 : 0; }
@@ -1557,17 +1700,26 @@ uint64_t sageicp_map_num_voxels(const sageicp_map *m) {
 
 int sageicp_map_add_points(sageicp_map *m, const double *xyzl, uint64_t n) {
     if (!m || (n && !xyzl)) return fail(SAGEICP_ERR_INVALID, "null argument");
+    if (m->replicas_diverged)
+        return fail(SAGEICP_ERR_INVALID, "the copies of this multi-device map diverged in an earlier failed update: Clear() it");
     if (int rc = ensure_host(m)) return rc;
     uint64_t at = 0;
     const int why = m->host.add_points(xyzl, n, &at);     // limits are checked before a point is taken
+    // every copy of a multi-device map takes exactly the points rank 0 took: all of them, or the
+    // prefix before the point a limit stopped at
+    const uint64_t took = why ? at : n;
+    for (sageicp_map *r : m->replicas)
+        if (int rc = sageicp_map_add_points(r, xyzl, took)) {
+            m->replicas_diverged = true;
+            const std::string w2 = g_err;
+            return fail(rc, "AddPoints reached only some devices of the map (" + w2 + "); the map must be cleared");
+        }
     if (why == 1)
         return fail(SAGEICP_ERR_CAPACITY, "map full (2^24 voxels / 2^31 point slots): stopped before point " +
                                               std::to_string(at) + ", the points before it are in");
     if (why == 2)
         return fail(SAGEICP_ERR_CAPACITY, "voxel index beyond +-2^20: stopped before point " +
                                               std::to_string(at) + ", the points before it are in");
-    for (sageicp_map *r : m->replicas)
-        if (int rc = sageicp_map_add_points(r, xyzl, n)) return rc;
     return SAGEICP_OK;
 }
 
@@ -2051,6 +2203,23 @@ struct sageicp_pipeline {
     bool ready = false;                  // prep[cur ^ 1] holds (or the worker is filling it with) pf_frame
     const double *pf_frame = nullptr;
     uint64_t pf_n = 0;
+    uint64_t an_print = 0, pf_print = 0; // content fingerprints (a buffer re-used for other data is another frame)
+    // FNV-1a over n and 64 rows spread over the frame: cheap, and enough to tell a buffer that was
+    // refilled since it was announced from the frame that was announced
+    static uint64_t fingerprint(const double *f, uint64_t m) {
+        uint64_t h = 1469598103934665603ull ^ m;
+        if (!f || !m) return h;
+        const uint64_t step = std::max<uint64_t>(1, m / 64);
+        for (uint64_t i = 0; i < m; i += step) {
+            uint64_t w[4];
+            std::memcpy(w, f + 4 * i, 32);
+            for (uint64_t x : w) { h ^= x; h *= 1099511628211ull; }
+        }
+        uint64_t w[4];
+        std::memcpy(w, f + 4 * (m - 1), 32);
+        for (uint64_t x : w) { h ^= x; h *= 1099511628211ull; }
+        return h;
+    }
     int pf_rc = 0;
     std::string pf_err;
     explicit sageicp_pipeline(const sageicp_pipeline_config &c) : impl(c), device(c.device) {}
@@ -2068,6 +2237,9 @@ struct sageicp_pipeline {
         const int crop[2] = {1, 0};
         const double scales[2] = {0.5, 1.5};
         std::vector<std::vector<double>> res;
+        // level 0 (frame_downsample: it goes into the map, AddPoints depends on arrival order)
+        // keeps the reference's emission order; level 1 (the registered source) does not need it
+        pr.arrival_order_levels = env_int("SAGEICP_SOURCE_REFERENCE_ORDER", 0) ? 0u : 2u;
         return pr.run(f, m, impl.max_range_(), impl.min_range_(), impl.label_max_range_(),
                       static_cast<int>(counts.size()), counts.data(), labels.data(), vs.data(),
                       crop, scales, 2, res, false);
@@ -2100,7 +2272,8 @@ int sageicp_pipeline_register_frame(sageicp_pipeline *p, const double *frame, ui
         int voxelize(const double *f, uint64_t m, uint64_t &n_src) {
             if (p->worker.joinable()) p->worker.join();
             int r;
-            if (p->ready && p->pf_frame == f && p->pf_n == m) {      // prepared while the last frame registered
+            if (p->ready && p->pf_frame == f && p->pf_n == m &&
+                p->pf_print == sageicp_pipeline::fingerprint(f, m)) {   // prepared while the last frame registered
                 r = p->pf_rc ? fail(p->pf_rc, p->pf_err) : SAGEICP_OK;
                 p->cur ^= 1;
             } else {                                                 // none, or another frame: dropped
@@ -2114,6 +2287,7 @@ int sageicp_pipeline_register_frame(sageicp_pipeline *p, const double *frame, ui
                 p->ready = true;
                 p->pf_frame = p->an_frame;
                 p->pf_n = p->an_n;
+                p->pf_print = p->an_print;
                 p->pf_rc = 0;
                 p->pf_err.clear();
                 sageicp_pipeline *q = p;
@@ -2151,13 +2325,23 @@ int sageicp_pipeline_register_frame(sageicp_pipeline *p, const double *frame, ui
             return sageicp_map_update_pose(p->impl.map, fd.data(), n_fd, pose);
         }
     };
-    return p->impl.register_frame(frame, n, pose_out, icp_s, total_s, n_source, stats, Backend{p});
+    const int rc = p->impl.register_frame(frame, n, pose_out, icp_s, total_s, n_source, stats, Backend{p});
+    p->announced = false;       // an announcement is consumed by this call, also when it failed or the frame was empty
+    return rc;
 }
 int sageicp_pipeline_prefetch(sageicp_pipeline *p, const double *frame, uint64_t n) {
     if (!p || (n && !frame)) return fail(SAGEICP_ERR_INVALID, "null argument");
     p->announced = true;
     p->an_frame = frame;
     p->an_n = n;
+    p->an_print = sageicp_pipeline::fingerprint(frame, n);
+    return SAGEICP_OK;
+}
+int sageicp_pipeline_prefetch_cancel(sageicp_pipeline *p) {
+    if (!p) return fail(SAGEICP_ERR_INVALID, "null pipeline");
+    if (p->worker.joinable()) p->worker.join();     // nothing reads an announced buffer after this
+    p->announced = false;
+    p->ready = false;
     return SAGEICP_OK;
 }
 int sageicp_pipeline_reinitialize(sageicp_pipeline *p) {

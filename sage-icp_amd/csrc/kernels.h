@@ -107,6 +107,20 @@ struct FinParams {
 };
 void launch_fin(const FinParams &p, hipStream_t s);
 
+// Two-stage reduction for big frames: above kRedThreshold partials (what k_fin's one workgroup
+// fetches in a single round of loads) k_red first folds slices of kRedSlice partials into
+// red_rows_for(nparts) rows, and k_fin reduces those.
+constexpr int kRedThreshold = 2448;
+constexpr int kRedSlice = 256;
+struct RedParams {
+    const double *partials;   // [nparts][kNumSums]
+    int nparts;
+    double *out;              // [red_rows_for(nparts)][kNumSums]
+    const int32_t *done;      // the loop's done flag (a finished loop: no-op); nullptr: always run
+};
+int red_rows_for(int nparts);                 // 0: single stage
+void launch_red(const RedParams &p, hipStream_t s);
+
 constexpr int kMaxPartials = 1 << 16;
 constexpr uint64_t kMaxQueries = (1ull << 26) - 1;
 constexpr uint64_t kMaxMapPoints = (1ull << 31) - 512;   // blocks x capacity: point indices fit an int32 (nn_idx)

@@ -1083,6 +1083,20 @@ __device__ __forceinline__ void exchange_sums(IcpState *st, const P2pParams &X) 
     }
 }
 
+// ------------------------------------------------------------------------------------ k_red
+// First stage of the reduction for frames whose partials one workgroup cannot fetch in one round of
+// loads (c4: 7,813 partials = 1.25 MB through ONE CU took 13 us of every iteration): workgroup g
+// reduces slice g (kRedSlice partials, the same fixed order as k_fin's own reduction) into row g of
+// a second, small array of partials, which k_fin then reduces as usual.  Sums are in a fixed order
+// that depends on the number of partials only: bit-reproducible.
+__global__ __launch_bounds__(kFinThreads) void k_red(RedParams P) {
+    __shared__ double S[kNumSums];
+    const int lo = static_cast<int>(blockIdx.x) * kRedSlice;
+    const int cnt = min(kRedSlice, P.nparts - lo);
+    if (!reduce_partials(P.partials + static_cast<size_t>(lo) * kNumSums, cnt, S, P.done)) return;
+    if (threadIdx.x < kNumSums) P.out[static_cast<size_t>(blockIdx.x) * kNumSums + threadIdx.x] = S[threadIdx.x];
+}
+
 // ------------------------------------------------------------------------------------ k_fin
 __global__ __launch_bounds__(kFinThreads) void k_fin(FinParams P) {
     __shared__ double S[kNumSums];
@@ -1340,6 +1354,11 @@ int launch_gn(const GnParams &p, hipStream_t s) {
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_gn, dim3(static_cast<int>(blocks)), dim3(256), 0, s, p);
     return static_cast<int>(blocks);
+}
+
+int red_rows_for(int nparts) { return nparts > kRedThreshold ? (nparts + kRedSlice - 1) / kRedSlice : 0; }
+void launch_red(const RedParams &p, hipStream_t s) {
+    hipLaunchKernelGGL(k_red, dim3(red_rows_for(p.nparts)), dim3(kFinThreads), 0, s, p);
 }
 
 void launch_fin(const FinParams &p, hipStream_t s) {

@@ -10,8 +10,11 @@
 // noise; profiles/README.md).  So the device down-sampling (preprocess.hip), which finds the
 // survivors in arrival order, hands their voxel keys to this routine and permutes them.
 //
-// The layout of a robin-hood table is not a function of the key set alone (growth re-inserts in
-// bucket order, clusters wrap around the end of the array), so the insertions are replayed:
+// The layout of a robin-hood table is not a function of the key set alone (an entry pushed out of
+// its bucket walks past the entries that share its home, so the order inside such a group records
+// which insertions went through it; growth re-inserts in bucket order; clusters wrap around the end
+// of the array — a closed form built on sorting by home bucket was tried twice and reproduces the
+// order on no realistic input), so the insertions are replayed:
 //   * 0 buckets at first; before an insertion the array doubles (2, 4, 8, ...) when
 //     size >= size_t(float(buckets) * 0.5f)                          (max load factor 0.5)
 //   * ideal bucket = hash & (buckets - 1); an entry walks forward until it is farther from its
@@ -20,6 +23,14 @@
 //   * growth re-inserts the old buckets in index order; iteration is bucket 0 .. buckets-1
 // Keys are distinct by construction (one survivor per voxel), so no look-up is needed.
 // O(n) expected; ~25 ns per key on the host.
+//
+// Not modelled — and therefore REFUSED rather than answered wrongly: tsl::robin_map also grows
+// when an insertion's probe distance passes a limit (DIST_FROM_IDEAL_BUCKET_LIMIT; the library is
+// not in this image and its releases have used limits between 128 and 8192, so the strictest is
+// taken).  The replay tracks the largest distance it meets; once that reaches kProbeLimit the order
+// it would return is no longer claimed to be the reference's and iteration_order() returns false
+// (street scenes stay below 40).  With the reference's 20-bit hash this happens at the latest when
+// a label group passes ~2^19 voxels (more buckets than hash values).
 #pragma once
 
 #include <algorithm>
@@ -40,15 +51,19 @@ inline uint32_t reference_voxel_hash(int32_t x, int32_t y, int32_t z) {
 // growth step switches to the other array and clears only what it is about to use, instead of
 // allocating, zero-filling and page-faulting a fresh block at every doubling of every frame.
 struct RobinScratch {
-    std::vector<uint64_t> a, b;
+    std::vector<uint64_t> a, b, dense;
 };
 
 class RobinOrderReplay {
 public:
     // hashes[i]: reference_voxel_hash of the i-th inserted (distinct) voxel, n < 2^28.  Appends to
     // `order` the insertion indices (+ base) in the table's iteration order.
-    static void iteration_order(const uint32_t *hashes, size_t n, uint32_t base, std::vector<uint32_t> &order,
-                                RobinScratch *scratch = nullptr) {
+    static constexpr uint64_t kProbeLimit = 128;
+    // returns false (and leaves `order` as it was) when the replay met a probe distance it does
+    // not model; max_probe (optional): the largest distance met
+    static bool iteration_order(const uint32_t *hashes, size_t n, uint32_t base, std::vector<uint32_t> &order,
+                                RobinScratch *scratch = nullptr, uint32_t *max_probe = nullptr) {
+        if (n >= (static_cast<size_t>(1) << 27)) return false;     // 28-bit insertion indices, 2^28 buckets
         RobinScratch local;
         RobinOrderReplay t(scratch ? *scratch : local, n);
         // a put is a dependent cache miss into a table of megabytes: the home bucket of the
@@ -56,9 +71,13 @@ public:
         for (size_t i = 0; i < n; ++i) {
             if (i + kAhead < n && t.buckets_) __builtin_prefetch(t.cur_ + (hashes[i + kAhead] & (t.buckets_ - 1)), 1);
             t.insert(hashes[i], static_cast<uint32_t>(i));
+            if (t.max_field_ > kProbeLimit) break;     // (the field holds distance + 1)
         }
+        if (max_probe) *max_probe = static_cast<uint32_t>(t.max_field_ ? t.max_field_ - 1 : 0);
+        if (t.max_field_ > kProbeLimit) return false;
         for (size_t b = 0; b < t.buckets_; ++b)
             if (const uint64_t e = t.cur_[b]) order.push_back(base + static_cast<uint32_t>(e & kValMask));
+        return true;
     }
 
 private:
@@ -71,12 +90,17 @@ private:
     }
     uint64_t *cur_ = nullptr, *other_ = nullptr;
     size_t buckets_ = 0, size_ = 0;
+    uint64_t max_field_ = 0;               // largest (distance + 1) any entry was stored with
+    size_t thresh_ = 0;                    // size at which the next insertion grows the array first
+    uint64_t *dense_ = nullptr;            // the occupied buckets of the array being re-inserted, compacted
 
     RobinOrderReplay(RobinScratch &s, size_t n) {
         size_t cap = 2;                    // the bucket count the n-th insertion will have seen
         while (static_cast<size_t>(static_cast<float>(cap) * 0.5f) < n) cap *= 2;
         if (s.a.size() < cap) s.a.resize(cap);
         if (s.b.size() < cap) s.b.resize(cap);
+        if (s.dense.size() < cap / 2 + 1) s.dense.resize(cap / 2 + 1);
+        dense_ = s.dense.data();
         cur_ = s.a.data();
         other_ = s.b.data();
     }
@@ -87,39 +111,68 @@ private:
             const uint64_t r = cur_[b];
             if ((e >> 48) > (r >> 48)) {          // strictly farther from home than the resident
                 cur_[b] = e;
+                if ((e >> 48) > max_field_) max_field_ = e >> 48;
                 if (!r) return;
                 e = r;
+            }
+            if ((e >> 48) > kProbeLimit) {        // not modelled beyond here (and the 16-bit field must not wrap)
+                max_field_ = e >> 48;
+                return;
             }
             e += 1ull << 48;
             b = (b + 1) & mask;
         }
     }
     // Growth re-inserts the old buckets in index order into an empty array of twice the size.
-    // Without wrap-around the old order is sorted by home bucket, an entry's new home is its old one
-    // or that plus old_n (one more hash bit), and an entry inserted after everything with a smaller
-    // or equal home in its half displaces nobody: it lands on max(home, last position of its half
-    // + 1).  That is one sequential pass with no probing.  It is only taken when it is provably the
-    // replay's result — no entry of the old array wrapped past its end, and neither half of the new
-    // one spills over its own end — otherwise the insertions are replayed one by one (the small
-    // arrays at the start of a replay, mostly).
-    bool grow_linear(const uint64_t *old, size_t old_n) {
-        for (size_t b = 0; b < old_n && old[b]; ++b)          // the cluster at bucket 0, if any
-            if ((old[b] >> 48) - 1 > b) return false;          // farther from home than its index: wrapped
-        size_t last[2] = {static_cast<size_t>(-1), old_n - 1};
+    // The old order is sorted by home bucket (robin-hood invariant; the entries that had wrapped
+    // past the old end come first), an entry's new home is its old one or that plus old_n (one more
+    // hash bit), so each half of the new array is filled front to back and almost every entry lands
+    // without probing.  Two cases are decided without a walk, each provably what put() would do:
+    //   * the home bucket is empty: the entry stays there;
+    //   * the home bucket is taken, the previous entry placed in this half had a home <= this one's
+    //     (not so right after the wrapped entries) and sits at `last` >= home, and bucket last + 1 is
+    //     empty: [home, last] is then fully occupied (the previous entry walked through it or sits
+    //     on it), every resident there is at least as far from its home as this entry would be (a
+    //     cluster is sorted by home; entries that wrapped are farther still), so none yields, and
+    //     the entry lands on last + 1.
+    // Anything else — the wrapped entries' neighbourhoods, the ends of the halves — goes through
+    // put(), after which `last` is not trusted until an entry has found its home bucket empty.
+    void grow_fast(const uint64_t *old, size_t old_n) {
         const size_t mask = buckets_ - 1;
         unsigned sh = 0;
         while ((static_cast<size_t>(1) << sh) < old_n) ++sh;
+        // (occupied buckets compacted first: testing tens of thousands of buckets that are full or
+        // empty at random costs more in mispredicted branches than the placements do)
+        uint64_t *dn = dense_;          // (an array of old_n buckets holds at most old_n / 2 entries when it grows)
+        size_t k = 0;
         for (size_t j = 0; j < old_n; ++j) {
-            const uint64_t e = old[j];
-            if (!e) continue;
+            dn[k] = old[j];
+            k += old[j] != 0;
+        }
+        size_t last[2] = {0, 0}, last_home[2] = {0, 0};
+        bool trust[2] = {false, false};
+        for (size_t q = 0; q < k; ++q) {
+            const uint64_t e = dn[q] & ((1ull << 48) - 1);
             const size_t home = (e >> 28) & 0xFFFFFu & mask;
             const size_t half = (home >> sh) & 1u;
-            const size_t pos = std::max(home, last[half] + 1);
+            size_t pos;
+            if (!cur_[home]) {
+                pos = home;
+            } else if (trust[half] && home >= last_home[half] && last[half] >= home && last[half] + 1 < buckets_ && !cur_[last[half] + 1] &&
+                       last[half] + 1 - home < kProbeLimit) {
+                pos = last[half] + 1;
+            } else {
+                put(e | (1ull << 48));
+                trust[0] = trust[1] = false;
+                continue;
+            }
             last[half] = pos;
-            if (pos >= (half + 1) * old_n) return false;       // spilled into the other half / past the end
-            cur_[pos] = (e & ((1ull << 48) - 1)) | (static_cast<uint64_t>(pos - home + 1) << 48);
+            last_home[half] = home;
+            trust[half] = true;
+            const uint64_t d1 = pos - home + 1;
+            cur_[pos] = e | (d1 << 48);
+            if (d1 > max_field_) max_field_ = d1;
         }
-        return true;
     }
     void grow() {
         const uint64_t *old = cur_;
@@ -128,14 +181,17 @@ private:
         buckets_ = old_n ? 2 * old_n : 2;
         std::memset(cur_, 0, buckets_ * sizeof(uint64_t));
         if (old_n >= 64) {
-            if (grow_linear(old, old_n)) return;
-            std::memset(cur_, 0, buckets_ * sizeof(uint64_t));
+            grow_fast(old, old_n);
+            return;
         }
         for (size_t j = 0; j < old_n; ++j)
             if (const uint64_t e = old[j]) put((e & ((1ull << 48) - 1)) | (1ull << 48));       // distance 0 again
     }
     void insert(uint32_t h, uint32_t v) {
-        if (size_ >= static_cast<size_t>(static_cast<float>(buckets_) * 0.5f)) grow();
+        if (size_ >= thresh_) {
+            grow();
+            thresh_ = static_cast<size_t>(static_cast<float>(buckets_) * 0.5f);
+        }
         put(pack(h, v, 0));
         ++size_;
     }

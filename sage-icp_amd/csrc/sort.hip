@@ -2,8 +2,9 @@
 // hash-map iteration order (core/Preprocessing.cpp:75-82), i.e. spatially random.  Here the
 // frame is re-ordered once per call along the Morton curve of the map-frame voxels its points
 // fall into under the current pose, so that the queries of a k_icp wave are neighbours: they touch
-// the same voxel blocks (L1/L2 hits) and cost about the same.  run_icp re-sorts when the
-// pose has carried the points a fraction of a voxel away from the order they were sorted in.
+// the same voxel blocks (L1/L2 hits) and cost about the same.  (Round 1 re-sorted when the pose had
+// carried the points a fraction of a voxel away from that order; with a lane per query and cached
+// neighbourhood rows that costs what it saves, so run_icp sorts once per call.)
 // (Re-ordering the queries by the work the previous iteration measured was tried in four forms —
 // frame-wide work classes; sorted, or dealt out evenly over the waves, inside chunks of 1024
 // consecutive queries; sorted inside one workgroup's 64 queries — and is not kept: the lockstep

@@ -115,6 +115,36 @@ def test_stream_with_prefetch_is_bit_identical(gpu_sage, reference_emission_orde
     assert np.array_equal(a.LocalMap(), b.LocalMap())
 
 
+@pytest.mark.gpu
+def test_prefetch_recognises_a_refilled_buffer_and_can_be_cancelled(gpu_sage, reference_emission_order):
+    """the announced frame is matched by pointer, size AND content: a buffer refilled with another
+    scan after its clouds were prepared is registered as what it now holds (the stale prepared
+    clouds are dropped); a cancelled announcement leaves nothing prepared and nothing reading"""
+    import time
+    from sage_icp_amd import synthetic as syn
+    frames, _ = syn.make_stream(6, 6, points_per_frame=20000)
+    n = min(len(f) for f in frames)
+    frames = [np.ascontiguousarray(f[:n], dtype=np.float64) for f in frames]
+    cfg = gpu_sage.make_pipeline_config()
+    a, b = gpu_sage.SageICP(cfg), gpu_sage.SageICP(cfg)
+    seq = [frames[0], frames[2], frames[3], frames[4]]
+    ref = [a.RegisterFrame(f)[0] for f in seq]
+    buf = frames[1].copy()
+    b.prefetch(buf)                                   # announces the scan `buf` holds now (frame 1)
+    assert np.array_equal(b.RegisterFrame(frames[0])[0], ref[0])
+    time.sleep(0.5)                                   # the helper has prepared frame 1's clouds by now
+    buf[:] = frames[2]                                # same pointer, same size, another scan
+    assert np.array_equal(b.RegisterFrame(buf)[0], ref[1]), "stale prepared clouds were used"
+    b.prefetch(frames[4])
+    b.prefetch_cancel()                               # announced, then withdrawn
+    assert np.array_equal(b.RegisterFrame(frames[3])[0], ref[2])
+    b.prefetch(frames[4])                             # and the ordinary use still works afterwards
+    b.prefetch_cancel()
+    b.prefetch(frames[4])
+    assert np.array_equal(b.RegisterFrame(frames[4])[0], ref[3])
+    assert np.array_equal(a.LocalMap(), b.LocalMap())
+
+
 def _py_preprocess(frame, max_range, min_range, label_max_range):
     out = []
     for p in frame:

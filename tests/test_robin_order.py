@@ -18,6 +18,7 @@ class PyRobin:
     def __init__(self):
         self.slots = []          # None or [key, value, dist]
         self.n = 0
+        self.max_dist = 0        # largest distance any entry was ever stored with
 
     def _insert_raw(self, key, val):
         mask = len(self.slots) - 1
@@ -26,9 +27,11 @@ class PyRobin:
             r = self.slots[i]
             if r is None:
                 self.slots[i] = cur
+                self.max_dist = max(self.max_dist, cur[2])
                 return
             if cur[2] > r[2]:
                 self.slots[i], cur = cur, r
+                self.max_dist = max(self.max_dist, self.slots[i][2])
             cur[2] += 1
             i = (i + 1) & mask
 
@@ -167,3 +170,64 @@ def test_product_replay_matches_independent_restatement(sage):
         for i, k in enumerate(keys):
             r.insert(tuple(int(v) for v in k), i)
         assert list(out[:n]) == r.order(), (n, span)
+
+
+def _voxels_with_hash(pred, want, rng, span=400):
+    """distinct voxels whose reference hash satisfies `pred` (vectorised search over a random cube)"""
+    got = []
+    seen = set()
+    while len(got) < want:
+        k = rng.integers(-span, span, size=(200000, 3)).astype(np.int64)
+        h = ((k[:, 0] * 73856093) ^ (k[:, 1] * 19349663) ^ (k[:, 2] * 83492791)) & 0xFFFFF
+        for row in k[pred(h)]:
+            t = tuple(int(v) for v in row)
+            if t not in seen:
+                seen.add(t)
+                got.append(t)
+                if len(got) == want:
+                    break
+    return got
+
+
+def test_product_replay_on_wrap_heavy_key_sets(sage):
+    """key sets built to wrap around the end of the bucket array at every growth (hashes whose low
+    bits are all ones, at the ends of both halves of the next array) — where the replay's fast
+    growth path hands over to one-by-one insertion: still the restatement's order"""
+    L = sage.lib()
+    rng = np.random.default_rng(23)
+    cases = [
+        lambda h: (h & 0x3F) >= 0x3C,                       # the top 4 of every 64: wraps in the small arrays
+        lambda h: (h & 0xFF) >= 0xF8,
+        lambda h: ((h & 0x3FF) >= 0x3FA) | ((h & 0x3FF) == 0x1FF) | ((h & 0x3FF) < 2),
+        lambda h: (h & 0xFFF) >= 0xFF0,
+    ]
+    for ci, pred in enumerate(cases):
+        for n in (40, 300, 1500, 5000):
+            hot = _voxels_with_hash(pred, n // 3, rng)
+            cold = [tuple(int(v) for v in r) for r in rng.integers(-300, 300, size=(n, 3))]
+            keys = list(dict.fromkeys(hot + cold))
+            order = rng.permutation(len(keys))
+            keys = np.ascontiguousarray(np.array([keys[i] for i in order], dtype=np.int32))
+            m = len(keys)
+            out = np.zeros(m, dtype=np.uint32)
+            rc = L.sageicp_robin_iteration_order(keys.ctypes.data, m, out.ctypes.data)
+            r = PyRobin()
+            for i, k in enumerate(keys):
+                r.insert(tuple(int(v) for v in k), i)
+            if rc != 0:          # refused: only where the restatement met a probe distance at the limit
+                assert rc == sage.ERR_CAPACITY and r.max_dist >= 127, (ci, n, r.max_dist)
+                continue
+            assert r.max_dist < 128, (ci, n, r.max_dist)
+            assert list(out[:m]) == r.order(), (ci, n)
+
+
+def test_product_replay_refuses_what_it_does_not_model(sage):
+    """beyond a probe distance of 128 tsl::robin_map forces a growth the replay does not model: an
+    error, not a wrong order (voxels that all hash to one bucket)"""
+    L = sage.lib()
+    rng = np.random.default_rng(29)
+    keys = np.ascontiguousarray(np.array(_voxels_with_hash(lambda h: h == 0x12345, 200, rng, span=3000), dtype=np.int32))
+    out = np.zeros(len(keys), dtype=np.uint32)
+    assert L.sageicp_robin_iteration_order(keys.ctypes.data, len(keys), out.ctypes.data) == sage.ERR_CAPACITY
+    assert b"probe distance" in L.sageicp_last_error()
+    assert L.sageicp_robin_iteration_order(keys.ctypes.data, 100, out.ctypes.data) == 0      # 100 in a row is fine
