@@ -109,6 +109,7 @@ struct Scratch {
     uint32_t *d_work = nullptr;    // instrumented builds: points handed to each query
     double *d_partials = nullptr; size_t partials_cap = 0;
     double *d_partials2 = nullptr; size_t partials2_cap = 0;   // second stage of the reduction (k_red, big frames)
+    long long *d_acc = nullptr;    // fixed-point accumulators of the Gauss-Newton sums (kernels.h, kAcc*)
     unsigned long long *d_cand = nullptr;      // per-wave counters of k_icp [2 x sort_cap]
     IcpState *d_state = nullptr;
     IcpState *h_state = nullptr;   // pinned
@@ -126,6 +127,7 @@ struct Scratch {
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIPCHK(hipMalloc(&d_state, sizeof(IcpState)));
+        HIPCHK(hipMalloc(&d_acc, sizeof(long long) * kAccReplicas * kAccWords));
 
         HIPCHK(hipHostMalloc(&h_state, sizeof(IcpState), hipHostMallocDefault));
         HIPCHK(hipHostMalloc(&h_prog, sizeof(IcpProgress), hipHostMallocMapped | hipHostMallocCoherent));
@@ -233,6 +235,7 @@ struct Scratch {
         if (d_partials) (void)hipFree(d_partials);
         if (d_partials2) (void)hipFree(d_partials2);
         if (d_state) (void)hipFree(d_state);
+        if (d_acc) (void)hipFree(d_acc);
         if (d_cand) (void)hipFree(d_cand);
         if (h_state) (void)hipHostFree(h_state);
         if (h_prog) (void)hipHostFree(h_prog);
@@ -1181,13 +1184,20 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         HIPCHK(hipMemsetAsync(sc.d_prev, 0xFF, n * sizeof(uint2), s));     // no previous answers yet
     }
 
-    // big frames: k_red folds the workgroup partials into a few rows first (kernels.h)
-    const int red_rows = n ? red_rows_for(blocks) : 0;
+    // The workgroups of k_icp add their sums into fixed-point accumulators (kernels.h) that k_fin
+    // reads in one round trip; SAGEICP_PARTIALS=1 keeps the older form — one fp64 partial per
+    // workgroup, reduced by k_fin (big frames: k_red folds them into a few rows first) — for
+    // comparisons.
+    const bool use_acc = env_int("SAGEICP_PARTIALS", 0) == 0;
+    if (use_acc) HIPCHK(hipMemsetAsync(sc.d_acc, 0, sizeof(long long) * kAccReplicas * kAccWords, s));
+    ip.acc = use_acc ? sc.d_acc : nullptr;
+    const int red_rows = (n && !use_acc) ? red_rows_for(blocks) : 0;
     if (red_rows && (rc = sc.reserve_partials2(static_cast<size_t>(red_rows)))) return rc;
     RedParams rp{sc.d_partials, blocks, sc.d_partials2, &sc.d_state->done};
     FinParams fp{};
     fp.st = sc.d_state;
     fp.partials = red_rows ? sc.d_partials2 : sc.d_partials;
+    fp.acc = ip.acc;
     fp.nparts = n ? (red_rows ? red_rows : blocks) : 0;
     fp.mode = p2p ? 3 : (comm ? 1 : 0);
     fp.standalone = 0;
@@ -1293,6 +1303,9 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         }
     }
     const IcpState &st = *sc.h_state;
+    if (st.acc_overflow)
+        return fail(SAGEICP_ERR_CAPACITY, "a Gauss-Newton sum left the range of the fixed-point accumulators "
+                                          "(coordinates beyond ~10^6 m?)");
     if (st.exchange_failed) {
         // the ranks' exchange counters may now differ by one: a later exchange could pass its wait
         // on a stale tag and add rows of another iteration.  The blocks are dead until every rank

@@ -60,7 +60,9 @@ struct IcpParams {
                               // when big)}; key 0xFFFFFFFF: none.  Seeds the next search with a
                               // tight bound.
     uint32_t *work;           // instrumented builds only: [n] map points handed to each query
-    double *partials;         // out: [gridDim.x][kNumSums] one partial per workgroup
+    double *partials;         // out: [gridDim.x][kNumSums] one partial per workgroup (acc == nullptr)
+    long long *acc;           // out: the Gauss-Newton sums as fixed-point accumulators (see kAcc* below):
+                              // every workgroup ADDS its 16 sums and its pair count with integer atomics
     unsigned long long *counters;  // optional: [2 x waves] running sums of {C_q, pairs evaluated}
     unsigned nwaves;          // waves that own queries: ceil(n / (64 >> lw))
 #ifdef SAGE_ICP_DELAY_PROBE
@@ -97,9 +99,22 @@ int launch_gn(const GnParams &p, hipStream_t s);   // returns the number of part
 //   mode 1: reduce -> st->sums        (multi GPU, before the RCCL all-reduce)
 //   mode 2: solve from st->sums       (multi GPU, after the all-reduce)
 //   mode 3: reduce + direct exchange over xGMI + solve
+// Fixed-point accumulators of the Gauss-Newton sums.  A workgroup of k_icp used to leave one fp64
+// partial (160 B) for k_fin, whose single workgroup then pulled 1,920 (c2) to 7,813 (c4) of them
+// through one CU: 3.6 to 13 us of every iteration.  Integer addition is associative, so the
+// workgroups can add into shared accumulators with fire-and-forget atomics in any order and the
+// result is still bit-reproducible — and exact: each sum is a 120-bit fixed-point number held as
+// three signed digits of 40 bits (weights 2^0, 2^-40, 2^-80) in 64-bit words, which leaves 23 bits
+// of head-room per digit for the carries of up to 2^23 workgroups; nothing is rounded until k_fin
+// converts the totals to fp64 once.  kAccReplicas copies (chosen by workgroup index) keep the
+// atomics of a launch off any single address; k_fin adds the copies (exactly) and clears them.
+constexpr int kAccReplicas = 32;
+constexpr int kAccWords = 64;              // per replica: (16 sums + pair count) x 3 digits = 51 used
+constexpr int kAccValues = 17;
 struct FinParams {
     IcpState *st;
     const double *partials;
+    long long *acc;           // non-null: the sums come from the fixed-point accumulators (k_icp), not from partials
     int nparts;
     int mode;
     int standalone;           // 1: run even when st->done (AlignClouds entry)

@@ -799,7 +799,40 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
         if (lane == 0)
             prior = __hip_atomic_fetch_add(&smem[kWgArrive], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
         prior = __builtin_amdgcn_readfirstlane(prior);
-        if (prior == kIcpWavesPerBlock - 1u) {
+        if (prior == kIcpWavesPerBlock - 1u && P.acc) {
+            // The workgroup's 16 sums and its pair count go into the shared fixed-point accumulators
+            // (kernels.h): lane l adds digit l % 3 of value l / 3 with one fire-and-forget 64-bit
+            // integer atomic — any order of arrival gives the same bits.
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const double *ws = reinterpret_cast<const double *>(smem + kWgSums);
+            const int c = min(lane / 3, kAccValues - 1), digit = lane % 3;
+            double v = 0.0;
+            if (c < kCount) {
+#pragma unroll
+                for (int k = 0; k < kIcpWavesPerBlock; ++k) v += ws[k * kCount + c];
+            } else {
+                unsigned n = 0u;
+#pragma unroll
+                for (int k = 0; k < kIcpWavesPerBlock; ++k) n += smem[kWgPairs + k];
+                v = static_cast<double>(n);
+            }
+            // exact split v = a + b 2^-40 + c2 2^-80 (+ what lies below 2^-80, dropped): three
+            // integers of at most 40 bits and a sign, each exactly representable
+            const double a = __builtin_rint(v);
+            const double r1 = (v - a) * 1099511627776.0;             // 2^40, exact
+            const double b = __builtin_rint(r1);
+            const double c2 = __builtin_rint((r1 - b) * 1099511627776.0);
+            const double d = digit == 0 ? a : (digit == 1 ? b : c2);
+            // integer of magnitude < 2^51 held in a double -> int64 through the 2^52 + 2^51 trick
+            const bool ok = fabs(a) < 1125899906842624.0;             // 2^50 (coordinates of 10^6 m stay far below)
+            // (both numbers lie in [2^52, 2^53): their bit patterns differ by exactly d)
+            const long long x = __double_as_longlong(d + 6755399441055744.0) - 0x4338000000000000ll;
+            if (lane < 3 * kAccValues) {
+                long long *dst = P.acc + static_cast<size_t>(blockIdx.x & (kAccReplicas - 1)) * kAccWords + lane;
+                if (ok) (void)__hip_atomic_fetch_add(dst, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else (void)__hip_atomic_fetch_or(P.acc + kAccWords - 1, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (prior == kIcpWavesPerBlock - 1u) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             const double *ws = reinterpret_cast<const double *>(smem + kWgSums);
             double *out = P.partials + static_cast<size_t>(blockIdx.x) * kNumSums;
@@ -955,8 +988,76 @@ __device__ __forceinline__ bool reduce_partials(const double *partials, int npar
     return true;
 }
 
+// The sums from the fixed-point accumulators k_icp's workgroups added into (kernels.h): one round
+// trip for 16 KB, the replicas added exactly (integers), three digits -> one fp64 per sum, and the
+// accumulators cleared for the next iteration.  Returns false when *done is set (see above).
+__device__ __forceinline__ bool reduce_accumulators(long long *acc, double *S /* LDS [kNumSums] */,
+                                                    const int32_t *done, int32_t *overflow) {
+    __shared__ long long part[kAccReplicas][kAccWords];
+    __shared__ long long part2[8][kAccWords];
+    const int t = static_cast<int>(threadIdx.x);
+    // 2,048 words over 1,024 threads: 16 B each, one coalesced round trip
+    typedef long long ll2 __attribute__((ext_vector_type(2)));
+    ll2 *src = reinterpret_cast<ll2 *>(acc);
+    const ll2 v = src[t];
+    if (done) {
+        const int32_t d = done[__builtin_amdgcn_mbcnt_lo(0u, 0u)];      // travels with the load above
+        if (__builtin_amdgcn_readfirstlane(d)) return false;
+    }
+    ll2 z;
+    z.x = 0; z.y = 0;
+    src[t] = z;                                                          // cleared for the next launch of k_icp
+    reinterpret_cast<ll2 *>(&part[0][0])[t] = v;
+    __syncthreads();
+    if (t < 8 * kAccWords) {
+        const int w = t % kAccWords, g = t / kAccWords;
+        long long s = 0;
+#pragma unroll
+        for (int k = 0; k < kAccReplicas / 8; ++k) s += part[g * (kAccReplicas / 8) + k][w];
+        part2[g][w] = s;
+    }
+    __syncthreads();
+    if (t < kAccWords) {
+        long long s = 0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) s += part2[g][t];
+        part[0][t] = s;
+    }
+    __syncthreads();
+    if (t < kNumSums) {
+        double r = 0.0;
+        if (t < kAccValues) {
+            const double a = static_cast<double>(part[0][3 * t]);
+            const double b = static_cast<double>(part[0][3 * t + 1]);
+            const double c = static_cast<double>(part[0][3 * t + 2]);
+            r = a + (b * 9.094947017729282e-13 + c * 8.271806125530277e-25);      // 2^-40, 2^-80
+        }
+        S[t] = r;
+        if (t == 0 && part[0][kAccWords - 1] != 0) *overflow = 1;
+    }
+    __syncthreads();
+    return true;
+}
+
 // the solve: wave 0, all 64 lanes, uniform data (see WaveLanes); lane 0 / lane 1 publish the state
-__device__ __forceinline__ void solve_and_publish(IcpState *st, const double *S) {
+// The loop state the finish needs (the two poses the estimate is composed with, the iteration
+// count), requested by the first wave BEFORE the reduction so that its cold round trip (~0.7 us)
+// runs under it instead of after the solve.
+struct FinState {
+    double rhs[7];            // lane 1: T_icp, the other lanes: T
+    int iter;
+};
+__device__ __forceinline__ FinState prefetch_state(const IcpState *st) {
+    FinState f;
+    const int lane = static_cast<int>(threadIdx.x);
+    const double *src = (lane == 1) ? st->T_icp : st->T;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) f.rhs[i] = src[i];
+    f.iter = st->iter;
+    return f;
+}
+
+__device__ __forceinline__ void solve_and_publish(IcpState *st, const double *S, const FinState &pre) {
 #ifdef SAGE_GN_TIMING
     unsigned long long fin_t[8];
 #endif
@@ -972,10 +1073,8 @@ __device__ __forceinline__ void solve_and_publish(IcpState *st, const double *S)
     FIN_STAMP(3);
 
     // the two compositions (Registration.cpp:135 and the cumulative pose) on lanes 0 and 1
-    double rhs[7], Tn[7];
-#pragma unroll
-    for (int i = 0; i < 7; ++i) rhs[i] = (lane == 1) ? st->T_icp[i] : st->T[i];
-    se3_mul(est, rhs, Tn);
+    double Tn[7];
+    se3_mul(est, pre.rhs, Tn);
     if (lane < 2) {
         double *dst = (lane == 1) ? st->T_icp : st->T;
 #pragma unroll
@@ -1002,7 +1101,7 @@ __device__ __forceinline__ void solve_and_publish(IcpState *st, const double *S)
         nrm = sqrt(nrm);
     }
     st->last_step_norm = nrm;
-    const int it = st->iter;
+    const int it = pre.iter;
     if (it < kHistory) st->n_corr[it] = static_cast<uint32_t>(S[kCount]);
     st->iter = it + 1;
     unsigned long long done = 0;
@@ -1105,8 +1204,12 @@ __global__ __launch_bounds__(kFinThreads) void k_fin(FinParams P) {
 #ifdef SAGE_GN_TIMING
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
 #endif
+    FinState pre{};
+    if (threadIdx.x < 64) pre = prefetch_state(st);
     if (P.mode != 2) {
-        if (!reduce_partials(P.partials, P.nparts, S, P.standalone ? nullptr : &st->done)) return;
+        if (P.acc) {
+            if (!reduce_accumulators(P.acc, S, P.standalone ? nullptr : &st->done, &st->acc_overflow)) return;
+        } else if (!reduce_partials(P.partials, P.nparts, S, P.standalone ? nullptr : &st->done)) return;
 #ifdef SAGE_GN_TIMING
         if (threadIdx.x == 0) atomicAdd(&g_gn_phase[8], __builtin_amdgcn_s_memrealtime() - t_start);
 #endif
@@ -1124,7 +1227,7 @@ __global__ __launch_bounds__(kFinThreads) void k_fin(FinParams P) {
         __syncthreads();
     }
     if (threadIdx.x >= 64) return;
-    solve_and_publish(st, S);
+    solve_and_publish(st, S, pre);
 }
 
 // ------------------------------------------------------------------------------------ k_gn

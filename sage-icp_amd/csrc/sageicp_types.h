@@ -119,7 +119,7 @@ struct IcpState {
     uint32_t n_corr[kHistory];      // accepted correspondences per iteration (all ranks)
     IcpProgress *progress;          // host-mapped progress block (nullptr: not published)
     int32_t exchange_failed;        // a peer's sums did not arrive in time (multi-GPU direct exchange)
-    int32_t pad_;
+    int32_t acc_overflow;           // a workgroup's sum did not fit the fixed-point accumulators (|value| >= 2^50)
 };
 
 // Index into the 16 closed-form sums of AlignClouds (Registration.cpp:59-94):
