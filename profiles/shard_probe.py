@@ -7,7 +7,7 @@ import sage_icp_amd as sage
 from sage_icp_amd import synthetic as syn
 wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
 w = syn.make_workload(wl, lambda: sage.VoxelHashMap(syn.WORKLOADS[wl]["voxel"], 100.0))
-p = syn.PARAMS["cold"]
+p = syn.PARAMS[sys.argv[2] if len(sys.argv) > 2 else "cold"]
 for N in (1, 2, 4, 8):
     n = len(w["scan"]) // N
     f = sage.Frame(w["map"], w["scan"][:n])
