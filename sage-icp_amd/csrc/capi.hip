@@ -796,7 +796,9 @@ int sync_mirror(const sageicp_map *m) {
 // The compact copy the scan reads (kernels.hip, k_derive_cand): rebuilt from the HBM copy of the
 // map when that has changed (mirror refresh, device-side update, clone).  One pass over the hash
 // table and the live points; the ICP loop that follows reads the map ~150 times.
-int ensure_cand(const sageicp_map *m) {
+// (`derive` false: the coming search scans the full records — small frames, sparse voxels — so only
+// the allocation is kept in step and the copy stays marked stale for the search that wants it)
+int ensure_cand(const sageicp_map *m, bool derive = true) {
     hipStream_t s = m->sc.stream;
     const size_t slots = m->d_blocks_cap * static_cast<size_t>(m->host.cap);
     if (!m->d_cand_flags) {
@@ -810,7 +812,7 @@ int ensure_cand(const sageicp_map *m) {
         m->d_cand_slots = slots;
         m->cand_stale = true;
     }
-    if (!m->cand_stale) return SAGEICP_OK;
+    if (!m->cand_stale || !derive) return SAGEICP_OK;
     HIPCHK(hipMemsetAsync(m->d_cand_flags, 0, 16, s));
     if (m->d_table && m->d_pts && slots)
         launch_derive_cand(m->d_table, static_cast<uint32_t>(m->d_table_cap), m->d_pts, m->d_cand,
@@ -1075,6 +1077,16 @@ static bool sparse_voxels(const sageicp_map *m) {
     return mp < 6 * mv;
 }
 
+// Does the scan of `n` queries read the compact copy behind its fp32 filter?  Worth it where scans
+// are long and bytes are what the kernel is made of: frames of 40k+ points against voxels holding
+// 6+ points on average (c2: +6 %, c4: +10 %; c1, c5 and the streamed 24k-point frames lose 4-5 %
+// with it; SAGEICP_FILTER=0/1 overrides).  Off for a negative or NaN sem_th, where a larger
+// distance can scale to a smaller one and the filter's thresholds do not exist.
+static bool wants_filter(const sageicp_map *m, uint64_t n, double sem_th) {
+    const int want = env_int("SAGEICP_FILTER", (n >= 40000 && !sparse_voxels(m)) ? 1 : 0);
+    return sem_th >= 0.0 && want != 0;
+}
+
 // k_icp's arguments for a search of `n` queries against the HBM copy of `m`
 IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, double sem_th, int lw) {
     const Scratch &sc = m->sc;
@@ -1100,12 +1112,8 @@ IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, 
     {
         const double k1 = (1.0 + 1.0 / 1024.0) * (1.0 + 1e-6);
         const double inf = std::numeric_limits<double>::infinity();
-        // worth it where scans are long and bytes are what the kernel is made of: frames of 40k+
-        // points against voxels holding 6+ points on average (c2: +6 %, c4: +10 %; c1, c5 and the
-        // streamed 24k-point frames lose 4-5 % with it; SAGEICP_FILTER=0/1 overrides)
-        const int want = env_int("SAGEICP_FILTER", (n >= 40000 && !sparse_voxels(m)) ? 1 : 0);
-        const bool filt = sem_th >= 0.0 && want != 0 && env_int("SAGEICP_NO_FILTER", 0) == 0;
-        ip.filter = (sem_th >= 0.0 && want != 0) ? 1 : 0;
+        const bool filt = wants_filter(m, n, sem_th) && env_int("SAGEICP_NO_FILTER", 0) == 0;
+        ip.filter = wants_filter(m, n, sem_th) ? 1 : 0;
         ip.filt_inv_diff = filt ? k1 : inf;
         ip.filt_inv_same = filt ? (sem_th > 0.0 ? k1 / sem_th : inf) : inf;
         ip.filt_slack = std::ldexp(1.0, -44) * 1025.0 * (1.0 + 1e-6);
@@ -1130,6 +1138,7 @@ IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, 
     ip.nwaves = static_cast<unsigned>((n + qw - 1) / qw);
 #ifdef SAGE_ICP_DELAY_PROBE
     ip.dbg_delay = static_cast<unsigned>(env_int("SAGEICP_DBG_DELAY", 0));
+    ip.dbg_repeat = static_cast<unsigned>(env_int("SAGEICP_DBG_REPEAT", 0));
 #endif
     return ip;
 }
@@ -1165,7 +1174,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
 
     const int lw = icp_lw(n, sparse_voxels(m));
     const int blocks = n ? icp_blocks_for(static_cast<int>(n), lw) : 1;
-    if ((rc = ensure_cand(m))) return rc;
+    if ((rc = ensure_cand(m, wants_filter(m, n, sem_th)))) return rc;
     if ((rc = sc.reserve_sort(n))) return rc;
     if ((rc = sc.reserve_partials(static_cast<size_t>(blocks)))) return rc;
     IcpParams ip = icp_params(m, sc.d_sorted, n, sem_th, lw);
@@ -1462,7 +1471,7 @@ int register_sharded(const sageicp_map *m, const double *h_frame, const Point4 *
             Scratch &sc = mk->sc;
             if ((r = sc.reserve_frame(cnt))) return r;
             const int lw = icp_lw(cnt, sparse_voxels(mk));
-            if ((r = ensure_cand(mk))) return r;
+            if ((r = ensure_cand(mk, wants_filter(mk, cnt, sem_th)))) return r;
             if ((r = sc.reserve_sort(cnt))) return r;
             if ((r = sc.reserve_partials(static_cast<size_t>(cnt ? icp_blocks_for(static_cast<int>(cnt), lw) : 1)))) return r;
             mine = sc.d_frame;
@@ -1857,7 +1866,7 @@ int sageicp_get_correspondences(const sageicp_map *m, const double *q, uint64_t 
                       m->host.voxel_size, sc.d_keys, sc.d_vals, sc.d_sort_temp, sc.sort_temp_bytes_,
                       s));
     const int lw = icp_lw(n, sparse_voxels(m));
-    if ((rc = ensure_cand(m))) return rc;
+    if ((rc = ensure_cand(m, wants_filter(m, n, sem_th)))) return rc;
     const IcpParams ip = icp_params(m, sc.d_sorted, n, sem_th, lw);     // identity pose, no loop state
     launch_rows(ip, s);
     launch_icp(ip, lw, false, s);

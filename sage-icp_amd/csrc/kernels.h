@@ -67,6 +67,7 @@ struct IcpParams {
     unsigned nwaves;          // waves that own queries: ceil(n / (64 >> lw))
 #ifdef SAGE_ICP_DELAY_PROBE
     unsigned dbg_delay;       // probe builds: ticks (100 MHz) a wave waits for "the pose" after its start
+    unsigned dbg_repeat;      // probe builds: extra passes of the whole body inside one launch (warm L2s)
 #endif
 };
 

@@ -342,6 +342,14 @@ void k_icp(IcpParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     if (P.check_done && P.st->done) return;
     icp_body<LW, FUSED, BIG, FILT>(P, smem);
+#ifdef SAGE_ICP_DELAY_PROBE
+    // probe: the same pass again inside the launch — what an iteration costs on L2s that were not
+    // emptied by a kernel boundary (its sums are added a second time: the solve does not care)
+    for (unsigned r = 0; r < P.dbg_repeat; ++r) {
+        __syncthreads();
+        icp_body<LW, FUSED, BIG, FILT>(P, smem);
+    }
+#endif
 }
 
 template <int LW, bool FUSED, bool BIG, bool FILT>
