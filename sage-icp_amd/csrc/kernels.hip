@@ -255,6 +255,11 @@ struct Query {
     double x, y, z, l;
     int kx, ky, kz;
 };
+// QUAD: the lanes of a query come in aligned groups of four (k_icp with 4+ lanes per query) that
+// all hold the same point: lane a < 3 of a quad then divides axis a only (an fp64 divide is ~15
+// instructions) and the three voxel indices are handed round by quad broadcasts — the same
+// divisions, a third of them per lane.
+template <bool QUAD = false>
 __device__ __forceinline__ Query make_query(const Point4 &f, const IcpState *st, int apply_pose,
                                             double voxel_size) {
     Query q;
@@ -266,9 +271,18 @@ __device__ __forceinline__ Query make_query(const Point4 &f, const IcpState *st,
         q.y = R[3] * f.x + R[4] * f.y + R[5] * f.z + T[5];
         q.z = R[6] * f.x + R[7] * f.y + R[8] * f.z + T[6];
     }
-    q.kx = static_cast<int>(q.x / voxel_size);
-    q.ky = static_cast<int>(q.y / voxel_size);
-    q.kz = static_cast<int>(q.z / voxel_size);
+    if constexpr (QUAD) {
+        const unsigned a = threadIdx.x & 3u;
+        const double num = a == 0u ? q.x : (a == 1u ? q.y : q.z);
+        const unsigned k = static_cast<unsigned>(static_cast<int>(num / voxel_size));
+        q.kx = static_cast<int>(dpp_u32<0x00>(k));       // quad_perm [0,0,0,0]
+        q.ky = static_cast<int>(dpp_u32<0x55>(k));       // quad_perm [1,1,1,1]
+        q.kz = static_cast<int>(dpp_u32<0xAA>(k));       // quad_perm [2,2,2,2]
+    } else {
+        q.kx = static_cast<int>(q.x / voxel_size);
+        q.ky = static_cast<int>(q.y / voxel_size);
+        q.kz = static_cast<int>(q.z / voxel_size);
+    }
     return q;
 }
 
@@ -429,7 +443,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
         __builtin_amdgcn_sched_barrier(0);
     }
 #endif
-    const Query s = make_query(f, P.st, P.apply_pose, P.voxel_size);
+    const Query s = make_query<(W >= 4)>(f, P.st, P.apply_pose, P.voxel_size);
     const bool stale = valid && (static_cast<uint32_t>(s.kx) != rk.x || static_cast<uint32_t>(s.ky) != rk.y ||
                                  static_cast<uint32_t>(s.kz) != rk.z);
     unsigned occ = rk.w;
@@ -716,11 +730,35 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
     const double bound = seg_min_f64<W>(best);
     fb = bound;                                // (set_thresholds runs at the start of the scan)
     unsigned need = P.keep_all;
+    if constexpr (W >= 4) {
+        // The 26 bound tests are the same for every lane of the query: lane a < 3 takes the x-layer
+        // a (nine voxels, one add and one compare each on top of the shared gy + gz sums), the
+        // layers meet in two DPP exchanges.  Same operands, same association: the same mask as
+        // the loop below, in 40 instructions instead of 100.
+        const unsigned a = ci & 3u;
+        const double ga = a == 0u ? gx[0] : (a == 2u ? gx[2] : 0.0);
+        unsigned layer = 0u;
 #pragma unroll
-    for (int v = 0; v < 27; ++v) {
-        if (v == static_cast<int>(kHome)) continue;
-        const double lb = gx[v / 9] + (gy[(v / 3) % 3] + gz[v % 3]);
-        need |= (lb <= bound) ? (1u << v) : 0u;
+        for (int b = 0; b < 3; ++b) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double lb = ga + (gy[b] + gz[c]);
+                layer |= (lb <= bound) ? (1u << (3 * b + c)) : 0u;
+            }
+        }
+        layer = (a < 3u && ci < 4u) ? layer << (9u * a) : 0u;
+        layer |= dpp_u32<kDppXor1>(layer);
+        layer |= dpp_u32<kDppXor2>(layer);          // lanes 0..3 of the query now hold all three layers
+        if (W >= 8) layer |= dpp_u32<kDppHalfMirror>(layer);
+        if (W >= 16) layer |= dpp_u32<kDppMirror>(layer);
+        need |= layer & ~(1u << kHome);
+    } else {
+#pragma unroll
+        for (int v = 0; v < 27; ++v) {
+            if (v == static_cast<int>(kHome)) continue;
+            const double lb = gx[v / 9] + (gy[(v / 3) % 3] + gz[v % 3]);
+            need |= (lb <= bound) ? (1u << v) : 0u;
+        }
     }
     scan(need & occ & ~(1u << kHome), nullptr, false, 0u);
 
@@ -736,15 +774,27 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
     NN_T(3);
 
     if (P.counters) {                          // C_q and pairs handed out, summed over the wave
-        unsigned a = (valid && ci == 0u) ? lrow[kRowCq] : 0u, b = (valid && ci == 0u) ? npairs : 0u;
+        // (both fit 16 bits per query: one packed value goes through the four DPP exchanges inside
+        // the rows of 16 lanes, four v_readlane collect the rows; the wave's private slot takes the
+        // sums as fire-and-forget atomics — a read-modify-write would hold the wave for a round trip)
+        const unsigned long long ab = (valid && ci == 0u)
+                                          ? (static_cast<unsigned long long>(lrow[kRowCq]) << 32) | npairs : 0ull;
+        unsigned lo = static_cast<unsigned>(ab), hi = static_cast<unsigned>(ab >> 32);
+        lo += dpp_u32<kDppXor1>(lo);        hi += dpp_u32<kDppXor1>(hi);
+        lo += dpp_u32<kDppXor2>(lo);        hi += dpp_u32<kDppXor2>(hi);
+        lo += dpp_u32<kDppHalfMirror>(lo);  hi += dpp_u32<kDppHalfMirror>(hi);
+        lo += dpp_u32<kDppMirror>(lo);      hi += dpp_u32<kDppMirror>(hi);
+        unsigned b = 0u, a = 0u;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            a += __shfl_xor(a, d, 64);
-            b += __shfl_xor(b, d, 64);
+        for (int r = 0; r < 4; ++r) {
+            b += static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(lo), 16 * r));
+            a += static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(hi), 16 * r));
         }
         if (lane == 0 && wave_id < P.nwaves) {
-            P.counters[2u * wave_id] += a;     // private slot per wave: no contention
-            P.counters[2u * wave_id + 1u] += b;
+            (void)__hip_atomic_fetch_add(&P.counters[2u * wave_id], static_cast<unsigned long long>(a),
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_add(&P.counters[2u * wave_id + 1u], static_cast<unsigned long long>(b),
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 
