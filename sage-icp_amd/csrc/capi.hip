@@ -506,15 +506,9 @@ struct Prep {
                     runs.emplace_back(a, hi);
                     a = hi;
                 }
-                const long long B = 1ll << 19;
                 auto replay = [&](size_t r) {
                     const uint32_t a = runs[r].first, b = runs[r].second;
-                    for (uint32_t i = a; i < b; ++i) {
-                        const unsigned long long k = h_keys[i];
-                        h_hash[i] = reference_voxel_hash(static_cast<int32_t>(static_cast<long long>((k >> 40) & 0xFFFFFu) - B),
-                                                         static_cast<int32_t>(static_cast<long long>((k >> 20) & 0xFFFFFu) - B),
-                                                         static_cast<int32_t>(static_cast<long long>(k & 0xFFFFFu) - B));
-                    }
+                    for (uint32_t i = a; i < b; ++i) h_hash[i] = static_cast<uint32_t>(h_keys[i] & 0xFFFFFu);   // hashed on the device
                     std::vector<uint32_t> part;
                     part.reserve(b - a);
                     if (!RobinOrderReplay::iteration_order(h_hash.data() + a, b - a, a, part, &rscratch[r & 7])) {

@@ -167,8 +167,8 @@ struct VdsParams {
     uint32_t *sort_key;                // [2n]
     uint32_t *sort_val;                // [2n]
     int *overflow;                     // set when a voxel index does not fit the key
-    unsigned long long *out_keys;      // optional [n]: (group << 60 | vx+2^19 << 40 | vy.. << 20 | vz..)
-                                       // of every survivor, in output order
+    unsigned long long *out_keys;      // optional [n]: (group << 60) | the reference's 20-bit VoxelHash of
+                                       // every survivor's voxel, in output order
 };
 size_t vds_sort_temp_bytes(int n);
 void launch_vds_permute(const Point4 *in, const uint32_t *perm, uint32_t n, Point4 *out, hipStream_t s);

@@ -102,8 +102,10 @@ __global__ __launch_bounds__(256) void k_vds_count(const uint32_t *sorted_key, i
     if (i == n - 1 && !here) *n_kept = static_cast<uint32_t>(n);
 }
 
-// survivors in group-major arrival order; optionally their (group, voxel) keys for the host's
-// replay of the reference's emission order (robin_order.hpp)
+// survivors in group-major arrival order; optionally, for the host's replay of the reference's
+// emission order (robin_order.hpp), what it needs of each survivor's key: the label group (bits
+// 60..63) and the reference's 20-bit VoxelHash of the voxel (core/VoxelHashMap.hpp:72-77; bits
+// 0..19) — hashed here, one lane per survivor, instead of by the replaying host thread
 __global__ __launch_bounds__(256) void k_vds_gather(const Point4 *tmp, const uint32_t *sorted_val,
                                                     const uint32_t *n_kept, Point4 *out,
                                                     const uint32_t *slot_of,
@@ -113,7 +115,15 @@ __global__ __launch_bounds__(256) void k_vds_gather(const Point4 *tmp, const uin
     if (i >= *n_kept) return;
     const uint32_t src = sorted_val[i];
     out[i] = tmp[src];
-    if (out_keys) out_keys[i] = keys[slot_of[src]];
+    if (out_keys) {
+        const unsigned long long k = keys[slot_of[src]];
+        const long long B = 1ll << 19;
+        const uint32_t vx = static_cast<uint32_t>(static_cast<int32_t>(static_cast<long long>((k >> 40) & 0xFFFFFu) - B));
+        const uint32_t vy = static_cast<uint32_t>(static_cast<int32_t>(static_cast<long long>((k >> 20) & 0xFFFFFu) - B));
+        const uint32_t vz = static_cast<uint32_t>(static_cast<int32_t>(static_cast<long long>(k & 0xFFFFFu) - B));
+        const uint32_t h = ((1u << 20) - 1u) & (vx * 73856093u ^ vy * 19349663u ^ vz * 83492791u);
+        out_keys[i] = (k & 0xF000000000000000ull) | h;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_vds_permute(const Point4 *in, const uint32_t *perm, uint32_t n,
