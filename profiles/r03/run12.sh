@@ -1,4 +1,4 @@
-# round-3 evidence on the final code: suite, smoke, rocprofv3 sets for c2-cold and c4-steady, the driver's bench command,
+# round-3 evidence on the final code (re-run after the lane-split bound tests / divisions and the device-side hashing): suite, smoke, rocprofv3 sets for c2-cold and c4-steady, the driver's bench command,
 # other workloads, stream (plain / LocalMap every frame / prefetch), k_fin phases
 timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/gputests_final.txt 2>&1; grep -n "passed\|failed" gpurun_out/gputests_final.txt; grep -n "Error\|assert" gpurun_out/gputests_final.txt | head
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
@@ -13,3 +13,6 @@ done
 timeout 300 python profiles/stream_probe.py > gpurun_out/stream_final.txt 2>&1; grep "per frame" gpurun_out/stream_final.txt
 STREAM_LOCALMAP=1 timeout 300 python profiles/stream_probe.py > gpurun_out/stream_localmap_final.txt 2>&1; grep "per frame\|LocalMap() per" gpurun_out/stream_localmap_final.txt
 STREAM_PREFETCH=1 timeout 300 python profiles/stream_probe.py > gpurun_out/stream_prefetch_final.txt 2>&1; grep "per frame" gpurun_out/stream_prefetch_final.txt
+timeout 600 python profiles/fin_phases.py c2 c4 > gpurun_out/fin_phases_final.txt 2>&1; grep "sum (" gpurun_out/fin_phases_final.txt
+timeout 600 python profiles/shard_probe.py c2 cold > gpurun_out/shard_c2_final.txt 2>&1; cat gpurun_out/shard_c2_final.txt
+timeout 900 python profiles/shard_probe.py c4 steady > gpurun_out/shard_c4_final.txt 2>&1; cat gpurun_out/shard_c4_final.txt
