@@ -189,3 +189,28 @@ def test_multi_device_map_replicates_mutations_on_the_host(sage):
     assert a.Empty() and not c.Empty()
     with pytest.raises(sage.SageIcpError):
         a.set_devices(list(range(9)))
+
+
+def test_round3_entries_on_the_host_side(sage):
+    """entries added with ABI version 2 that need no device: which copy of a map is the authority,
+    Pointcloud() of a host-authoritative map with a short buffer, what a communicator without an
+    RCCL side reports, prefetch cancel, null arguments"""
+    import ctypes as C
+    L = sage.lib()
+    m = sage.VoxelHashMap(1.0, 100.0)
+    pts = np.array([[0.5, 0.5, 0.5, 40.0], [0.6, 0.5, 0.5, 40.0], [5.5, 0.5, 0.5, 0.0]])
+    m.AddPoints(pts)
+    assert not m.resident() and L.sageicp_map_resident(None) == 0
+    part = np.full((2, 4), -1.0)
+    assert L.sageicp_map_pointcloud(m._h, part.ctypes.data_as(C.POINTER(C.c_double)), 2) == 3
+    assert np.array_equal(part, m.Pointcloud()[:2])
+    assert L.sageicp_map_pointcloud(m._h, None, 0) == 3 and L.sageicp_map_pointcloud(None, None, 0) == 0
+    comm = sage.Comm(None, 1, 4, 0)                       # no RCCL side, nothing connected yet
+    info = comm.describe()
+    assert (info["rank"], info["nranks"], info["has_rccl"], info["rccl_ranks"], info["rccl_rank"]) == (1, 4, 0, -1, -1)
+    assert info["p2p_connected"] == 0 and info["p2p_enabled"] == 0 and info["p2p_poisoned"] == 0
+    assert L.sageicp_comm_describe(None, None) == sage.ERR_INVALID
+    p = sage.SageICP(sage.make_pipeline_config())
+    p.prefetch(np.zeros((5, 4)))
+    p.prefetch_cancel()                                    # nothing started yet: a no-op that must not hang
+    assert L.sageicp_pipeline_prefetch_cancel(None) == sage.ERR_INVALID
