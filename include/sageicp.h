@@ -126,6 +126,12 @@ uint64_t sageicp_map_pointcloud(const sageicp_map *map, double *out_xyzl, uint64
 /* 1 while the HBM copy of the map is the authority (device-side updates; Pointcloud() and
  * RegisterFrame keep it so), 0 while the host copy is (AddPoints / Update on the host, Clear). */
 int sageicp_map_resident(const sageicp_map *map);
+/* Point slots (32 B each) the map's voxel storage occupies, free regions included — the footprint of
+ * the point array in HBM and on the host.  Voxels live in size-classed regions (4 / 8 / 16 points,
+ * then max_points_per_voxel): a voxel starts in the smallest and moves up when it fills, so a map
+ * of sparsely filled voxels does not pay max_points_per_voxel slots for each.  SAGEICP_SIZE_CLASSES=0
+ * in the environment when the map is created gives every voxel a full-size region instead. */
+uint64_t sageicp_map_point_slots(const sageicp_map *map);
 /* Push pending host-side changes to the HBM mirror now (otherwise done lazily by the next
  * search).  Lets a caller keep the refresh out of a timed region. */
 int sageicp_map_sync(const sageicp_map *map);

@@ -144,6 +144,7 @@ _SIGNATURES = [
     ("sageicp_map_update_pose_device", C.c_int, [C.c_void_p, _dp, C.c_uint64, _dp]),
     ("sageicp_map_pointcloud", C.c_uint64, [C.c_void_p, _dp, C.c_uint64]),
     ("sageicp_map_resident", C.c_int, [C.c_void_p]),
+    ("sageicp_map_point_slots", C.c_uint64, [C.c_void_p]),
     ("sageicp_map_sync", C.c_int, [C.c_void_p]),
     ("sageicp_get_correspondences", C.c_int,
      [C.c_void_p, _dp, C.c_uint64, C.c_double, C.c_double, _dp, _dp, _u64p, _i64p]),
@@ -248,7 +249,7 @@ class Frame:
             raise SageIcpError(ERR_HIP, (lib().sageicp_last_error() or b"").decode())
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:       # (None: interpreter shutdown)
             lib().sageicp_frame_destroy(self._h)
             self._h = None
 
@@ -300,7 +301,7 @@ class Comm:
         return bytes(buf)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:       # (None: interpreter shutdown)
             lib().sageicp_comm_destroy(self._h)
             self._h = None
 
@@ -328,7 +329,7 @@ class VoxelHashMap:
             raise SageIcpError(ERR_INVALID, (lib().sageicp_last_error() or b"").decode())
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:       # (None: interpreter shutdown)
             lib().sageicp_map_destroy(self._h)
             self._h = None
 
@@ -394,6 +395,10 @@ class VoxelHashMap:
     def resident(self):
         """True while the HBM copy of the map is the authority (after a device-side update)"""
         return bool(lib().sageicp_map_resident(self._h))
+
+    def point_slots(self):
+        """32-B point slots the voxel storage occupies (size-classed regions, free ones included)"""
+        return int(lib().sageicp_map_point_slots(self._h))
 
     def sync(self):
         _check(lib().sageicp_map_sync(self._h))
@@ -464,7 +469,7 @@ class SageICP:
             raise SageIcpError(ERR_INVALID, (lib().sageicp_last_error() or b"").decode())
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:       # (None: interpreter shutdown)
             lib().sageicp_pipeline_destroy(self._h)
             self._h = None
 

@@ -584,7 +584,14 @@ struct sageicp_map {
     mutable Slot *d_table = nullptr;
     mutable size_t d_table_cap = 0;      // slots
     mutable Point4 *d_pts = nullptr;
-    mutable size_t d_blocks_cap = 0;     // blocks
+    mutable size_t d_units_cap = 0;      // units (4 points) the point array holds
+    mutable size_t d_blocks_cap = 0;     // blocks the per-block arrays (d_regions, and the update's aux arrays) hold
+    mutable uint32_t *d_regions = nullptr;              // per block: (class << 28) | first unit of its region
+    mutable size_t d_regions_cap = 0;
+    mutable uint32_t *d_free_units[kMaxClasses] = {};   // device-side update: per-class stacks of free regions
+    mutable size_t d_free_units_cap[kMaxClasses] = {};
+    mutable uint32_t *d_freed = nullptr;                // regions released by one insertion pass
+    mutable size_t d_freed_cap = 0;
     mutable bool mirror_stale_all = true;
     // compact copy of d_pts for k_icp's scan (fp32 x, y, z, label), derived on the device whenever
     // the HBM copy of the map has changed since the last search
@@ -706,6 +713,42 @@ int reserve_stage(const sageicp_map *m, size_t bytes) {
     return SAGEICP_OK;
 }
 
+// The point array on the device: at least `units` units (+ one NaN point after them: a harmless
+// target for an offset of one past the end), the first `keep` units preserved.
+int reserve_device_points(const sageicp_map *m, size_t units, size_t keep) {
+    if (units <= m->d_units_cap) return SAGEICP_OK;
+    hipStream_t s = m->sc.stream;
+    Point4 *np_ = nullptr;
+    const size_t bytes = units * kUnitPoints * sizeof(Point4);
+    HIPCHK(hipMalloc(&np_, bytes + sizeof(Point4)));
+    if (keep && m->d_pts)
+        HIPCHK(hipMemcpyAsync(np_, m->d_pts, keep * kUnitPoints * sizeof(Point4), hipMemcpyDeviceToDevice, s));
+    const double qnan = std::numeric_limits<double>::quiet_NaN();
+    const Point4 pad{qnan, qnan, qnan, qnan};
+    HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(np_) + bytes, &pad, sizeof(Point4), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (m->d_pts) HIPCHK(hipFree(m->d_pts));
+    m->d_pts = np_;
+    m->d_units_cap = units;
+    m->cand_stale = true;
+    return SAGEICP_OK;
+}
+// d_regions for at least `blocks` blocks, the first `keep` preserved, the rest marked free
+int reserve_device_regions(const sageicp_map *m, size_t blocks, size_t keep) {
+    if (blocks <= m->d_regions_cap) return SAGEICP_OK;
+    hipStream_t s = m->sc.stream;
+    uint32_t *nr = nullptr;
+    HIPCHK(hipMalloc(&nr, blocks * sizeof(uint32_t)));
+    HIPCHK(hipMemsetAsync(nr, 0xFF, blocks * sizeof(uint32_t), s));      // kNoRegion
+    if (keep && m->d_regions)
+        HIPCHK(hipMemcpyAsync(nr, m->d_regions, keep * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (m->d_regions) HIPCHK(hipFree(m->d_regions));
+    m->d_regions = nr;
+    m->d_regions_cap = blocks;
+    return SAGEICP_OK;
+}
+
 // Refresh the HBM mirror from the host-authoritative map.  Everything after a (re)allocation,
 // otherwise only the slots and points written since the last sync: they are packed into one
 // pinned staging buffer, copied once and scattered by a kernel.
@@ -725,40 +768,44 @@ int sync_mirror(const sageicp_map *m) {
         m->d_table_cap = h.table.size();
         table_full = true;
     }
-    // (the host arrays grow by doubling; the map itself never holds more than the addressable
-    // 2^31 point slots — HostMap::add_point refuses the voxel that would cross the limit)
-    const size_t block_bytes = static_cast<size_t>(h.cap) * sizeof(Point4);
-    const size_t blocks_cap = std::min<size_t>(h.cnt.size(), kMaxMapPoints / static_cast<uint64_t>(h.cap));
+    // (the host arrays grow by doubling; the map itself never holds more than 2^24 units of 4
+    // points — HostMap::add_point refuses the point that would cross the limit)
+    // (sized by what the map holds, not by the host vector's doubled capacity)
     bool points_full = h.points_all_dirty || m->mirror_stale_all;
-    if (blocks_cap > m->d_blocks_cap) {
-        if (m->d_pts) HIPCHK(hipFree(m->d_pts));
-        m->d_pts = nullptr; m->d_blocks_cap = 0;
-        // (one extra point after the blocks, NaN coordinates: a harmless target for an offset of
-        // one past the end)
-        HIPCHK(hipMalloc(&m->d_pts, blocks_cap * block_bytes + sizeof(Point4)));
-        const double qnan = std::numeric_limits<double>::quiet_NaN();
-        const Point4 pad{qnan, qnan, qnan, qnan};
-        HIPCHK(hipMemcpy(reinterpret_cast<char *>(m->d_pts) + blocks_cap * block_bytes, &pad,
-                         sizeof(Point4), hipMemcpyHostToDevice));
-        m->d_blocks_cap = blocks_cap;
+    if (h.units_hi > m->d_units_cap) {
+        const size_t want = std::min<size_t>(kMaxUnits, static_cast<size_t>(h.units_hi) + h.units_hi / 8 + 1024);
+        if ((rc = reserve_device_points(m, want, 0))) return rc;
         points_full = true;
+    }
+    bool regions_full = h.regions_all_dirty || m->mirror_stale_all;
+    if (h.regions.size() > m->d_regions_cap) {
+        if ((rc = reserve_device_regions(m, h.regions.size(), 0))) return rc;
+        regions_full = true;
+    }
+    if (regions_full && h.blocks_hi) {
+        HIPCHK(hipMemcpyAsync(m->d_regions, h.regions.data(), h.blocks_hi * sizeof(uint32_t),
+                              hipMemcpyHostToDevice, s));
+        any = true;
     }
     if (table_full) {
         HIPCHK(hipMemcpyAsync(m->d_table, h.table.data(), h.table.size() * sizeof(Slot),
                               hipMemcpyHostToDevice, s));
         any = true;
     }
-    if (points_full && h.blocks_hi) {
-        HIPCHK(hipMemcpyAsync(m->d_pts, h.pts.data(), h.blocks_hi * block_bytes,
+    if (points_full && h.units_hi) {
+        HIPCHK(hipMemcpyAsync(m->d_pts, h.pts.data(), static_cast<size_t>(h.units_hi) * kUnitPoints * sizeof(Point4),
                               hipMemcpyHostToDevice, s));
         any = true;
     }
     const size_t ns = table_full ? 0 : h.dirty_slots.size();
     const size_t np = points_full ? 0 : h.dirty_pts.size();
-    if (ns || np) {
-        // staging layout: [slot idx][point idx][slot values][point values], 32-B aligned parts
+    const size_t nr = regions_full ? 0 : h.dirty_regions.size();
+    if (ns || np || nr) {
+        // staging layout: [slot idx][point idx][region idx][region values][slot values][point values],
+        // 32-B aligned parts
         auto up = [](size_t x) { return (x + 31) & ~static_cast<size_t>(31); };
-        const size_t o_si = 0, o_pi = up(o_si + ns * 4), o_sv = up(o_pi + np * 4),
+        const size_t o_si = 0, o_pi = up(o_si + ns * 4), o_ri = up(o_pi + np * 4), o_rv = up(o_ri + nr * 4),
+                     o_sv = up(o_rv + nr * 4),
                      o_pv = up(o_sv + ns * sizeof(Slot)), total = o_pv + np * sizeof(Point4);
         if ((rc = reserve_stage(m, total))) return rc;
         char *hs = static_cast<char *>(m->h_stage);
@@ -768,8 +815,12 @@ int sync_mirror(const sageicp_map *m) {
         Point4 *pv = reinterpret_cast<Point4 *>(hs + o_pv);
         for (size_t i = 0; i < ns; ++i) { si[i] = h.dirty_slots[i]; sv[i] = h.table[h.dirty_slots[i]]; }
         for (size_t i = 0; i < np; ++i) { pi[i] = h.dirty_pts[i]; pv[i] = h.pts[h.dirty_pts[i]]; }
+        uint32_t *ri = reinterpret_cast<uint32_t *>(hs + o_ri), *rv = reinterpret_cast<uint32_t *>(hs + o_rv);
+        for (size_t i = 0; i < nr; ++i) { ri[i] = h.dirty_regions[i]; rv[i] = h.regions[h.dirty_regions[i]]; }
         HIPCHK(hipMemcpyAsync(m->d_stage, m->h_stage, total, hipMemcpyHostToDevice, s));
         char *ds = static_cast<char *>(m->d_stage);
+        launch_scatter_u32(reinterpret_cast<uint32_t *>(ds + o_ri), reinterpret_cast<uint32_t *>(ds + o_rv),
+                           static_cast<uint32_t>(nr), m->d_regions, s);
         launch_scatter_slots(reinterpret_cast<uint32_t *>(ds + o_si), reinterpret_cast<Slot *>(ds + o_sv),
                              static_cast<uint32_t>(ns), m->d_table, s);
         launch_scatter_points(reinterpret_cast<uint32_t *>(ds + o_pi),
@@ -794,7 +845,7 @@ int sync_mirror(const sageicp_map *m) {
 // the allocation is kept in step and the copy stays marked stale for the search that wants it)
 int ensure_cand(const sageicp_map *m, bool derive = true) {
     hipStream_t s = m->sc.stream;
-    const size_t slots = m->d_blocks_cap * static_cast<size_t>(m->host.cap);
+    const size_t slots = m->d_units_cap * kUnitPoints;
     if (!m->d_cand_flags) {
         HIPCHK(hipMalloc(&m->d_cand_flags, 16));
         HIPCHK(hipMemsetAsync(m->d_cand_flags, 0, 16, s));
@@ -809,8 +860,8 @@ int ensure_cand(const sageicp_map *m, bool derive = true) {
     if (!m->cand_stale || !derive) return SAGEICP_OK;
     HIPCHK(hipMemsetAsync(m->d_cand_flags, 0, 16, s));
     if (m->d_table && m->d_pts && slots)
-        launch_derive_cand(m->d_table, static_cast<uint32_t>(m->d_table_cap), m->d_pts, m->d_cand,
-                           static_cast<uint32_t>(m->host.cap), slots, m->d_cand_flags, s);
+        launch_derive_cand(m->d_table, static_cast<uint32_t>(m->d_table_cap), m->d_regions, m->d_pts, m->d_cand,
+                           slots, m->d_cand_flags, s);
     HIPCHK(hipGetLastError());
     m->cand_stale = false;
     return SAGEICP_OK;
@@ -833,6 +884,19 @@ int ensure_host(const sageicp_map *m) {
     std::vector<Slot> tab(m->d_table_cap);
     std::vector<uint8_t> zeros(std::max<uint32_t>(c.blocks_hi, 1));
     std::vector<uint32_t> fl(std::max<uint32_t>(c.free_count, 1));
+    std::vector<uint32_t> regs(std::max<uint32_t>(c.blocks_hi, 1));
+    std::vector<uint32_t> fu[kMaxClasses];
+    const uint32_t *fu_ptr[kMaxClasses];
+    uint32_t fu_n[kMaxClasses];
+    for (int k = 0; k < kMaxClasses; ++k) {
+        fu_n[k] = static_cast<uint32_t>(std::max(0, c.free_units_count[k]));
+        fu[k].resize(std::max<uint32_t>(fu_n[k], 1));
+        fu_ptr[k] = fu[k].data();
+        if (fu_n[k])
+            HIPCHK(hipMemcpyAsync(fu[k].data(), m->d_free_units[k], fu_n[k] * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    }
+    if (c.blocks_hi)
+        HIPCHK(hipMemcpyAsync(regs.data(), m->d_regions, c.blocks_hi * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(tab.data(), m->d_table, tab.size() * sizeof(Slot), hipMemcpyDeviceToHost, s));
     if (c.blocks_hi)
         HIPCHK(hipMemcpyAsync(zeros.data(), m->d_zeros, c.blocks_hi, hipMemcpyDeviceToHost, s));
@@ -840,11 +904,11 @@ int ensure_host(const sageicp_map *m) {
         HIPCHK(hipMemcpyAsync(fl.data(), m->d_free, c.free_count * sizeof(uint32_t),
                               hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    h.adopt(tab, m->d_blocks_cap, c.blocks_hi, zeros.data(), fl.data(), c.free_count, c.num_voxels,
-            c.total_points);
-    if (c.blocks_hi) {
+    h.adopt(tab, std::max<size_t>(m->d_blocks_cap, c.blocks_hi), c.blocks_hi, zeros.data(), fl.data(), c.free_count,
+            c.num_voxels, c.total_points, regs.data(), m->d_units_cap, c.units_hi, fu_ptr, fu_n);
+    if (c.units_hi) {
         HIPCHK(hipMemcpyAsync(h.pts.data(), m->d_pts,
-                              static_cast<size_t>(c.blocks_hi) * h.cap * sizeof(Point4),
+                              static_cast<size_t>(c.units_hi) * kUnitPoints * sizeof(Point4),
                               hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
     }
@@ -898,21 +962,8 @@ static int reserve_update_scratch(const sageicp_map *m, size_t n, size_t nb) {
 // (re)allocate the per-block device arrays for `blocks` blocks, keeping the first `keep` blocks
 static int grow_device_blocks(const sageicp_map *m, size_t blocks, size_t keep) {
     hipStream_t s = m->sc.stream;
-    const size_t block_bytes = static_cast<size_t>(m->host.cap) * sizeof(Point4);
-    if (blocks > m->d_blocks_cap) {
-        Point4 *np_ = nullptr;
-        HIPCHK(hipMalloc(&np_, blocks * block_bytes + sizeof(Point4)));
-        if (keep && m->d_pts)
-            HIPCHK(hipMemcpyAsync(np_, m->d_pts, keep * block_bytes, hipMemcpyDeviceToDevice, s));
-        const double qnan = std::numeric_limits<double>::quiet_NaN();
-        const Point4 pad{qnan, qnan, qnan, qnan};
-        HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(np_) + blocks * block_bytes, &pad, sizeof(Point4),
-                              hipMemcpyHostToDevice, s));
-        HIPCHK(hipStreamSynchronize(s));
-        if (m->d_pts) HIPCHK(hipFree(m->d_pts));
-        m->d_pts = np_;
-        m->d_blocks_cap = blocks;
-    }
+    if (int rc = reserve_device_regions(m, blocks, keep)) return rc;
+    if (blocks > m->d_blocks_cap) m->d_blocks_cap = blocks;
     if (m->d_blocks_cap > m->d_aux_cap) {
         const size_t nb = m->d_blocks_cap;
         uint8_t *z = nullptr;
@@ -942,6 +993,54 @@ static int grow_device_blocks(const sageicp_map *m, size_t blocks, size_t keep) 
     return SAGEICP_OK;
 }
 
+// the unit allocator's device arrays: per-class stacks able to hold every region the point array
+// can be cut into, and the scratch list of one pass's released regions (at most one per point)
+static int reserve_unit_stacks(const sageicp_map *m, size_t n) {
+    hipStream_t s = m->sc.stream;
+    const HostMap &h = m->host;
+    for (int k = 0; k < h.n_classes; ++k) {
+        const size_t need = m->d_units_cap / h.class_units(k) + 1;
+        if (need <= m->d_free_units_cap[k]) continue;
+        uint32_t *nf = nullptr;
+        HIPCHK(hipMalloc(&nf, need * sizeof(uint32_t)));
+        const size_t keep = m->on_device ? static_cast<size_t>(std::max(0, m->ctr.free_units_count[k])) : 0;
+        if (keep)
+            HIPCHK(hipMemcpyAsync(nf, m->d_free_units[k], keep * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (m->d_free_units[k]) HIPCHK(hipFree(m->d_free_units[k]));
+        m->d_free_units[k] = nf;
+        m->d_free_units_cap[k] = need;
+    }
+    if (n > m->d_freed_cap) {
+        if (m->d_freed) HIPCHK(hipFree(m->d_freed));
+        m->d_freed = nullptr; m->d_freed_cap = 0;
+        const size_t c = n + n / 2 + 1024;
+        HIPCHK(hipMalloc(&m->d_freed, c * sizeof(uint32_t)));
+        m->d_freed_cap = c;
+    }
+    return SAGEICP_OK;
+}
+
+static DevMap dev_map(const sageicp_map *m) {
+    DevMap dm{};
+    dm.table = m->d_table;
+    dm.mask = static_cast<uint32_t>(m->d_table_cap - 1);
+    dm.pts = m->d_pts;
+    dm.cap = m->host.cap;
+    dm.zeros = m->d_zeros;
+    dm.slot_of = m->d_slot_of;
+    dm.free_list = m->d_free;
+    dm.ctr = m->d_ctr;
+    dm.regions = m->d_regions;
+    for (int k = 0; k < kMaxClasses; ++k) {
+        dm.free_units[k] = m->d_free_units[k];
+        dm.class_points[k] = k < m->host.n_classes ? static_cast<uint32_t>(m->host.class_points[k]) : 0u;
+    }
+    dm.freed = m->d_freed;
+    dm.n_classes = m->host.n_classes;
+    return dm;
+}
+
 // VoxelHashMap::Update(points, pose) on the device.
 // `d_points`: the points are already in HBM (the pipeline's down-sampled frame); else `xyzl` (host).
 int device_update(sageicp_map *m, const double *xyzl, uint64_t n, const double pose[7],
@@ -962,18 +1061,25 @@ int device_update(sageicp_map *m, const double *xyzl, uint64_t n, const double p
         m->ctr.num_voxels = h.num_voxels;
         m->ctr.used_slots = h.num_voxels;
         m->ctr.total_points = h.total_points;
+        m->ctr.units_hi = h.units_hi;
+        for (int k = 0; k < h.n_classes; ++k) m->ctr.free_units_count[k] = static_cast<int32_t>(h.free_units[k].size());
     }
     // capacity for the worst case (every point opens a voxel); the host rule is load <= 1/4
     const uint64_t need_blocks = static_cast<uint64_t>(m->ctr.blocks_hi) + n;
     if (need_blocks + 3 >= (1ull << kMaxBlockBits)) return fail(SAGEICP_ERR_CAPACITY, "more than 2^24 voxels");
     size_t blocks = m->d_blocks_cap;
     if (need_blocks > blocks) blocks = std::max<size_t>(need_blocks, std::max<size_t>(1024, 2 * blocks));
-    if (static_cast<uint64_t>(blocks) * h.cap > kMaxMapPoints) {
-        blocks = need_blocks;
-        if (static_cast<uint64_t>(blocks) * h.cap > kMaxMapPoints)
-            return fail(SAGEICP_ERR_CAPACITY, "voxel blocks x capacity beyond 2^31 points");
-    }
     if ((rc = grow_device_blocks(m, blocks, m->ctr.blocks_hi))) return rc;
+    // ... and of units: a point opens a voxel (one unit) or, at worst, moves a full voxel into a
+    // region of the last class
+    const uint64_t need_units = static_cast<uint64_t>(m->ctr.units_hi) + n * static_cast<uint64_t>(h.class_units(h.n_classes - 1));
+    if (need_units > kMaxUnits) return fail(SAGEICP_ERR_CAPACITY, "voxel storage beyond 2^24 units of 4 points");
+    if (need_units > m->d_units_cap) {
+        const size_t units = std::min<size_t>(kMaxUnits, std::max<size_t>(need_units, std::max<size_t>(4096, 2 * m->d_units_cap)));
+        if ((rc = reserve_device_points(m, units, m->ctr.units_hi))) return rc;
+    }
+    if ((rc = reserve_unit_stacks(m, n))) return rc;
+    m->ctr.units_cap = static_cast<uint32_t>(m->d_units_cap);
     if (!m->on_device && !(m->aux_valid && m->aux_generation == h.generation)) {
         // auxiliary arrays from the host's view of the map
         const std::vector<uint32_t> so = h.slot_of_blocks();
@@ -985,16 +1091,20 @@ int device_update(sageicp_map *m, const double *xyzl, uint64_t n, const double p
         if (!h.free_blocks.empty())
             HIPCHK(hipMemcpyAsync(m->d_free, h.free_blocks.data(), h.free_blocks.size() * sizeof(uint32_t),
                                   hipMemcpyHostToDevice, s));
+        for (int k = 0; k < h.n_classes; ++k)
+            if (!h.free_units[k].empty())
+                HIPCHK(hipMemcpyAsync(m->d_free_units[k], h.free_units[k].data(),
+                                      h.free_units[k].size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
         HIPCHK(hipStreamSynchronize(s));
         m->aux_valid = true;
         m->aux_generation = h.generation;
     }
     *m->h_ctr = m->ctr;
     m->h_ctr->n_new = m->h_ctr->n_far = m->h_ctr->overflow = 0;
+    m->h_ctr->unit_overflow = m->h_ctr->n_freed = 0;
     HIPCHK(hipMemcpyAsync(m->d_ctr, m->h_ctr, sizeof(MapCounters), hipMemcpyHostToDevice, s));
 
-    DevMap dm{m->d_table, static_cast<uint32_t>(m->d_table_cap - 1), m->d_pts, h.cap, m->d_zeros,
-              m->d_slot_of, m->d_free, m->d_ctr};
+    DevMap dm = dev_map(m);
     // table: (live + tombstoned + incoming) slots must stay within a quarter of the capacity
     if ((static_cast<uint64_t>(m->ctr.used_slots) + n) * 4 > m->d_table_cap) {
         size_t cap = 1024;
@@ -1029,6 +1139,13 @@ int device_update(sageicp_map *m, const double *xyzl, uint64_t n, const double p
     if (m->h_ctr->overflow) {
         // nothing was inserted or evicted (every kernel checks the flag first)
         return fail(SAGEICP_ERR_CAPACITY, "voxel index beyond +-2^20 in the device map update");
+    }
+    if (m->h_ctr->unit_overflow) {
+        // (the reservation above covers the worst case; a set flag means the map's storage is in an
+        // undefined state)
+        m->on_device = false;
+        m->mirror_stale_all = true;
+        return fail(SAGEICP_ERR_CAPACITY, "device map update ran out of storage units");
     }
     m->ctr = *m->h_ctr;
     m->on_device = true;
@@ -1095,7 +1212,7 @@ IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, 
     ip.table = m->d_table;
     ip.mask = static_cast<uint32_t>(m->d_table_cap - 1);
     ip.pts = m->d_pts;
-    const uint64_t pts_bytes = (static_cast<uint64_t>(m->d_blocks_cap) * m->host.cap + 1) * sizeof(Point4);
+    const uint64_t pts_bytes = (static_cast<uint64_t>(m->d_units_cap) * kUnitPoints + 1) * sizeof(Point4);
     ip.big = pts_bytes >= (1ull << 32) || env_int("SAGEICP_FORCE_BIG", 0);
     ip.pts_bytes = ip.big ? 0u : static_cast<uint32_t>(pts_bytes);
     ip.cand = m->d_cand;
@@ -1112,8 +1229,10 @@ IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, 
         ip.filt_inv_same = filt ? (sem_th > 0.0 ? k1 / sem_th : inf) : inf;
         ip.filt_slack = std::ldexp(1.0, -44) * 1025.0 * (1.0 + 1e-6);
     }
-    ip.cap_bytes = static_cast<uint32_t>(m->host.cap * sizeof(Point4));
-    ip.cap_points = static_cast<uint32_t>(m->host.cap);
+    // (rows address storage units of 4 points: kernels.hip's row_word())
+    ip.cap_bytes = static_cast<uint32_t>(kUnitPoints * sizeof(Point4));
+    ip.cap_points = static_cast<uint32_t>(kUnitPoints);
+    ip.regions = m->d_regions;
     ip.sem_th = sem_th;
     ip.dist_init = DBL_MAX;
     // scaled distance = d2 * sem_th for matching labels, d2 otherwise: >= min(sem_th, 1) * d2.
@@ -1626,6 +1745,10 @@ void sageicp_map_destroy(sageicp_map *m) {
         if (m->d_cand_flags) (void)hipFree(m->d_cand_flags);
         if (m->d_stage) (void)hipFree(m->d_stage);
         if (m->h_stage) (void)hipHostFree(m->h_stage);
+        for (int k = 0; k < kMaxClasses; ++k)
+            if (m->d_free_units[k]) (void)hipFree(m->d_free_units[k]);
+        if (m->d_regions) (void)hipFree(m->d_regions);
+        if (m->d_freed) (void)hipFree(m->d_freed);
         void *aux[] = {m->d_zeros, m->d_slot_of, m->d_free, m->d_ctr, m->up.raw, m->up.w, m->up.keys,
                        m->up.keys_alt, m->up.idx, m->up.idx_alt, m->up.head_slot, m->up.flag, m->up.rank,
                        m->up.far_flag, m->up.far_sel, m->up.n_sel, m->up.temp};
@@ -1644,20 +1767,32 @@ static int clone_on_device(const sageicp_map *src, sageicp_map *m) {
     const HostMap &h = src->host;
     m->host.configure(h.voxel_size, h.max_distance, h.basic, h.critical, h.basic_labels.data(),
                       static_cast<int>(h.basic_labels.size()));
+    m->host.n_classes = h.n_classes;                    // (the source's size classes, whatever the environment says now)
+    for (int k = 0; k < kMaxClasses; ++k) m->host.class_points[k] = h.class_points[k];
     int rc = m->sc.init(m->device);
     if (rc) return rc;
     HIPCHK(hipSetDevice(m->device));
     hipStream_t s = m->sc.stream;
     HIPCHK(hipStreamSynchronize(src->sc.stream));
-    const size_t block_bytes = static_cast<size_t>(h.cap) * sizeof(Point4);
     HIPCHK(hipMalloc(&m->d_table, src->d_table_cap * sizeof(Slot)));
     m->d_table_cap = src->d_table_cap;
     HIPCHK(hipMemcpyAsync(m->d_table, src->d_table, src->d_table_cap * sizeof(Slot),
                           hipMemcpyDeviceToDevice, s));
     m->ctr = src->ctr;
     if ((rc = grow_device_blocks(m, src->d_blocks_cap, 0))) return rc;
-    HIPCHK(hipMemcpyAsync(m->d_pts, src->d_pts, m->ctr.blocks_hi * block_bytes, hipMemcpyDeviceToDevice, s));
+    if ((rc = reserve_device_points(m, src->d_units_cap, 0))) return rc;
+    m->on_device = false;       // (reserve_unit_stacks: nothing of this map's to keep yet)
+    if ((rc = reserve_unit_stacks(m, 0))) return rc;
+    HIPCHK(hipMemcpyAsync(m->d_pts, src->d_pts, static_cast<size_t>(m->ctr.units_hi) * kUnitPoints * sizeof(Point4),
+                          hipMemcpyDeviceToDevice, s));
+    for (int k = 0; k < h.n_classes; ++k)
+        if (m->ctr.free_units_count[k] > 0)
+            HIPCHK(hipMemcpyAsync(m->d_free_units[k], src->d_free_units[k],
+                                  static_cast<size_t>(m->ctr.free_units_count[k]) * sizeof(uint32_t),
+                                  hipMemcpyDeviceToDevice, s));
     if (m->ctr.blocks_hi) {
+        HIPCHK(hipMemcpyAsync(m->d_regions, src->d_regions, m->ctr.blocks_hi * sizeof(uint32_t),
+                              hipMemcpyDeviceToDevice, s));
         HIPCHK(hipMemcpyAsync(m->d_zeros, src->d_zeros, m->ctr.blocks_hi, hipMemcpyDeviceToDevice, s));
         HIPCHK(hipMemcpyAsync(m->d_slot_of, src->d_slot_of, m->ctr.blocks_hi * sizeof(uint32_t),
                               hipMemcpyDeviceToDevice, s));
@@ -1800,8 +1935,7 @@ static int pointcloud_from_device(const sageicp_map *m, double *out, uint64_t ca
         HIPCHK(hipMalloc(&m->d_pc, c * sizeof(Point4)));
         m->d_pc_cap = c;
     }
-    const DevMap dm{m->d_table, static_cast<uint32_t>(m->d_table_cap - 1), m->d_pts, m->host.cap, m->d_zeros,
-                    m->d_slot_of, m->d_free, m->d_ctr};
+    const DevMap dm = dev_map(m);
     HIPCHK(map_pointcloud_device(dm, m->ctr.blocks_hi, m->up.far_flag, m->up.far_sel, m->up.temp,
                                  m->up.temp_bytes, m->d_pc, s));
     // (the destination is the caller's pageable buffer: the runtime stages the copy itself at
@@ -1823,6 +1957,11 @@ uint64_t sageicp_map_pointcloud(const sageicp_map *m, double *out, uint64_t cap)
 }
 
 int sageicp_map_resident(const sageicp_map *m) { return (m && m->on_device) ? 1 : 0; }
+
+uint64_t sageicp_map_point_slots(const sageicp_map *m) {
+    if (!m) return 0;
+    return static_cast<uint64_t>(m->on_device ? m->ctr.units_hi : m->host.units_hi) * kUnitPoints;
+}
 
 int sageicp_map_sync(const sageicp_map *m) {
     if (!m) return fail(SAGEICP_ERR_INVALID, "null map");

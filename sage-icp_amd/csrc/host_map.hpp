@@ -9,6 +9,15 @@
 //   Pointcloud                   VoxelHashMap.cpp:132-142
 //   Clear / Empty                VoxelHashMap.hpp:93-94
 //
+// Size-classed storage (round 3).  A voxel is a BLOCK b (its identity: count, unlabelled count, key,
+// place in the iteration order, exactly as before) whose points live in a REGION of the point
+// array: `regions[b]` = (class << 28) | first unit, a unit being kUnitPoints consecutive points
+// (128 B).  A region holds 4, 8, 16 or (basic + critical) points — the smallest class that holds
+// the voxel's count; when a voxel outgrows its region its points move to one of the next class and
+// the old region goes to that class's free list.  A two-point voxel of a 0.1 m map then costs
+// 128 B instead of 1,280 B.  Readers never need the class: a region starts at unit x kUnitPoints
+// and the count says how far it is filled (the device's neighbourhood rows carry (unit << 8) | count).
+//
 // Iteration order (Pointcloud(), far-voxel sweep) is block-pool order, not tsl::robin_map
 // bucket order; the far-voxel sweep removes EVERY voxel whose first point is out of range
 // (the reference erases while iterating its robin_map, which may skip some until a later
@@ -17,7 +26,9 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <new>
 #include <utility>
 #include <vector>
@@ -97,6 +108,12 @@ private:
 };
 
 constexpr uint64_t kHostMaxPointSlots = (1ull << 31) - 512;   // == kMaxMapPoints (kernels.h): point indices fit an int32
+constexpr uint32_t kUnitPoints = 4;                           // points per allocation unit of the point array
+constexpr uint32_t kMaxUnits = (1u << 24) - 2;                // a row word keeps 24 bits for the unit (8 for the count)
+constexpr int kMaxClasses = 4;
+constexpr uint32_t region_unit(uint32_t r) { return r & 0x0FFFFFFFu; }
+constexpr uint32_t region_class(uint32_t r) { return r >> 28; }
+constexpr uint32_t kNoRegion = 0xFFFFFFFFu;
 
 class HostMap {
 public:
@@ -110,7 +127,14 @@ public:
     std::vector<Slot> table;          // power-of-two capacity
     uint32_t mask = 0;
     uint32_t num_voxels = 0;
-    PointStore pts;                   // block b owns pts[b*cap .. b*cap+cap)
+    PointStore pts;                   // block b owns pts[unit(b) * kUnitPoints ..) for class_size(class(b)) points
+    std::vector<uint32_t> regions;    // per block: (class << 28) | first unit of its region (kNoRegion: free block)
+    int n_classes = 1;                // region sizes in points, ascending; the last one is >= cap
+    uint32_t class_points[kMaxClasses] = {40, 0, 0, 0};
+    std::vector<uint32_t> free_units[kMaxClasses];   // per class: first units of free regions (stacks)
+    uint32_t units_hi = 0;            // high-water mark of the unit allocator
+    bool regions_all_dirty = true;    // the device copy of `regions` needs a refresh
+    std::vector<uint32_t> dirty_regions;             // blocks whose region word changed since the last sync
     std::vector<uint8_t> cnt;         // points in block b (0 = block is free)
     std::vector<uint8_t> zeros;       // how many of them are unlabelled ((int)label == 0)
     std::vector<int32_t> keys;        // 3 ints per block: its voxel key
@@ -135,13 +159,29 @@ public:
         critical = c;
         cap = b + c;
         basic_labels.assign(labels, labels + nl);
+        // size classes 4 / 8 / 16 below the capacity, then the capacity (rounded up to whole units);
+        // SAGEICP_SIZE_CLASSES=0 (read when the map is created) keeps the single full-size class
+        const char *e = std::getenv("SAGEICP_SIZE_CLASSES");
+        const bool classed = !(e && e[0] == '0');
+        n_classes = 0;
+        if (classed)
+            for (uint32_t sz : {4u, 8u, 16u})
+                if (sz < static_cast<uint32_t>(cap)) class_points[n_classes++] = sz;
+        class_points[n_classes++] = (static_cast<uint32_t>(cap) + kUnitPoints - 1) / kUnitPoints * kUnitPoints;
     }
+    uint32_t class_units(uint32_t k) const { return class_points[k] / kUnitPoints; }
+    size_t first_point(uint32_t b) const { return static_cast<size_t>(region_unit(regions[b])) * kUnitPoints; }
 
     bool empty() const { return num_voxels == 0; }
 
     void clear() {
         reset_table(1024);
         pts.clear();
+        regions.clear();
+        for (auto &f : free_units) f.clear();
+        units_hi = 0;
+        regions_all_dirty = true;
+        dirty_regions.clear();
         cnt.clear();
         zeros.clear();
         keys.clear();
@@ -178,10 +218,11 @@ public:
                                                  static_cast<int32_t>(p[2] / voxel_size)) & mask];
                 if (e.blk != kEmptySlot) {       // a hint only: the home slot may hold another voxel
                     const size_t b = e.blk >> 8, c = e.blk & 255u;
-                    if (b < cnt.size()) {
+                    if (b < cnt.size() && regions[b] != kNoRegion) {
                         __builtin_prefetch(&cnt[b]);
-                        __builtin_prefetch(&pts[b * cap]);
-                        __builtin_prefetch(&pts[b * cap + (c < static_cast<size_t>(cap) ? c : 0)]);
+                        const size_t f0 = first_point(static_cast<uint32_t>(b));
+                        __builtin_prefetch(&pts[f0]);
+                        __builtin_prefetch(&pts[f0 + (c < static_cast<size_t>(cap) ? c : 0)]);
                     }
                 }
             }
@@ -200,7 +241,7 @@ public:
         bool any = false;
         for (uint32_t b = 0; b < blocks_hi; ++b) {
             if (cnt[b] == 0) continue;
-            const Point4 &p = pts[static_cast<size_t>(b) * cap];
+            const Point4 &p = pts[first_point(b)];
             const double dx = p.x - origin[0], dy = p.y - origin[1], dz = p.z - origin[2];
             if (SAGE_SQNORM3(dx * dx, dy * dy, dz * dz) > max2) {
                 erase_block(b);
@@ -213,7 +254,8 @@ public:
     uint64_t pointcloud(double *out, uint64_t capacity) const {
         uint64_t k = 0;
         for (uint32_t b = 0; b < blocks_hi; ++b) {
-            const Point4 *p = &pts[static_cast<size_t>(b) * cap];
+            if (!cnt[b]) continue;
+            const Point4 *p = &pts[first_point(b)];
             for (int j = 0; j < cnt[b]; ++j, ++k)
                 if (k < capacity) std::memcpy(out + 4 * k, &p[j], 32);
         }
@@ -224,13 +266,24 @@ public:
     // table (any slot layout, tombstones allowed), the first `bhi` point blocks, the per-block
     // unlabelled counts, the free-list stack and the counters.  The host table is rebuilt
     // tombstone-free at the same capacity, so afterwards it must be uploaded as a whole.
+    // `dregions`: the region words of blocks [0, bhi); `dfree_units[k]` / `nfree_units[k]`: the free
+    // regions of class k; units [0, uhi) of the point array are filled by the caller afterwards.
     void adopt(const std::vector<Slot> &dtab, size_t blocks_cap, uint32_t bhi, const uint8_t *dzeros,
-               const uint32_t *dfree, uint32_t nfree, uint32_t nvox, uint64_t total) {
+               const uint32_t *dfree, uint32_t nfree, uint32_t nvox, uint64_t total,
+               const uint32_t *dregions, size_t units_cap, uint32_t uhi,
+               const uint32_t *const dfree_units[kMaxClasses], const uint32_t nfree_units[kMaxClasses]) {
         reset_table(static_cast<uint32_t>(dtab.size()));
         cnt.assign(blocks_cap, 0);
         zeros.assign(blocks_cap, 0);
         keys.assign(3 * blocks_cap, 0);
-        pts.resize(blocks_cap * cap, static_cast<size_t>(bhi) * cap);     // blocks [0, bhi) filled by the caller
+        regions.assign(blocks_cap, kNoRegion);
+        if (bhi) std::memcpy(regions.data(), dregions, static_cast<size_t>(bhi) * sizeof(uint32_t));
+        for (int k = 0; k < kMaxClasses; ++k)
+            free_units[k].assign(dfree_units[k], dfree_units[k] + nfree_units[k]);
+        units_hi = uhi;
+        regions_all_dirty = false;
+        dirty_regions.clear();
+        pts.resize(units_cap * kUnitPoints, static_cast<size_t>(uhi) * kUnitPoints);   // units [0, uhi) filled by the caller
         for (const Slot &e : dtab) {
             if (e.blk == kEmptySlot || e.blk == kTombstone) continue;
             table[probe(e.x, e.y, e.z)] = e;
@@ -261,8 +314,10 @@ public:
     void clear_dirty() {
         dirty_pts.clear();
         dirty_slots.clear();
+        dirty_regions.clear();
         table_all_dirty = false;
         points_all_dirty = false;
+        regions_all_dirty = false;
     }
 
 private:
@@ -316,6 +371,16 @@ private:
         dirty_slots.push_back(s);
     }
 
+    void mark_region(uint32_t b) {
+        if (regions_all_dirty) return;
+        if (dirty_regions.size() > regions.size() / 4) {
+            regions_all_dirty = true;
+            dirty_regions.clear();
+            return;
+        }
+        dirty_regions.push_back(b);
+    }
+
     uint32_t alloc_block() {
         uint32_t b;
         if (!free_blocks.empty()) {
@@ -328,11 +393,45 @@ private:
                 cnt.resize(nb, 0);
                 zeros.resize(nb, 0);
                 keys.resize(nb * 3, 0);
-                pts.resize(nb * cap, static_cast<size_t>(blocks_hi) * cap);
+                regions.resize(nb, kNoRegion);
+                regions_all_dirty = true;          // (the device array is re-allocated with it)
+                dirty_regions.clear();
             }
-            pts.set_used(static_cast<size_t>(blocks_hi) * cap);      // what a copy of the map carries
         }
         return b;
+    }
+    // can a region of class k be had without crossing the unit limit?
+    bool region_available(uint32_t k) const {
+        return !free_units[k].empty() || static_cast<uint64_t>(units_hi) + class_units(k) <= kMaxUnits;
+    }
+    uint32_t alloc_region(uint32_t k) {
+        uint32_t u;
+        if (!free_units[k].empty()) {
+            u = free_units[k].back();
+            free_units[k].pop_back();
+        } else {
+            u = units_hi;
+            units_hi += class_units(k);
+            const size_t need = static_cast<size_t>(units_hi) * kUnitPoints;
+            if (need > pts.size()) pts.resize(std::max<size_t>(4096 * kUnitPoints, std::max(need, pts.size() * 2)), need);
+            pts.set_used(need);                    // what a copy of the map carries
+        }
+        return (k << 28) | u;
+    }
+    void free_region(uint32_t r) { free_units[region_class(r)].push_back(region_unit(r)); }
+    // move block b's `c` points into a region of the next class (its region is full); false: no room
+    bool grow_region(uint32_t b, int c) {
+        const uint32_t old = regions[b], k = region_class(old) + 1;
+        if (!region_available(k)) return false;
+        const uint32_t nr = alloc_region(k);
+        const size_t from = static_cast<size_t>(region_unit(old)) * kUnitPoints,
+                     to = static_cast<size_t>(region_unit(nr)) * kUnitPoints;
+        std::memcpy(&pts[to], &pts[from], static_cast<size_t>(c) * sizeof(Point4));
+        for (int j = 0; j < c; ++j) mark_point(to + j);
+        free_region(old);
+        regions[b] = nr;
+        mark_region(b);
+        return true;
     }
 
     int add_point(const double *p) {
@@ -346,16 +445,16 @@ private:
         const Point4 np{p[0], p[1], p[2], p[3]};
         if (table[s].blk == kEmptySlot) {
             // new voxel: its first point is taken unconditionally (VoxelHashMap.cpp:171)
-            if (free_blocks.empty() &&
-                (blocks_hi + 3u >= (1u << kMaxBlockBits) ||
-                 (static_cast<uint64_t>(blocks_hi) + 1u) * static_cast<uint64_t>(cap) > kHostMaxPointSlots))
+            if ((free_blocks.empty() && blocks_hi + 3u >= (1u << kMaxBlockBits)) || !region_available(0))
                 return 1;                    // checked BEFORE anything is touched
             if ((static_cast<uint64_t>(num_voxels) + 1) * 4 > table.size()) {
                 grow_table();
                 s = probe(vx, vy, vz);
             }
             const uint32_t b = alloc_block();
-            pts[static_cast<size_t>(b) * cap] = np;
+            regions[b] = alloc_region(0);
+            mark_region(b);
+            pts[first_point(b)] = np;
             cnt[b] = 1;
             zeros[b] = static_cast<int>(p[3]) == 0 ? 1 : 0;
             keys[3 * b] = vx; keys[3 * b + 1] = vy; keys[3 * b + 2] = vz;
@@ -363,20 +462,25 @@ private:
             ++num_voxels;
             ++total_points;
             mark_slot(s);
-            mark_point(static_cast<size_t>(b) * cap);
+            mark_point(first_point(b));
             return 0;
         }
         const uint32_t b = table[s].blk >> 8;
-        Point4 *blk = &pts[static_cast<size_t>(b) * cap];
+        Point4 *blk = &pts[first_point(b)];
         int c = cnt[b];
+        bool full = false;                   // the map's point array (not the voxel) is out of room
         auto append = [&]() {
+            if (static_cast<uint32_t>(c) == class_points[region_class(regions[b])]) {
+                if (!grow_region(b, c)) { full = true; return; }     // nothing was touched
+                blk = &pts[first_point(b)];
+            }
             blk[c] = np;
             if (static_cast<int>(p[3]) == 0) ++zeros[b];
             cnt[b] = static_cast<uint8_t>(c + 1);
             table[s].blk = (b << 8) | static_cast<uint32_t>(c + 1);
             ++total_points;
             mark_slot(s);
-            mark_point(static_cast<size_t>(b) * cap + c);
+            mark_point(first_point(b) + c);
         };
         // the incoming point has a non-zero label here; blocks without an unlabelled point (the
         // common case once a voxel is saturated) are skipped without touching their 1.3 KB
@@ -386,13 +490,13 @@ private:
                 if (static_cast<int>(blk[j].l) == 0) {
                     blk[j] = np;
                     --zeros[b];
-                    mark_point(static_cast<size_t>(b) * cap + j);
+                    mark_point(first_point(b) + j);
                     break;
                 }
         };
         if (c < basic) {
             append();
-            return 0;
+            return full ? 1 : 0;
         }
         const int label = static_cast<int>(p[3]);
         if (label == 0) return 0;
@@ -403,7 +507,7 @@ private:
         } else {
             replace_first_unlabelled();
         }
-        return 0;
+        return full ? 1 : 0;
     }
 
     void erase_block(uint32_t b) {
@@ -425,6 +529,9 @@ private:
         mark_slot(i);
         total_points -= cnt[b];
         cnt[b] = 0;
+        free_region(regions[b]);
+        regions[b] = kNoRegion;
+        mark_region(b);
         free_blocks.push_back(b);
         --num_voxels;
     }

@@ -10,7 +10,8 @@ namespace sageicp {
 // Neighbourhood row of one query: the 27 voxels around its home voxel as found in the map's hash,
 // cached across the iterations of one RegisterFrame call (the map is constant during a call and
 // the pose moves by millimetres per iteration, so a query's home voxel rarely changes).
-//   [0..26]  the hash slot's packed word (block << 8) | count of voxel (ox, oy, oz) + 1 =
+//   [0..26]  (first unit of the voxel's region << 8) | count (a unit = 4 points of the point array;
+//            kernels.hip row_word) of voxel (ox, oy, oz) + 1 =
 //            (v / 9, v / 3 % 3, v % 3) — x outer, y, z inner, the reference's enumeration order
 //            (VoxelHashMap.cpp:57-63) — or kEmptySlot
 //   [27]     C_q: points stored in the neighbourhood (the algorithmic-bytes accounting)
@@ -29,6 +30,8 @@ struct IcpParams {
     double voxel_size;
     uint32_t *rows;           // [n][kRowWords] cached neighbourhood rows
     const Slot *table;        // the open-addressed voxel hash
+    const uint32_t *regions;  // per voxel block: (class << 28) | first unit (4 points) of its region of the
+                              // point array (host_map.hpp); a row word is (unit << 8) | count
     uint32_t mask;
     const Point4 *pts;
     uint32_t pts_bytes;       // size of the point array when it is under 4 GiB (32-bit byte offsets
@@ -81,8 +84,8 @@ int icp_blocks_for(int n, int lw);
 size_t icp_lds_bytes(int lw);
 void launch_rows(const IcpParams &p, hipStream_t s);                     // (re)build every row
 // the compact copy of the map's points the scan reads (see kernels.hip)
-void launch_derive_cand(const Slot *table, uint32_t nslots, const Point4 *pts, uint4 *cand, uint32_t cap,
-                        uint64_t nslots_pts, uint32_t *flags, hipStream_t s);
+void launch_derive_cand(const Slot *table, uint32_t nslots, const uint32_t *regions, const Point4 *pts,
+                        uint4 *cand, uint64_t nslots_pts, uint32_t *flags, hipStream_t s);
 void launch_icp(const IcpParams &p, int lw, bool fused, hipStream_t s);
 
 struct GnParams {             // stand-alone AlignClouds on explicit pairs
@@ -146,6 +149,7 @@ void launch_scatter_points(const uint32_t *idx, const Point4 *vals, uint32_t n, 
                            hipStream_t s);
 void launch_scatter_slots(const uint32_t *idx, const Slot *vals, uint32_t n, Slot *table,
                           hipStream_t s);
+void launch_scatter_u32(const uint32_t *idx, const uint32_t *vals, uint32_t n, uint32_t *dst, hipStream_t s);
 void launch_sum_counters(const unsigned long long *c, int n, IcpState *st, hipStream_t s);
 
 // preprocess.hip: one level of per-label-group voxel down-sampling (optionally with the range crop)

@@ -26,7 +26,13 @@ struct MapCounters {
     uint32_t n_new;          // voxels created by the last update
     uint32_t n_far;          // voxels evicted by the last update
     uint32_t overflow;       // a voxel index beyond +-2^20 was seen (update rejected)
-    uint32_t pad;
+    uint32_t unit_overflow;  // the point array ran out of units (cannot happen: the host reserves the worst case)
+    // size-classed regions (host_map.hpp): the unit allocator's state
+    uint32_t units_hi;       // high-water mark
+    uint32_t units_cap;      // units the point array holds
+    int32_t free_units_count[4];     // entries of each class's stack of free regions
+    uint32_t n_freed;        // regions released by the last insertion pass (pushed to the stacks after it)
+    uint32_t units_base0;    // first unit of the fresh range this pass's new voxels draw from (map_update.hip)
 };
 
 struct DevMap {
@@ -38,7 +44,15 @@ struct DevMap {
     uint32_t *slot_of;       // block -> its slot (kNoSlot for a free block)
     uint32_t *free_list;
     MapCounters *ctr;
+    // size-classed regions: block b's points start at unit (regions[b] & 0x0FFFFFFF), class in the top 4 bits
+    uint32_t *regions;
+    uint32_t *free_units[4]; // per class: stack of the first units of free regions
+    uint32_t *freed;         // scratch: regions released during an insertion pass
+    uint32_t class_points[4];
+    int n_classes;
 };
+constexpr uint32_t kDevUnitPoints = 4;
+constexpr uint32_t kDevNoRegion = 0xFFFFFFFFu;
 
 struct UpdatePolicy {
     double voxel_size;

@@ -98,6 +98,27 @@ __global__ __launch_bounds__(256) void k_up_heads(const unsigned long long *keys
     if (found == kNoSlot) flag[idx[i]] = 1u;
 }
 
+// A region of class k >= 1 for a voxel that outgrew its region.  Lanes of the insertion kernel only
+// POP from the class stacks (the regions released in the pass are collected in M.freed and pushed
+// afterwards), so a plain counter decrement hands out distinct entries: the poppers that draw a
+// positive count take that entry, the others give their decrement back and take fresh units from
+// the bump pointer.  Which lane gets which region is a race — and unobservable: readers go through
+// regions[] and the iteration order of the map is the order of its blocks, not of their storage.
+// (New voxels do not come here: their class-0 regions are handed out by rank like their blocks —
+// thousands of lanes on one counter cost the pass 0.2 ms.)
+__device__ __forceinline__ uint32_t alloc_region(const DevMap &M, uint32_t k) {
+    const int old = atomicSub(&M.ctr->free_units_count[k], 1);
+    if (old > 0) return (k << 28) | M.free_units[k][old - 1];
+    atomicAdd(&M.ctr->free_units_count[k], 1);
+    const uint32_t units = M.class_points[k] / kDevUnitPoints;
+    const uint32_t u = atomicAdd(&M.ctr->units_hi, units);
+    if (u + units > M.ctr->units_cap) {
+        M.ctr->unit_overflow = 1u;
+        return kDevNoRegion;
+    }
+    return (k << 28) | u;
+}
+
 __device__ __forceinline__ bool is_basic_label(const UpdatePolicy &P, int label) {
     for (int i = 0; i < P.n_labels; ++i)
         if (P.labels[i] == label) return true;
@@ -111,12 +132,12 @@ __global__ __launch_bounds__(256) void k_up_insert(const unsigned long long *key
                                                    const uint32_t *rank, DevMap M, UpdatePolicy P) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     unsigned appended = 0;
-    const bool ok = !M.ctr->overflow;
+    const bool ok = !M.ctr->overflow && !M.ctr->unit_overflow;
     if (ok && i < n && head_slot[i] != kNonHead) {
         const unsigned long long k = keys[i];
         int vx, vy, vz;
         unpack_key(k, vx, vy, vz);
-        uint32_t s = head_slot[i], b;
+        uint32_t s = head_slot[i], b, reg;
         int c, z;
         const bool fresh = (s == kNoSlot);
         if (fresh) {
@@ -133,13 +154,21 @@ __global__ __launch_bounds__(256) void k_up_insert(const unsigned long long *key
             M.table[s].z = vz;
             c = 0;
             z = 0;
+            // class-0 region by rank: the stack's top entries first, then the fresh range
+            // k_up_before_insert set aside
+            const uint32_t fu = static_cast<uint32_t>(M.ctr->free_units_count[0]);
+            reg = (j < fu) ? M.free_units[0][fu - 1u - j]
+                           : M.ctr->units_base0 + (j - fu) * (M.class_points[0] / kDevUnitPoints);
         } else {
             const uint32_t blk = M.table[s].blk;
             b = blk >> 8;
             c = static_cast<int>(blk & 255u);
             z = M.zeros[b];
+            reg = M.regions[b];
         }
-        Point4 *blkp = M.pts + static_cast<size_t>(b) * M.cap;
+        const bool lost = reg == kDevNoRegion;       // (unit overflow: flagged, nothing is written)
+        Point4 *blkp = M.pts + static_cast<size_t>(reg & 0x0FFFFFFFu) * kDevUnitPoints;
+        uint32_t room = lost ? 0x7FFFFFFFu : M.class_points[reg >> 28];
         for (int t = i; t < n && keys[t] == k; ++t) {
             const Point4 p = w[idx[t]];
             const int label = static_cast<int>(p.l);
@@ -152,6 +181,18 @@ __global__ __launch_bounds__(256) void k_up_insert(const unsigned long long *key
                 if (is_basic_label(P, label)) replace = true;
                 else if (c < P.basic + P.critical) append = true;
                 else replace = true;
+            }
+            if (lost) continue;
+            if (append && static_cast<uint32_t>(c) == room) {
+                // the region is full: the voxel's points move to one of the next class
+                const uint32_t nr = alloc_region(M, (reg >> 28) + 1u);
+                if (nr == kDevNoRegion) continue;
+                Point4 *np_ = M.pts + static_cast<size_t>(nr & 0x0FFFFFFFu) * kDevUnitPoints;
+                for (int j = 0; j < c; ++j) np_[j] = blkp[j];
+                M.freed[atomicAdd(&M.ctr->n_freed, 1u)] = reg;
+                reg = nr;
+                blkp = np_;
+                room = M.class_points[reg >> 28];
             }
             if (append) {
                 blkp[c] = p;
@@ -170,6 +211,7 @@ __global__ __launch_bounds__(256) void k_up_insert(const unsigned long long *key
         M.table[s].blk = (b << 8) | static_cast<uint32_t>(c);
         M.zeros[b] = static_cast<uint8_t>(z);
         M.slot_of[b] = s;
+        M.regions[b] = reg;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) appended += __shfl_down(appended, off, 64);
@@ -178,10 +220,51 @@ __global__ __launch_bounds__(256) void k_up_insert(const unsigned long long *key
                   static_cast<unsigned long long>(appended));
 }
 
+// Region r of each lane (kDevNoRegion: none) back onto its class's stack; whole waves call this
+// together, in kernels that only push: one counter update per wave and class.
+__device__ __forceinline__ void push_regions(const DevMap &M, uint32_t r) {
+    const unsigned lane = threadIdx.x & 63u;
+    for (int k = 0; k < M.n_classes; ++k) {
+        const bool mine = r != kDevNoRegion && (r >> 28) == static_cast<uint32_t>(k);
+        const unsigned long long mask = __ballot(mine);
+        if (!mask) continue;
+        const int leader = __ffsll(static_cast<long long>(mask)) - 1;
+        int base = 0;
+        if (static_cast<int>(lane) == leader) base = atomicAdd(&M.ctr->free_units_count[k], __popcll(mask));
+        base = __shfl(base, leader, 64);
+        if (mine) M.free_units[k][base + __popcll(mask & ((1ull << lane) - 1ull))] = r & 0x0FFFFFFFu;
+    }
+}
+
+// regions released by the insertion pass (voxels that moved to a bigger class) onto their class stacks
+__global__ __launch_bounds__(256) void k_up_push_freed(DevMap M, uint32_t bound) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    push_regions(M, (i < bound && i < M.ctr->n_freed) ? M.freed[i] : kDevNoRegion);
+}
+
+// the fresh units this pass's new voxels take beyond the class-0 stack: [units_base0, units_hi)
+__global__ void k_up_before_insert(MapCounters *ctr, const uint32_t *rank, int n, uint32_t class0_units) {
+    if (threadIdx.x || blockIdx.x) return;
+    if (ctr->overflow) return;
+    const uint32_t n_new = rank[n];
+    const uint32_t fu = static_cast<uint32_t>(ctr->free_units_count[0]);
+    const uint32_t fresh = n_new > fu ? n_new - fu : 0u;
+    ctr->units_base0 = ctr->units_hi;
+    if (static_cast<unsigned long long>(ctr->units_hi) + static_cast<unsigned long long>(fresh) * class0_units > ctr->units_cap) {
+        ctr->unit_overflow = 1u;
+        return;
+    }
+    ctr->units_hi += fresh * class0_units;
+}
+
 __global__ void k_up_after_insert(MapCounters *ctr, const uint32_t *rank, int n) {
     if (threadIdx.x || blockIdx.x) return;
-    if (ctr->overflow) { ctr->n_new = 0; return; }
+    if (ctr->overflow || ctr->unit_overflow) { ctr->n_new = 0; return; }
     const uint32_t n_new = rank[n];
+    {
+        const uint32_t fu = static_cast<uint32_t>(ctr->free_units_count[0]);
+        ctr->free_units_count[0] = static_cast<int32_t>(fu - (n_new < fu ? n_new : fu));
+    }
     const uint32_t fc = ctr->free_count;
     const uint32_t from_free = n_new < fc ? n_new : fc;
     ctr->free_count = fc - from_free;
@@ -198,7 +281,7 @@ __global__ __launch_bounds__(256) void k_far_flags(DevMap M, UpdatePolicy P, dou
     if (b >= bound) return;
     uint32_t far = 0;
     if (!M.ctr->overflow && b < M.ctr->blocks_hi && M.slot_of[b] != kNoSlot) {
-        const Point4 p = M.pts[static_cast<size_t>(b) * M.cap];
+        const Point4 p = M.pts[static_cast<size_t>(M.regions[b] & 0x0FFFFFFFu) * kDevUnitPoints];
         const double dx = p.x - ox, dy = p.y - oy, dz = p.z - oz;
         far = (SAGE_SQNORM3(dx * dx, dy * dy, dz * dz) > P.max_dist2) ? 1u : 0u;
     }
@@ -210,6 +293,7 @@ __global__ __launch_bounds__(256) void k_far_apply(DevMap M, const uint32_t *sel
                                                    uint32_t bound) {
     const uint32_t j = blockIdx.x * 256 + threadIdx.x;
     unsigned removed = 0;
+    uint32_t r = kDevNoRegion;
     if (j < bound && j < *n_sel) {
         const uint32_t b = sel[j];
         const uint32_t s = M.slot_of[b];
@@ -219,7 +303,10 @@ __global__ __launch_bounds__(256) void k_far_apply(DevMap M, const uint32_t *sel
         M.table[s] = t;
         M.slot_of[b] = kNoSlot;
         M.free_list[M.ctr->free_count + j] = b;
+        r = M.regions[b];
+        M.regions[b] = kDevNoRegion;
     }
+    push_regions(M, r);        // (pushes only in this kernel)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) removed += __shfl_down(removed, off, 64);
     if ((threadIdx.x & 63) == 0 && removed)
@@ -264,17 +351,17 @@ __global__ __launch_bounds__(256) void k_pc_counts(DevMap M, uint32_t blocks_hi,
     }
     counts[b] = c;                 // counts[blocks_hi] = 0: its scan entry is the total
 }
-// lane per point slot: the live points of block b land at offsets[b] in block-pool order, the
-// order HostMap::pointcloud emits (host_map.hpp)
-__global__ __launch_bounds__(256) void k_pc_gather(const Point4 *pts, uint32_t cap, uint64_t nslots,
-                                                   const uint32_t *counts, const uint32_t *offsets,
-                                                   Point4 *out) {
+// lane per (block, slot of the largest class): block b's live points, found through its region,
+// land at offsets[b] in block-pool order — the order HostMap::pointcloud emits (host_map.hpp)
+__global__ __launch_bounds__(256) void k_pc_gather_regions(DevMap M, uint32_t blocks_hi, uint32_t span,
+                                                           const uint32_t *counts, const uint32_t *offsets,
+                                                           Point4 *out) {
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
-    if (i >= nslots) return;
-    const uint32_t b = static_cast<uint32_t>(i / cap), j = static_cast<uint32_t>(i % cap);
-    if (j < counts[b]) out[static_cast<size_t>(offsets[b]) + j] = pts[i];
+    const uint32_t b = static_cast<uint32_t>(i / span), j = static_cast<uint32_t>(i % span);
+    if (b >= blocks_hi || j >= counts[b]) return;
+    out[static_cast<size_t>(offsets[b]) + j] =
+        M.pts[static_cast<size_t>(M.regions[b] & 0x0FFFFFFFu) * kDevUnitPoints + j];
 }
-
 __global__ void k_rebuild_after(MapCounters *ctr) {
     if (threadIdx.x || blockIdx.x) return;
     ctr->used_slots = ctr->num_voxels;
@@ -322,9 +409,12 @@ hipError_t map_update_device(const DevMap &M, const UpdatePolicy &P, const Updat
         e = rocprim::exclusive_scan(S.temp, tb, S.flag, S.rank, 0u, static_cast<size_t>(n) + 1,
                                     rocprim::plus<uint32_t>(), s);
         if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_up_before_insert, dim3(1), dim3(64), 0, s, M.ctr, S.rank, n,
+                           M.class_points[0] / kDevUnitPoints);
         hipLaunchKernelGGL(k_up_insert, dim3(grid), dim3(256), 0, s, S.keys_alt, S.idx_alt, n, S.w,
                            S.head_slot, S.rank, M, P);
         hipLaunchKernelGGL(k_up_after_insert, dim3(1), dim3(64), 0, s, M.ctr, S.rank, n);
+        hipLaunchKernelGGL(k_up_push_freed, dim3(grid), dim3(256), 0, s, M, static_cast<uint32_t>(n));
     }
     if (blocks_hi_bound > 0) {
         const int gb = static_cast<int>((blocks_hi_bound + 255u) / 256u);
@@ -349,9 +439,10 @@ hipError_t map_pointcloud_device(const DevMap &M, uint32_t blocks_hi, uint32_t *
     hipError_t e = rocprim::exclusive_scan(temp, tb, counts, offsets, 0u, static_cast<size_t>(blocks_hi) + 1,
                                            rocprim::plus<uint32_t>(), s);
     if (e != hipSuccess) return e;
-    const uint64_t nslots = static_cast<uint64_t>(blocks_hi) * static_cast<uint64_t>(M.cap);
-    hipLaunchKernelGGL(k_pc_gather, dim3(static_cast<unsigned>((nslots + 255) / 256)), dim3(256), 0, s, M.pts,
-                       static_cast<uint32_t>(M.cap), nslots, counts, offsets, out);
+    const uint32_t span = static_cast<uint32_t>(M.cap);
+    const uint64_t nslots = static_cast<uint64_t>(blocks_hi) * span;
+    hipLaunchKernelGGL(k_pc_gather_regions, dim3(static_cast<unsigned>((nslots + 255) / 256)), dim3(256), 0, s, M,
+                       blocks_hi, span, counts, offsets, out);
     return hipGetLastError();
 }
 

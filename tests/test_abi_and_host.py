@@ -154,6 +154,47 @@ def test_host_map_survives_heavy_erase_and_reinsert(sage, oracle):
     assert np.array_equal(_sorted(a.Pointcloud()), _sorted(b.pointcloud()))
 
 
+def test_size_classed_storage_is_invisible_and_smaller(sage, oracle, monkeypatch):
+    """Voxels live in regions of 4 / 8 / 16 / max_points_per_voxel points and move up as they fill
+    (include/sageicp.h, sageicp_map_point_slots): the same map, point for point and in the same
+    Pointcloud() order, as with one full-size region per voxel — in a fraction of the storage."""
+    rng = np.random.default_rng(12)
+    maps = {}
+    for classes in ("1", "0"):
+        monkeypatch.setenv("SAGEICP_SIZE_CLASSES", classes)
+        maps[classes] = sage.VoxelHashMap(0.5, 9.0)           # the environment is read when the map is created
+    monkeypatch.delenv("SAGEICP_SIZE_CLASSES")
+    b = oracle.Map(0.5, 9.0)
+    for step in range(12):
+        c = rng.uniform(-6, 6, size=3)
+        # a dense clump (voxels climb through every class up to the 40-point cap) in a sparse cloud
+        pts = np.concatenate([rng.normal(size=(3000, 4)) * 0.6, rng.uniform(-8, 8, size=(3000, 4))]) + np.append(c, 0)
+        pts[:, 3] = rng.choice([0, 0, 40, 44, 70, 80], size=len(pts))
+        for m in maps.values():
+            m.Update(pts, c)
+        b.add_points(pts)
+        b.remove_far(c)
+        assert maps["1"].size() == maps["0"].size() == b.size()
+        assert maps["1"].num_voxels() == b.num_voxels()
+    pc = maps["1"].Pointcloud()
+    assert np.array_equal(pc, maps["0"].Pointcloud())            # same order, not only the same set
+    assert np.array_equal(_sorted(pc), _sorted(b.pointcloud()))
+    assert maps["0"].point_slots() >= 40 * maps["0"].num_voxels()
+    assert maps["1"].point_slots() >= maps["1"].size()
+    assert maps["1"].point_slots() < 0.5 * maps["0"].point_slots()
+    counts = np.unique(np.floor(pc[:, :3] / 0.5), axis=0, return_counts=True)[1]
+    assert counts.max() > 16 and (counts <= 4).sum() > 100          # both ends of the class ladder were in use
+    # a clone carries the layout along, whatever the environment says by then
+    monkeypatch.setenv("SAGEICP_SIZE_CLASSES", "0")
+    c1 = maps["1"].clone()
+    assert c1.point_slots() == maps["1"].point_slots() and np.array_equal(c1.Pointcloud(), pc)
+    # capacities below the class sizes: a single class, rounded up to whole units of 4 points
+    monkeypatch.delenv("SAGEICP_SIZE_CLASSES")
+    small = sage.VoxelHashMap(1.0, 100.0, 2, 1)
+    small.AddPoints(rng.uniform(-5, 5, size=(4000, 4)))
+    assert small.point_slots() == 4 * small.num_voxels()
+
+
 def test_synthetic_workload_is_deterministic_and_exact(sage):
     from sage_icp_amd import synthetic as syn
     mk = lambda: sage.VoxelHashMap(1.0, 100.0)
