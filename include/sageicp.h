@@ -33,7 +33,7 @@ extern "C" {
 #define SAGEICP_ERR_NO_DEVICE (-2)  /* no usable gfx950 device / HIP runtime failure at init */
 #define SAGEICP_ERR_HIP (-3)        /* a HIP call failed */
 #define SAGEICP_ERR_RCCL (-4)       /* RCCL could not be loaded or a collective failed */
-#define SAGEICP_ERR_CAPACITY (-5)   /* > 2^24 voxels, > 255 points per voxel, > 2^31 point slots, or a voxel
+#define SAGEICP_ERR_CAPACITY (-5)   /* > 2^24 voxels, > 255 points per voxel, > 2^26 point slots, or a voxel
                                      * index beyond +-2^20 */
 
 typedef struct sageicp_map sageicp_map;       /* opaque: host map + device mirror + scratch */
@@ -44,7 +44,7 @@ typedef struct sageicp_comm sageicp_comm;     /* opaque: RCCL communicator for q
  * a library whose version differs (the header shim and the Python loader do): struct layouts
  * below are part of it.   2: sageicp_stats without the three fields that had become constant
  * zeros (us_group, us_gn, resorts), with pairs_evaluated / lanes_per_query / compact_scan;
- * capacity limits 2^24 voxels / 2^31 point slots / |voxel index| < 2^20 (SAGEICP_ERR_CAPACITY);
+ * capacity limits 2^24 voxels / 2^26 point slots (sageicp_map_point_slots) / |voxel index| < 2^20 (SAGEICP_ERR_CAPACITY);
  * sageicp_comm_describe, sageicp_map_pointcloud served from the HBM copy. */
 #define SAGEICP_ABI_VERSION 2
 

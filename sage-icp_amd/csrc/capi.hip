@@ -1873,7 +1873,7 @@ int sageicp_map_add_points(sageicp_map *m, const double *xyzl, uint64_t n) {
             return fail(rc, "AddPoints reached only some devices of the map (" + w2 + "); the map must be cleared");
         }
     if (why == 1)
-        return fail(SAGEICP_ERR_CAPACITY, "map full (2^24 voxels / 2^31 point slots): stopped before point " +
+        return fail(SAGEICP_ERR_CAPACITY, "map full (2^24 voxels / 2^24 storage units of 4 points): stopped before point " +
                                               std::to_string(at) + ", the points before it are in");
     if (why == 2)
         return fail(SAGEICP_ERR_CAPACITY, "voxel index beyond +-2^20: stopped before point " +

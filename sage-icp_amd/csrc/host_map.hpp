@@ -107,7 +107,6 @@ private:
     }
 };
 
-constexpr uint64_t kHostMaxPointSlots = (1ull << 31) - 512;   // == kMaxMapPoints (kernels.h): point indices fit an int32
 constexpr uint32_t kUnitPoints = 4;                           // points per allocation unit of the point array
 constexpr uint32_t kMaxUnits = (1u << 24) - 2;                // a row word keeps 24 bits for the unit (8 for the count)
 constexpr int kMaxClasses = 4;

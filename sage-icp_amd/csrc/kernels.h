@@ -142,7 +142,6 @@ void launch_red(const RedParams &p, hipStream_t s);
 
 constexpr int kMaxPartials = 1 << 16;
 constexpr uint64_t kMaxQueries = (1ull << 26) - 1;
-constexpr uint64_t kMaxMapPoints = (1ull << 31) - 512;   // blocks x capacity: point indices fit an int32 (nn_idx)
 
 void launch_tf(Point4 *pts, int n, const IcpState *st, hipStream_t s);
 void launch_scatter_points(const uint32_t *idx, const Point4 *vals, uint32_t n, Point4 *pts,

@@ -32,7 +32,7 @@ struct MapCounters {
     uint32_t units_cap;      // units the point array holds
     int32_t free_units_count[4];     // entries of each class's stack of free regions
     uint32_t n_freed;        // regions released by the last insertion pass (pushed to the stacks after it)
-    uint32_t units_base0;    // first unit of the fresh range this pass's new voxels draw from (map_update.hip)
+    uint32_t pad;
 };
 
 struct DevMap {

@@ -98,48 +98,95 @@ __global__ __launch_bounds__(256) void k_up_heads(const unsigned long long *keys
     if (found == kNoSlot) flag[idx[i]] = 1u;
 }
 
-// A region of class k >= 1 for a voxel that outgrew its region.  Lanes of the insertion kernel only
-// POP from the class stacks (the regions released in the pass are collected in M.freed and pushed
-// afterwards), so a plain counter decrement hands out distinct entries: the poppers that draw a
-// positive count take that entry, the others give their decrement back and take fresh units from
-// the bump pointer.  Which lane gets which region is a race — and unobservable: readers go through
-// regions[] and the iteration order of the map is the order of its blocks, not of their storage.
-// (New voxels do not come here: their class-0 regions are handed out by rank like their blocks —
-// thousands of lanes on one counter cost the pass 0.2 ms.)
-__device__ __forceinline__ uint32_t alloc_region(const DevMap &M, uint32_t k) {
-    const int old = atomicSub(&M.ctr->free_units_count[k], 1);
-    if (old > 0) return (k << 28) | M.free_units[k][old - 1];
-    atomicAdd(&M.ctr->free_units_count[k], 1);
-    const uint32_t units = M.class_points[k] / kDevUnitPoints;
-    const uint32_t u = atomicAdd(&M.ctr->units_hi, units);
-    if (u + units > M.ctr->units_cap) {
-        M.ctr->unit_overflow = 1u;
-        return kDevNoRegion;
-    }
-    return (k << 28) | u;
-}
-
 __device__ __forceinline__ bool is_basic_label(const UpdatePolicy &P, int label) {
     for (int i = 0; i < P.n_labels; ++i)
         if (P.labels[i] == label) return true;
     return false;
 }
 
+// Regions for the lanes of a wave that need one (`want`: the class, -1: none), called by whole
+// waves.  The insertion kernel only POPS from the class stacks (regions released in the pass are
+// collected in M.freed and pushed after it), so one counter subtraction per wave and class hands
+// out a private interval of stack entries; what the stack cannot cover comes from the bump
+// pointer.  Which voxel gets which region is a race between waves — and unobservable: readers go
+// through regions[], and the iteration order of the map is the order of its blocks, not of their
+// storage.  (A counter update per LANE — thousands on one address — cost the pass 0.2 ms.)
+__device__ __forceinline__ uint32_t alloc_regions(const DevMap &M, int want) {
+    const unsigned lane = threadIdx.x & 63u;
+    uint32_t reg = kDevNoRegion;
+    for (int k = 0; k < M.n_classes; ++k) {
+        const bool mine = want == k;
+        const unsigned long long mask = __ballot(mine);
+        if (!mask) continue;
+        const int leader = __ffsll(static_cast<long long>(mask)) - 1;
+        const int cnt = __popcll(mask);
+        const uint32_t units = M.class_points[k] / kDevUnitPoints;
+        int old = 0;
+        uint32_t bump = 0;
+        if (static_cast<int>(lane) == leader) {
+            old = atomicSub(&M.ctr->free_units_count[k], cnt);
+            const int take = old < 0 ? 0 : (old < cnt ? old : cnt);
+            if (take < cnt) {
+                atomicAdd(&M.ctr->free_units_count[k], cnt - take);
+                bump = atomicAdd(&M.ctr->units_hi, static_cast<uint32_t>(cnt - take) * units);
+                if (bump + static_cast<uint32_t>(cnt - take) * units > M.ctr->units_cap) M.ctr->unit_overflow = 1u;
+            }
+        }
+        old = __shfl(old, leader, 64);
+        bump = __shfl(bump, leader, 64);
+        if (mine) {
+            const int take = old < 0 ? 0 : (old < cnt ? old : cnt);
+            const int i = __popcll(mask & ((1ull << lane) - 1ull));
+            const uint32_t u = i < take ? M.free_units[k][old - 1 - i] : bump + static_cast<uint32_t>(i - take) * units;
+            reg = (static_cast<uint32_t>(k) << 28) | u;
+            if (u + units > M.ctr->units_cap) reg = kDevNoRegion;      // (flagged above: nothing is written)
+        }
+    }
+    return reg;
+}
+
 // one lane per voxel run: claim a slot + block for a new voxel, then the retention policy of
-// VoxelBlock::AddPoint (VoxelHashMap.hpp:45-70) over the run in arrival order
+// VoxelBlock::AddPoint (VoxelHashMap.hpp:45-70) over the run in arrival order.  The policy is run
+// twice: first on the labels alone, for the count the voxel ends the pass with — it decides the
+// size class of its region, allocated once per wave and class — then for real.
 __global__ __launch_bounds__(256) void k_up_insert(const unsigned long long *keys, const uint32_t *idx,
                                                    int n, const Point4 *w, const uint32_t *head_slot,
                                                    const uint32_t *rank, DevMap M, UpdatePolicy P) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     unsigned appended = 0;
-    const bool ok = !M.ctr->overflow && !M.ctr->unit_overflow;
-    if (ok && i < n && head_slot[i] != kNonHead) {
-        const unsigned long long k = keys[i];
+    const bool active = !M.ctr->overflow && i < n && head_slot[i] != kNonHead;
+    unsigned long long k = 0;
+    uint32_t s = kNoSlot, b = 0, reg = kDevNoRegion;
+    int c = 0, z = 0, want = -1;
+    bool fresh = false;
+    if (active) {
+        k = keys[i];
+        s = head_slot[i];
+        fresh = (s == kNoSlot);
+        if (!fresh) {
+            const uint32_t blk = M.table[s].blk;
+            b = blk >> 8;
+            c = static_cast<int>(blk & 255u);
+            z = M.zeros[b];
+            reg = M.regions[b];
+        }
+        // the count after the run (labels only: what is appended depends on the count and the label)
+        int cf = c;
+        for (int t = i; t < n && keys[t] == k; ++t) {
+            const int label = static_cast<int>(w[idx[t]].l);
+            if ((fresh && t == i) || cf < P.basic ||
+                (label != 0 && !is_basic_label(P, label) && cf < P.basic + P.critical))
+                ++cf;
+        }
+        int kc = 0;
+        while (static_cast<uint32_t>(cf) > M.class_points[kc]) ++kc;
+        if (fresh || static_cast<uint32_t>(kc) > (reg >> 28)) want = kc;
+    }
+    const uint32_t nreg = alloc_regions(M, want);
+    uint32_t released = kDevNoRegion;
+    if (active && !(want >= 0 && nreg == kDevNoRegion)) {
         int vx, vy, vz;
         unpack_key(k, vx, vy, vz);
-        uint32_t s = head_slot[i], b, reg;
-        int c, z;
-        const bool fresh = (s == kNoSlot);
         if (fresh) {
             const uint32_t j = rank[idx[i]];
             const uint32_t fc = M.ctr->free_count;
@@ -152,23 +199,16 @@ __global__ __launch_bounds__(256) void k_up_insert(const unsigned long long *key
             M.table[s].x = vx;
             M.table[s].y = vy;
             M.table[s].z = vz;
-            c = 0;
-            z = 0;
-            // class-0 region by rank: the stack's top entries first, then the fresh range
-            // k_up_before_insert set aside
-            const uint32_t fu = static_cast<uint32_t>(M.ctr->free_units_count[0]);
-            reg = (j < fu) ? M.free_units[0][fu - 1u - j]
-                           : M.ctr->units_base0 + (j - fu) * (M.class_points[0] / kDevUnitPoints);
-        } else {
-            const uint32_t blk = M.table[s].blk;
-            b = blk >> 8;
-            c = static_cast<int>(blk & 255u);
-            z = M.zeros[b];
-            reg = M.regions[b];
+            reg = nreg;
+        } else if (want >= 0) {
+            // the voxel outgrows its region: its points move to the new one
+            const Point4 *from = M.pts + static_cast<size_t>(reg & 0x0FFFFFFFu) * kDevUnitPoints;
+            Point4 *to = M.pts + static_cast<size_t>(nreg & 0x0FFFFFFFu) * kDevUnitPoints;
+            for (int j = 0; j < c; ++j) to[j] = from[j];
+            released = reg;
+            reg = nreg;
         }
-        const bool lost = reg == kDevNoRegion;       // (unit overflow: flagged, nothing is written)
         Point4 *blkp = M.pts + static_cast<size_t>(reg & 0x0FFFFFFFu) * kDevUnitPoints;
-        uint32_t room = lost ? 0x7FFFFFFFu : M.class_points[reg >> 28];
         for (int t = i; t < n && keys[t] == k; ++t) {
             const Point4 p = w[idx[t]];
             const int label = static_cast<int>(p.l);
@@ -181,18 +221,6 @@ __global__ __launch_bounds__(256) void k_up_insert(const unsigned long long *key
                 if (is_basic_label(P, label)) replace = true;
                 else if (c < P.basic + P.critical) append = true;
                 else replace = true;
-            }
-            if (lost) continue;
-            if (append && static_cast<uint32_t>(c) == room) {
-                // the region is full: the voxel's points move to one of the next class
-                const uint32_t nr = alloc_region(M, (reg >> 28) + 1u);
-                if (nr == kDevNoRegion) continue;
-                Point4 *np_ = M.pts + static_cast<size_t>(nr & 0x0FFFFFFFu) * kDevUnitPoints;
-                for (int j = 0; j < c; ++j) np_[j] = blkp[j];
-                M.freed[atomicAdd(&M.ctr->n_freed, 1u)] = reg;
-                reg = nr;
-                blkp = np_;
-                room = M.class_points[reg >> 28];
             }
             if (append) {
                 blkp[c] = p;
@@ -212,6 +240,19 @@ __global__ __launch_bounds__(256) void k_up_insert(const unsigned long long *key
         M.zeros[b] = static_cast<uint8_t>(z);
         M.slot_of[b] = s;
         M.regions[b] = reg;
+    }
+    // released regions: one list append per wave
+    {
+        const unsigned lane = threadIdx.x & 63u;
+        const bool mine = released != kDevNoRegion;
+        const unsigned long long mask = __ballot(mine);
+        if (mask) {
+            const int leader = __ffsll(static_cast<long long>(mask)) - 1;
+            uint32_t base = 0;
+            if (static_cast<int>(lane) == leader) base = atomicAdd(&M.ctr->n_freed, static_cast<uint32_t>(__popcll(mask)));
+            base = __shfl(base, leader, 64);
+            if (mine) M.freed[base + __popcll(mask & ((1ull << lane) - 1ull))] = released;
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) appended += __shfl_down(appended, off, 64);
@@ -242,29 +283,10 @@ __global__ __launch_bounds__(256) void k_up_push_freed(DevMap M, uint32_t bound)
     push_regions(M, (i < bound && i < M.ctr->n_freed) ? M.freed[i] : kDevNoRegion);
 }
 
-// the fresh units this pass's new voxels take beyond the class-0 stack: [units_base0, units_hi)
-__global__ void k_up_before_insert(MapCounters *ctr, const uint32_t *rank, int n, uint32_t class0_units) {
-    if (threadIdx.x || blockIdx.x) return;
-    if (ctr->overflow) return;
-    const uint32_t n_new = rank[n];
-    const uint32_t fu = static_cast<uint32_t>(ctr->free_units_count[0]);
-    const uint32_t fresh = n_new > fu ? n_new - fu : 0u;
-    ctr->units_base0 = ctr->units_hi;
-    if (static_cast<unsigned long long>(ctr->units_hi) + static_cast<unsigned long long>(fresh) * class0_units > ctr->units_cap) {
-        ctr->unit_overflow = 1u;
-        return;
-    }
-    ctr->units_hi += fresh * class0_units;
-}
-
 __global__ void k_up_after_insert(MapCounters *ctr, const uint32_t *rank, int n) {
     if (threadIdx.x || blockIdx.x) return;
-    if (ctr->overflow || ctr->unit_overflow) { ctr->n_new = 0; return; }
+    if (ctr->overflow) { ctr->n_new = 0; return; }
     const uint32_t n_new = rank[n];
-    {
-        const uint32_t fu = static_cast<uint32_t>(ctr->free_units_count[0]);
-        ctr->free_units_count[0] = static_cast<int32_t>(fu - (n_new < fu ? n_new : fu));
-    }
     const uint32_t fc = ctr->free_count;
     const uint32_t from_free = n_new < fc ? n_new : fc;
     ctr->free_count = fc - from_free;
@@ -409,8 +431,6 @@ hipError_t map_update_device(const DevMap &M, const UpdatePolicy &P, const Updat
         e = rocprim::exclusive_scan(S.temp, tb, S.flag, S.rank, 0u, static_cast<size_t>(n) + 1,
                                     rocprim::plus<uint32_t>(), s);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_up_before_insert, dim3(1), dim3(64), 0, s, M.ctr, S.rank, n,
-                           M.class_points[0] / kDevUnitPoints);
         hipLaunchKernelGGL(k_up_insert, dim3(grid), dim3(256), 0, s, S.keys_alt, S.idx_alt, n, S.w,
                            S.head_slot, S.rank, M, P);
         hipLaunchKernelGGL(k_up_after_insert, dim3(1), dim3(64), 0, s, M.ctr, S.rank, n);
