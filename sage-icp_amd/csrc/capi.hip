@@ -921,10 +921,10 @@ static int reserve_update_scratch(const sageicp_map *m, size_t n, size_t nb) {
     UpdateScratch &u = m->up;
     if (n > m->up_n) {
         const size_t c = n + n / 2 + 1024;
-        void *olds[] = {u.raw, u.w, u.keys, u.keys_alt, u.idx, u.idx_alt, u.head_slot, u.flag, u.rank};
+        void *olds[] = {u.raw, u.w, u.keys, u.keys_alt, u.idx, u.idx_alt, u.head_slot, u.flag, u.rank, u.want};
         for (void *q : olds)
             if (q) HIPCHK(hipFree(q));
-        u = UpdateScratch{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+        u = UpdateScratch{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                           u.far_flag, u.far_sel, u.n_sel, u.temp, u.temp_bytes};
         m->up_n = 0;
         HIPCHK(hipMalloc(&u.raw, c * sizeof(Point4)));
@@ -934,8 +934,9 @@ static int reserve_update_scratch(const sageicp_map *m, size_t n, size_t nb) {
         HIPCHK(hipMalloc(&u.idx, c * sizeof(uint32_t)));
         HIPCHK(hipMalloc(&u.idx_alt, c * sizeof(uint32_t)));
         HIPCHK(hipMalloc(&u.head_slot, c * sizeof(uint32_t)));
-        HIPCHK(hipMalloc(&u.flag, (c + 1) * sizeof(uint32_t)));
-        HIPCHK(hipMalloc(&u.rank, (c + 1) * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&u.flag, (c + 1) * sizeof(UpdateEvents)));
+        HIPCHK(hipMalloc(&u.rank, (c + 1) * sizeof(UpdateEvents)));
+        HIPCHK(hipMalloc(&u.want, c));
         m->up_n = c;
     }
     if (nb > m->up_nb) {
@@ -1147,6 +1148,19 @@ int device_update(sageicp_map *m, const double *xyzl, uint64_t n, const double p
         m->mirror_stale_all = true;
         return fail(SAGEICP_ERR_CAPACITY, "device map update ran out of storage units");
     }
+#ifdef SAGE_UP_TIMING
+    {
+        const MapCounters &c = *m->h_ctr;
+        const double w = static_cast<double>(c.dbg_sum[7] ? c.dbg_sum[7] : 1);
+        std::fprintf(stderr, "k_up_insert phases, us (mean over %llu waves / slowest wave): stage %.2f/%.2f  dry run %.2f/%.2f  "
+                             "alloc %.2f/%.2f  claim+move %.2f/%.2f  policy %.2f/%.2f  tail %.2f/%.2f  whole %.2f/%.2f\n",
+                     c.dbg_sum[7], c.dbg_sum[0] / w / 100, c.dbg_max[0] / 100.0, c.dbg_sum[1] / w / 100, c.dbg_max[1] / 100.0,
+                     c.dbg_sum[2] / w / 100, c.dbg_max[2] / 100.0, c.dbg_sum[3] / w / 100, c.dbg_max[3] / 100.0,
+                     c.dbg_sum[4] / w / 100, c.dbg_max[4] / 100.0, c.dbg_sum[5] / w / 100, c.dbg_max[5] / 100.0,
+                     c.dbg_sum[6] / w / 100, c.dbg_max[6] / 100.0);
+        for (int j = 0; j < 8; ++j) m->h_ctr->dbg_sum[j] = m->h_ctr->dbg_max[j] = 0;
+    }
+#endif
     m->ctr = *m->h_ctr;
     m->on_device = true;
     m->cand_stale = true;
@@ -1750,7 +1764,7 @@ void sageicp_map_destroy(sageicp_map *m) {
         if (m->d_regions) (void)hipFree(m->d_regions);
         if (m->d_freed) (void)hipFree(m->d_freed);
         void *aux[] = {m->d_zeros, m->d_slot_of, m->d_free, m->d_ctr, m->up.raw, m->up.w, m->up.keys,
-                       m->up.keys_alt, m->up.idx, m->up.idx_alt, m->up.head_slot, m->up.flag, m->up.rank,
+                       m->up.keys_alt, m->up.idx, m->up.idx_alt, m->up.head_slot, m->up.flag, m->up.rank, m->up.want,
                        m->up.far_flag, m->up.far_sel, m->up.n_sel, m->up.temp};
         for (void *q : aux)
             if (q) (void)hipFree(q);

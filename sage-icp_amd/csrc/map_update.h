@@ -31,8 +31,11 @@ struct MapCounters {
     uint32_t units_hi;       // high-water mark
     uint32_t units_cap;      // units the point array holds
     int32_t free_units_count[4];     // entries of each class's stack of free regions
-    uint32_t n_freed;        // regions released by the last insertion pass (pushed to the stacks after it)
+    uint32_t n_freed;        // regions released by the last insertion pass (pushed onto the stacks after it)
     uint32_t pad;
+#ifdef SAGE_UP_TIMING
+    unsigned long long dbg_sum[8], dbg_max[8];     // probe: k_up_insert's phases per wave, 10-ns ticks
+#endif
 };
 
 struct DevMap {
@@ -62,14 +65,23 @@ struct UpdatePolicy {
     int labels[kMaxBasicLabels];
 };
 
+// What the run heads of an update ask for, laid at the arrival index of the head's point; its
+// exclusive prefix sum ranks every request: nw — a new voxel (a block: handed out in ARRIVAL order,
+// as the host's sequential loop does), c[k] — a region of class k (new voxel, or one that outgrows
+// its region), mg — a region released by such a move, ap — the points the run appends.
+struct UpdateEvents {
+    uint32_t nw, c[4], mg, ap;
+};
+
 struct UpdateScratch {       // device buffers sized for n points / nb blocks (capi.hip reserves them)
     Point4 *raw;             // [n] the caller's points
     Point4 *w;               // [n] transformed into the map frame
     unsigned long long *keys, *keys_alt;   // [n]
     uint32_t *idx, *idx_alt;               // [n]
     uint32_t *head_slot;     // [n]
-    uint32_t *flag;          // [n + 1]
-    uint32_t *rank;          // [n + 1]
+    UpdateEvents *flag;      // [n + 1]
+    UpdateEvents *rank;      // [n + 1] exclusive prefix sum of flag; [n]: the totals
+    int8_t *want;            // [n] per run head: the class of the region it asks for, -1: none
     uint32_t *far_flag;      // [nb]
     uint32_t *far_sel;       // [nb]
     uint32_t *n_sel;         // [1]

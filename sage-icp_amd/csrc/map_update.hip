@@ -50,9 +50,9 @@ __device__ __forceinline__ void unpack_key(unsigned long long k, int &x, int &y,
 // voxel index by fp64 divide + truncation (VoxelHashMap.cpp:165)
 __global__ __launch_bounds__(256) void k_up_keys(const Point4 *raw, int n, Pose34 T, double voxel_size,
                                                  Point4 *w, unsigned long long *keys, uint32_t *idx,
-                                                 uint32_t *flag, MapCounters *ctr) {
+                                                 UpdateEvents *flag, MapCounters *ctr) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) flag[n] = 0u;
+    if (i == 0) flag[n] = UpdateEvents{};
     if (i >= n) return;
     const Point4 p = raw[i];
     Point4 o;
@@ -68,34 +68,7 @@ __global__ __launch_bounds__(256) void k_up_keys(const Point4 *raw, int n, Pose3
     if (vx < -lim || vx > lim || vy < -lim || vy > lim || vz < -lim || vz > lim) ctr->overflow = 1u;
     keys[i] = pack_key(vx, vy, vz);
     idx[i] = static_cast<uint32_t>(i);
-    flag[i] = 0u;
-}
-
-// run heads: look the voxel up (before anything is inserted, so "absent" is definitive) and mark
-// the arrival index of the first point of every absent voxel
-__global__ __launch_bounds__(256) void k_up_heads(const unsigned long long *keys, const uint32_t *idx,
-                                                  int n, DevMap M, uint32_t *head_slot,
-                                                  uint32_t *flag) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    if (M.ctr->overflow) return;
-    const unsigned long long k = keys[i];
-    if (i > 0 && keys[i - 1] == k) {
-        head_slot[i] = kNonHead;
-        return;
-    }
-    int vx, vy, vz;
-    unpack_key(k, vx, vy, vz);
-    uint32_t s = voxel_hash(vx, vy, vz) & M.mask;
-    uint32_t found = kNoSlot;
-    for (;;) {
-        const Slot e = M.table[s];
-        if (e.blk == kEmptySlot) break;
-        if (e.x == vx && e.y == vy && e.z == vz) { found = s; break; }   // tombstones never match
-        s = (s + 1) & M.mask;
-    }
-    head_slot[i] = found;
-    if (found == kNoSlot) flag[idx[i]] = 1u;
+    flag[i] = UpdateEvents{};
 }
 
 __device__ __forceinline__ bool is_basic_label(const UpdatePolicy &P, int label) {
@@ -104,91 +77,193 @@ __device__ __forceinline__ bool is_basic_label(const UpdatePolicy &P, int label)
     return false;
 }
 
-// Regions for the lanes of a wave that need one (`want`: the class, -1: none), called by whole
-// waves.  The insertion kernel only POPS from the class stacks (regions released in the pass are
-// collected in M.freed and pushed after it), so one counter subtraction per wave and class hands
-// out a private interval of stack entries; what the stack cannot cover comes from the bump
-// pointer.  Which voxel gets which region is a race between waves — and unobservable: readers go
-// through regions[], and the iteration order of the map is the order of its blocks, not of their
-// storage.  (A counter update per LANE — thousands on one address — cost the pass 0.2 ms.)
-__device__ __forceinline__ uint32_t alloc_regions(const DevMap &M, int want) {
-    const unsigned lane = threadIdx.x & 63u;
-    uint32_t reg = kDevNoRegion;
-    for (int k = 0; k < M.n_classes; ++k) {
-        const bool mine = want == k;
-        const unsigned long long mask = __ballot(mine);
-        if (!mask) continue;
-        const int leader = __ffsll(static_cast<long long>(mask)) - 1;
-        const int cnt = __popcll(mask);
-        const uint32_t units = M.class_points[k] / kDevUnitPoints;
-        int old = 0;
-        uint32_t bump = 0;
-        if (static_cast<int>(lane) == leader) {
-            old = atomicSub(&M.ctr->free_units_count[k], cnt);
-            const int take = old < 0 ? 0 : (old < cnt ? old : cnt);
-            if (take < cnt) {
-                atomicAdd(&M.ctr->free_units_count[k], cnt - take);
-                bump = atomicAdd(&M.ctr->units_hi, static_cast<uint32_t>(cnt - take) * units);
-                if (bump + static_cast<uint32_t>(cnt - take) * units > M.ctr->units_cap) M.ctr->unit_overflow = 1u;
-            }
-        }
-        old = __shfl(old, leader, 64);
-        bump = __shfl(bump, leader, 64);
-        if (mine) {
-            const int take = old < 0 ? 0 : (old < cnt ? old : cnt);
-            const int i = __popcll(mask & ((1ull << lane) - 1ull));
-            const uint32_t u = i < take ? M.free_units[k][old - 1 - i] : bump + static_cast<uint32_t>(i - take) * units;
-            reg = (static_cast<uint32_t>(k) << 28) | u;
-            if (u + units > M.ctr->units_cap) reg = kDevNoRegion;      // (flagged above: nothing is written)
-        }
-    }
-    return reg;
+// what the retention policy asks of a label: unlabelled / one of basic_parts_labels / any other.
+// Evaluated by every lane for the point at its own position (the label list is read with
+// wave-uniform scalar loads: once per wave there, once per POINT inside a head's serial loop).
+constexpr int kUnlabelled = 0, kBasicPart = 1, kCritical = 2;
+__device__ __forceinline__ int label_code(const UpdatePolicy &P, int label) {
+    return label == 0 ? kUnlabelled : (is_basic_label(P, label) ? kBasicPart : kCritical);
 }
 
-// one lane per voxel run: claim a slot + block for a new voxel, then the retention policy of
-// VoxelBlock::AddPoint (VoxelHashMap.hpp:45-70) over the run in arrival order.  The policy is run
-// twice: first on the labels alone, for the count the voxel ends the pass with — it decides the
-// size class of its region, allocated once per wave and class — then for real.
+struct EventsPlus {
+    __host__ __device__ UpdateEvents operator()(const UpdateEvents &a, const UpdateEvents &b) const {
+        UpdateEvents r;
+        r.nw = a.nw + b.nw;
+        for (int k = 0; k < 4; ++k) r.c[k] = a.c[k] + b.c[k];
+        r.mg = a.mg + b.mg;
+        r.ap = a.ap + b.ap;
+        return r;
+    }
+};
+
+// The sorted positions of one workgroup staged in LDS: every lane fetches the key and the point at
+// its own position (one parallel gather); run heads then walk their runs through LDS instead of a
+// chain of dependent gathers.  A run that leaves the workgroup's 256 positions reads the rest from
+// memory.
+constexpr unsigned long long kNoKey = ~0ull;          // (no packed voxel key has bit 63 set)
+struct RunStage {
+    unsigned long long (&sk)[256];
+    const unsigned long long *keys;
+    const uint32_t *idx;
+    const Point4 *w;
+    int n, i, tid;
+    __device__ __forceinline__ unsigned long long key_at(int r) const {
+        const int u = tid + r;
+        if (u < 256) return sk[u];
+        return i + r < n ? keys[i + r] : kNoKey;
+    }
+};
+
+// Run heads: look the voxel up (before anything is inserted, so "absent" is definitive), run the
+// retention policy of VoxelBlock::AddPoint (VoxelHashMap.hpp:45-70) on the LABELS of the run for
+// the count the voxel ends the pass with — it decides the size class of its region — and lay the
+// head's requests (UpdateEvents) at the arrival index of its point.
+__global__ __launch_bounds__(256) void k_up_heads(const unsigned long long *keys, const uint32_t *idx,
+                                                  int n, const Point4 *w, DevMap M, UpdatePolicy P,
+                                                  uint32_t *head_slot, int8_t *want_out, UpdateEvents *flag) {
+    __shared__ unsigned long long sk[256];
+    __shared__ int sl[256];
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * 256 + tid;
+    {
+        unsigned long long ki = kNoKey;
+        int li = 0;
+        if (i < n) {
+            ki = keys[i];
+            li = static_cast<int>(w[idx[i]].l);
+        }
+        sk[tid] = ki;
+        sl[tid] = label_code(P, li);
+    }
+    __syncthreads();
+    if (i >= n) return;
+    if (M.ctr->overflow) return;
+    const unsigned long long k = sk[tid];
+    if (i > 0 && (tid > 0 ? sk[tid - 1] : keys[i - 1]) == k) {
+        head_slot[i] = kNonHead;
+        return;
+    }
+    int vx, vy, vz;
+    unpack_key(k, vx, vy, vz);
+    uint32_t s = voxel_hash(vx, vy, vz) & M.mask;
+    uint32_t found = kNoSlot;
+    int c = 0, cur = -1;
+    for (;;) {
+        const Slot e = M.table[s];
+        if (e.blk == kEmptySlot) break;
+        if (e.x == vx && e.y == vy && e.z == vz) {        // tombstones never match
+            found = s;
+            c = static_cast<int>(e.blk & 255u);
+            // its region's class is the smallest that holds its count (host and device grow a
+            // voxel that way, and counts never shrink): no need to fetch regions[] for it.  (Were
+            // the region bigger, the move asked for below would still land in one that fits.)
+            cur = 0;
+            while (static_cast<uint32_t>(c) > M.class_points[cur]) ++cur;
+            break;
+        }
+        s = (s + 1) & M.mask;
+    }
+    const bool fresh = found == kNoSlot;
+    // what is appended depends on the count and the label only
+    const RunStage R{sk, keys, idx, w, n, i, tid};
+    int cf = c;
+    for (int r = 0; R.key_at(r) == k; ++r) {
+        const int u = tid + r;
+        const int code = u < 256 ? sl[u] : label_code(P, static_cast<int>(w[idx[i + r]].l));
+        if ((fresh && r == 0) || cf < P.basic || (code == kCritical && cf < P.basic + P.critical)) ++cf;
+    }
+    int kc = 0;
+    while (static_cast<uint32_t>(cf) > M.class_points[kc]) ++kc;
+    const int want = (fresh || kc > cur) ? kc : -1;
+    head_slot[i] = found;
+    want_out[i] = static_cast<int8_t>(want);
+    UpdateEvents ev{};
+    ev.nw = fresh ? 1u : 0u;
+    if (want >= 0) ev.c[want] = 1u;
+    ev.mg = (!fresh && want >= 0) ? 1u : 0u;
+    ev.ap = static_cast<uint32_t>(cf - c);
+    flag[idx[i]] = ev;
+}
+
+// Where the regions of this pass come from: class k's requests are ranked 0 .. total_k-1; the first
+// fu_k = (entries on the class stack) take the stack from the top, the rest fresh units — class 0's
+// fresh range first, then class 1's ...  No counter is touched while the pass runs
+// (k_up_after_insert settles them): a request's region is a function of its rank.
+struct RegionPlan {
+    uint32_t fu[4], base[4], units[4];
+    uint32_t units_end;
+    __device__ __forceinline__ RegionPlan(const DevMap &M, const UpdateEvents &total) {
+        uint32_t at = M.ctr->units_hi;
+        for (int k = 0; k < 4; ++k) {
+            units[k] = k < M.n_classes ? M.class_points[k] / kDevUnitPoints : 0u;
+            fu[k] = k < M.n_classes ? static_cast<uint32_t>(M.ctr->free_units_count[k]) : 0u;
+            base[k] = at;
+            at += (total.c[k] > fu[k] ? total.c[k] - fu[k] : 0u) * units[k];
+        }
+        units_end = at;
+    }
+};
+
+// One lane per voxel run: claim a slot + block for a new voxel, take the region the run's rank
+// stands for (RegionPlan), move the voxel's points when it outgrows its region, then the retention
+// policy of VoxelBlock::AddPoint (VoxelHashMap.hpp:45-70) over the run in arrival order, the run's
+// points read from LDS (RunStage).
 __global__ __launch_bounds__(256) void k_up_insert(const unsigned long long *keys, const uint32_t *idx,
                                                    int n, const Point4 *w, const uint32_t *head_slot,
-                                                   const uint32_t *rank, DevMap M, UpdatePolicy P) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    unsigned appended = 0;
-    const bool active = !M.ctr->overflow && i < n && head_slot[i] != kNonHead;
-    unsigned long long k = 0;
-    uint32_t s = kNoSlot, b = 0, reg = kDevNoRegion;
-    int c = 0, z = 0, want = -1;
-    bool fresh = false;
-    if (active) {
-        k = keys[i];
-        s = head_slot[i];
-        fresh = (s == kNoSlot);
-        if (!fresh) {
-            const uint32_t blk = M.table[s].blk;
-            b = blk >> 8;
-            c = static_cast<int>(blk & 255u);
-            z = M.zeros[b];
-            reg = M.regions[b];
+                                                   const int8_t *want_in, const UpdateEvents *rank,
+                                                   DevMap M, UpdatePolicy P) {
+    __shared__ unsigned long long sk[256];
+    __shared__ Point4 sp[256];
+    __shared__ uint8_t sc[256];
+    const int tid = threadIdx.x;
+#ifdef SAGE_UP_TIMING
+    unsigned long long tph[7];
+    // (everything issued so far has completed when the stamp is taken, and nothing moves across it)
+#define UP_STAMP(j) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tph[j]) : : "memory")
+    UP_STAMP(0);
+#else
+#define UP_STAMP(j)
+#endif
+    const int i = blockIdx.x * 256 + tid;
+    {
+        unsigned long long ki = kNoKey;
+        Point4 pi{0.0, 0.0, 0.0, 0.0};
+        if (i < n) {
+            ki = keys[i];
+            pi = w[idx[i]];
         }
-        // the count after the run (labels only: what is appended depends on the count and the label)
-        int cf = c;
-        for (int t = i; t < n && keys[t] == k; ++t) {
-            const int label = static_cast<int>(w[idx[t]].l);
-            if ((fresh && t == i) || cf < P.basic ||
-                (label != 0 && !is_basic_label(P, label) && cf < P.basic + P.critical))
-                ++cf;
-        }
-        int kc = 0;
-        while (static_cast<uint32_t>(cf) > M.class_points[kc]) ++kc;
-        if (fresh || static_cast<uint32_t>(kc) > (reg >> 28)) want = kc;
+        sk[tid] = ki;
+        sp[tid] = pi;
+        sc[tid] = static_cast<uint8_t>(label_code(P, static_cast<int>(pi.l)));
     }
-    const uint32_t nreg = alloc_regions(M, want);
-    uint32_t released = kDevNoRegion;
-    if (active && !(want >= 0 && nreg == kDevNoRegion)) {
-        int vx, vy, vz;
-        unpack_key(k, vx, vy, vz);
+    __syncthreads();
+    UP_STAMP(1);
+    const RunStage R{sk, keys, idx, w, n, i, tid};
+    const UpdateEvents total = rank[n];
+    const RegionPlan plan(M, total);
+    // (more units than the array holds: flagged by k_up_after_insert, nothing is written)
+    const bool active = !M.ctr->overflow && plan.units_end <= M.ctr->units_cap && i < n && head_slot[i] != kNonHead;
+    UP_STAMP(2);
+    UP_STAMP(3);
+    UP_STAMP(4);
+    if (active) {
+        const unsigned long long k = sk[tid];
+        uint32_t s = head_slot[i], b = 0, reg = kDevNoRegion;
+        int c = 0, z = 0;
+        const int want = want_in[i];
+        const bool fresh = (s == kNoSlot);
+        const UpdateEvents my = rank[idx[i]];
+        uint32_t nreg = kDevNoRegion;
+        if (want >= 0) {
+            const uint32_t j = my.c[want], fu = plan.fu[want];
+            const uint32_t u = j < fu ? M.free_units[want][fu - 1u - j] : plan.base[want] + (j - fu) * plan.units[want];
+            nreg = (static_cast<uint32_t>(want) << 28) | u;
+        }
+        UP_STAMP(3);
         if (fresh) {
-            const uint32_t j = rank[idx[i]];
+            int vx, vy, vz;
+            unpack_key(k, vx, vy, vz);
+            const uint32_t j = my.nw;
             const uint32_t fc = M.ctr->free_count;
             b = (j < fc) ? M.free_list[fc - 1u - j] : M.ctr->blocks_hi + (j - fc);
             s = voxel_hash(vx, vy, vz) & M.mask;
@@ -200,40 +275,58 @@ __global__ __launch_bounds__(256) void k_up_insert(const unsigned long long *key
             M.table[s].y = vy;
             M.table[s].z = vz;
             reg = nreg;
-        } else if (want >= 0) {
-            // the voxel outgrows its region: its points move to the new one
-            const Point4 *from = M.pts + static_cast<size_t>(reg & 0x0FFFFFFFu) * kDevUnitPoints;
-            Point4 *to = M.pts + static_cast<size_t>(nreg & 0x0FFFFFFFu) * kDevUnitPoints;
-            for (int j = 0; j < c; ++j) to[j] = from[j];
-            released = reg;
-            reg = nreg;
+        } else {
+            const uint32_t blk = M.table[s].blk;
+            b = blk >> 8;
+            c = static_cast<int>(blk & 255u);
+            z = M.zeros[b];
+            reg = M.regions[b];
+            if (want >= 0) {
+                // the voxel outgrows its region: its points move to the new one, a unit (4 points)
+                // at a time — four loads in flight, then four stores
+                const Point4 *from = M.pts + static_cast<size_t>(reg & 0x0FFFFFFFu) * kDevUnitPoints;
+                Point4 *to = M.pts + static_cast<size_t>(nreg & 0x0FFFFFFFu) * kDevUnitPoints;
+                for (int j = 0; j < c; j += 4) {
+                    const Point4 a0 = from[j], a1 = from[j + 1], a2 = from[j + 2], a3 = from[j + 3];
+                    to[j] = a0; to[j + 1] = a1; to[j + 2] = a2; to[j + 3] = a3;
+                }
+                M.freed[my.mg] = reg;
+                reg = nreg;
+            }
         }
         Point4 *blkp = M.pts + static_cast<size_t>(reg & 0x0FFFFFFFu) * kDevUnitPoints;
-        for (int t = i; t < n && keys[t] == k; ++t) {
-            const Point4 p = w[idx[t]];
-            const int label = static_cast<int>(p.l);
+        UP_STAMP(4);
+        for (int r = 0; R.key_at(r) == k; ++r) {
+            const int u = tid + r;
+            const Point4 p = u < 256 ? sp[u] : w[idx[i + r]];
+            const int code = u < 256 ? sc[u] : label_code(P, static_cast<int>(p.l));
             bool append = false, replace = false;
-            if (fresh && t == i) {
+            if (fresh && r == 0) {
                 append = true;          // a new voxel takes its first point unconditionally (:171)
             } else if (c < P.basic) {
                 append = true;
-            } else if (label != 0) {
-                if (is_basic_label(P, label)) replace = true;
+            } else if (code != kUnlabelled) {
+                if (code == kBasicPart) replace = true;
                 else if (c < P.basic + P.critical) append = true;
                 else replace = true;
             }
             if (append) {
                 blkp[c] = p;
-                if (label == 0) ++z;
+                if (code == kUnlabelled) ++z;
                 ++c;
-                ++appended;
             } else if (replace && z > 0) {
-                for (int j = 0; j < c; ++j)
-                    if (static_cast<int>(blkp[j].l) == 0) {
-                        blkp[j] = p;
+                // the first unlabelled point of the voxel gives way; four labels in flight per step
+                // (the region holds whole units of 4 points: the reads stay inside it)
+                for (int j = 0; j < c; j += 4) {
+                    const double l0 = blkp[j].l, l1 = blkp[j + 1].l, l2 = blkp[j + 2].l, l3 = blkp[j + 3].l;
+                    const int f = static_cast<int>(l0) == 0 ? 0 : static_cast<int>(l1) == 0 ? 1 : static_cast<int>(l2) == 0 ? 2
+                                : static_cast<int>(l3) == 0 ? 3 : 4;
+                    if (f < 4 && j + f < c) {
+                        blkp[j + f] = p;
                         --z;
                         break;
                     }
+                }
             }
         }
         M.table[s].blk = (b << 8) | static_cast<uint32_t>(c);
@@ -241,24 +334,22 @@ __global__ __launch_bounds__(256) void k_up_insert(const unsigned long long *key
         M.slot_of[b] = s;
         M.regions[b] = reg;
     }
-    // released regions: one list append per wave
-    {
-        const unsigned lane = threadIdx.x & 63u;
-        const bool mine = released != kDevNoRegion;
-        const unsigned long long mask = __ballot(mine);
-        if (mask) {
-            const int leader = __ffsll(static_cast<long long>(mask)) - 1;
-            uint32_t base = 0;
-            if (static_cast<int>(lane) == leader) base = atomicAdd(&M.ctr->n_freed, static_cast<uint32_t>(__popcll(mask)));
-            base = __shfl(base, leader, 64);
-            if (mine) M.freed[base + __popcll(mask & ((1ull << lane) - 1ull))] = released;
+    UP_STAMP(5);
+#ifdef SAGE_UP_TIMING
+    UP_STAMP(6);
+    for (int j = 0; j < 6; ++j) {
+        const unsigned long long d = tph[j + 1] - tph[j];
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&M.ctr->dbg_sum[j], d);
+            atomicMax(&M.ctr->dbg_max[j], d);
         }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) appended += __shfl_down(appended, off, 64);
-    if ((threadIdx.x & 63) == 0 && appended)
-        atomicAdd(reinterpret_cast<unsigned long long *>(&M.ctr->total_points),
-                  static_cast<unsigned long long>(appended));
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&M.ctr->dbg_sum[6], tph[6] - tph[0]);
+        atomicMax(&M.ctr->dbg_max[6], tph[6] - tph[0]);
+        atomicAdd(&M.ctr->dbg_sum[7], 1ull);
+    }
+#endif
 }
 
 // Region r of each lane (kDevNoRegion: none) back onto its class's stack; whole waves call this
@@ -277,16 +368,35 @@ __device__ __forceinline__ void push_regions(const DevMap &M, uint32_t r) {
     }
 }
 
-// regions released by the insertion pass (voxels that moved to a bigger class) onto their class stacks
-__global__ __launch_bounds__(256) void k_up_push_freed(DevMap M, uint32_t bound) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    push_regions(M, (i < bound && i < M.ctr->n_freed) ? M.freed[i] : kDevNoRegion);
+// Regions released by the insertion pass (voxels that moved to a bigger class) onto their class
+// stacks: one workgroup, the stack tops kept in LDS while it runs (after k_up_after_insert has
+// settled the counters of the pass).
+__global__ __launch_bounds__(1024) void k_up_push_freed(DevMap M) {
+    __shared__ int top[4];
+    if (threadIdx.x < 4) top[threadIdx.x] = M.ctr->free_units_count[threadIdx.x];
+    __syncthreads();
+    const uint32_t nf = M.ctr->n_freed;
+    for (uint32_t i = threadIdx.x; i < nf; i += 1024) {
+        const uint32_t r = M.freed[i], k = r >> 28;
+        M.free_units[k][atomicAdd(&top[k], 1)] = r & 0x0FFFFFFFu;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) M.ctr->free_units_count[threadIdx.x] = top[threadIdx.x];
 }
 
-__global__ void k_up_after_insert(MapCounters *ctr, const uint32_t *rank, int n) {
+__global__ void k_up_after_insert(DevMap M, const UpdateEvents *rank, int n) {
     if (threadIdx.x || blockIdx.x) return;
+    MapCounters *ctr = M.ctr;
+    ctr->n_freed = 0;
     if (ctr->overflow) { ctr->n_new = 0; return; }
-    const uint32_t n_new = rank[n];
+    const UpdateEvents total = rank[n];
+    const RegionPlan plan(M, total);
+    if (plan.units_end > ctr->units_cap) {      // (the host reserves the worst case)
+        ctr->unit_overflow = 1u;
+        ctr->n_new = 0;
+        return;
+    }
+    const uint32_t n_new = total.nw;
     const uint32_t fc = ctr->free_count;
     const uint32_t from_free = n_new < fc ? n_new : fc;
     ctr->free_count = fc - from_free;
@@ -294,6 +404,11 @@ __global__ void k_up_after_insert(MapCounters *ctr, const uint32_t *rank, int n)
     ctr->num_voxels += n_new;
     ctr->used_slots += n_new;
     ctr->n_new = n_new;
+    for (int k = 0; k < M.n_classes; ++k)
+        ctr->free_units_count[k] = static_cast<int32_t>(plan.fu[k] - (total.c[k] < plan.fu[k] ? total.c[k] : plan.fu[k]));
+    ctr->units_hi = plan.units_end;
+    ctr->n_freed = total.mg;
+    ctr->total_points += total.ap;
 }
 
 // eviction test on the voxel's FIRST point (VoxelHashMap.cpp:179-181), one lane per block
@@ -396,7 +511,8 @@ size_t map_update_temp_bytes(int n, int nb) {
     unsigned long long *k = nullptr;
     uint32_t *v = nullptr;
     (void)rocprim::radix_sort_pairs(nullptr, a, k, k, v, v, static_cast<size_t>(n), 0, 63);
-    (void)rocprim::exclusive_scan(nullptr, b, v, v, 0u, static_cast<size_t>(n) + 1, rocprim::plus<uint32_t>());
+    UpdateEvents *ev = nullptr;
+    (void)rocprim::exclusive_scan(nullptr, b, ev, ev, UpdateEvents{}, static_cast<size_t>(n) + 1, EventsPlus());
     (void)rocprim::select(nullptr, c, rocprim::counting_iterator<uint32_t>(0), v, v, v,
                           static_cast<size_t>(nb));
     size_t d = 0;                  // map_pointcloud_device scans nb + 1 block counts
@@ -425,16 +541,16 @@ hipError_t map_update_device(const DevMap &M, const UpdatePolicy &P, const Updat
         e = rocprim::radix_sort_pairs(S.temp, tb, S.keys, S.keys_alt, S.idx, S.idx_alt,
                                       static_cast<size_t>(n), 0, 63, s);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_up_heads, dim3(grid), dim3(256), 0, s, S.keys_alt, S.idx_alt, n, M,
-                           S.head_slot, S.flag);
+        hipLaunchKernelGGL(k_up_heads, dim3(grid), dim3(256), 0, s, S.keys_alt, S.idx_alt, n, S.w, M, P,
+                           S.head_slot, S.want, S.flag);
         tb = S.temp_bytes;
-        e = rocprim::exclusive_scan(S.temp, tb, S.flag, S.rank, 0u, static_cast<size_t>(n) + 1,
-                                    rocprim::plus<uint32_t>(), s);
+        e = rocprim::exclusive_scan(S.temp, tb, S.flag, S.rank, UpdateEvents{}, static_cast<size_t>(n) + 1,
+                                    EventsPlus(), s);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_up_insert, dim3(grid), dim3(256), 0, s, S.keys_alt, S.idx_alt, n, S.w,
-                           S.head_slot, S.rank, M, P);
-        hipLaunchKernelGGL(k_up_after_insert, dim3(1), dim3(64), 0, s, M.ctr, S.rank, n);
-        hipLaunchKernelGGL(k_up_push_freed, dim3(grid), dim3(256), 0, s, M, static_cast<uint32_t>(n));
+                           S.head_slot, S.want, S.rank, M, P);
+        hipLaunchKernelGGL(k_up_after_insert, dim3(1), dim3(64), 0, s, M, S.rank, n);
+        hipLaunchKernelGGL(k_up_push_freed, dim3(1), dim3(1024), 0, s, M);
     }
     if (blocks_hi_bound > 0) {
         const int gb = static_cast<int>((blocks_hi_bound + 255u) / 256u);
