@@ -1227,10 +1227,9 @@ IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, 
     ip.mask = static_cast<uint32_t>(m->d_table_cap - 1);
     ip.pts = m->d_pts;
     const uint64_t pts_bytes = (static_cast<uint64_t>(m->d_units_cap) * kUnitPoints + 1) * sizeof(Point4);
-    ip.big = pts_bytes >= (1ull << 32) || env_int("SAGEICP_FORCE_BIG", 0);
-    ip.pts_bytes = ip.big ? 0u : static_cast<uint32_t>(pts_bytes);
+    ip.pts_bytes = static_cast<uint32_t>(pts_bytes);        // (< 4 GiB: kMaxUnits units of 128 B)
     ip.cand = m->d_cand;
-    ip.cand_bytes = ip.big ? 0u : static_cast<uint32_t>(pts_bytes / 2);
+    ip.cand_bytes = static_cast<uint32_t>(pts_bytes / 2);
     ip.cand_flags = m->d_cand_flags;
     // fp32 thresholds of the scan's filter (kernels.hip): off (infinite) for a negative or NaN
     // sem_th, where a larger distance can scale to a smaller one
@@ -1243,10 +1242,7 @@ IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, 
         ip.filt_inv_same = filt ? (sem_th > 0.0 ? k1 / sem_th : inf) : inf;
         ip.filt_slack = std::ldexp(1.0, -44) * 1025.0 * (1.0 + 1e-6);
     }
-    // (rows address storage units of 4 points: kernels.hip's row_word())
-    ip.cap_bytes = static_cast<uint32_t>(kUnitPoints * sizeof(Point4));
-    ip.cap_points = static_cast<uint32_t>(kUnitPoints);
-    ip.regions = m->d_regions;
+    ip.regions = m->d_regions;      // (rows address storage units of 4 points: kernels.hip's row_word())
     ip.sem_th = sem_th;
     ip.dist_init = DBL_MAX;
     // scaled distance = d2 * sem_th for matching labels, d2 otherwise: >= min(sem_th, 1) * d2.

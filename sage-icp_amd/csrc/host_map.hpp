@@ -107,12 +107,8 @@ private:
     }
 };
 
-constexpr uint32_t kUnitPoints = 4;                           // points per allocation unit of the point array
-constexpr uint32_t kMaxUnits = (1u << 24) - 2;                // a row word keeps 24 bits for the unit (8 for the count)
-constexpr int kMaxClasses = 4;
 constexpr uint32_t region_unit(uint32_t r) { return r & 0x0FFFFFFFu; }
 constexpr uint32_t region_class(uint32_t r) { return r >> 28; }
-constexpr uint32_t kNoRegion = 0xFFFFFFFFu;
 
 class HostMap {
 public:

@@ -34,18 +34,15 @@ struct IcpParams {
                               // point array (host_map.hpp); a row word is (unit << 8) | count
     uint32_t mask;
     const Point4 *pts;
-    uint32_t pts_bytes;       // size of the point array when it is under 4 GiB (32-bit byte offsets
-                              // through a buffer resource); bigger maps: `big`, 64-bit addresses
+    uint32_t pts_bytes;       // size of the point array: under 4 GiB (2^24 units of 128 B), read with 32-bit
+                              // byte offsets through a buffer resource
     int filter;               // 1: the scan reads the compact copy and filters in fp32 (big frames, dense voxels)
     const uint4 *cand;        // compact copy of pts (fp32 x, y, z, label; k_derive_cand), same indexing
-    uint32_t cand_bytes;      // its size when pts is under 4 GiB
+    uint32_t cand_bytes;      // its size
     const uint32_t *cand_flags;   // bit 0: some label of the map cannot be classified in fp32
     double filt_inv_same;     // (1 / sem_th)(1 + 2^-10)(1 + 1e-6): fp32 threshold of the label class (inf: off)
     double filt_inv_diff;     // (1 + 2^-10)(1 + 1e-6): of the other candidates (inf: off)
     double filt_slack;        // 2^-44 (1 + 2^10)(1 + 1e-6): times sum (|q_a| + 4 voxel)^2
-    uint32_t cap_bytes;       // bytes of one voxel block: (basic + critical) * 32
-    uint32_t cap_points;      // basic + critical
-    int big;                  // 1: the point array is 4 GiB or more
     double sem_th;
     double dist_init;         // DBL_MAX
     double prune_scale;       // min(sem_th, 1) * (1 - 1e-9): scaled distance >= this x squared
@@ -59,9 +56,8 @@ struct IcpParams {
     double accept_r2;         // largest r2 with sqrt(r2) < max_correspondence_distance (exact form
                               // of the acceptance test VoxelHashMap.cpp:111; -1: accept nothing)
     uint2 *nn_prev;           // [n] in/out: every query's record of the previous iteration {key =
-                              // (voxel << 8) | slot of its nearest neighbour, its byte offset (index
-                              // when big)}; key 0xFFFFFFFF: none.  Seeds the next search with a
-                              // tight bound.
+                              // (voxel << 8) | slot of its nearest neighbour, its byte offset};
+                              // key 0xFFFFFFFF: none.  Seeds the next search with a tight bound.
     uint32_t *work;           // instrumented builds only: [n] map points handed to each query
     double *partials;         // out: [gridDim.x][kNumSums] one partial per workgroup (acc == nullptr)
     long long *acc;           // out: the Gauss-Newton sums as fixed-point accumulators (see kAcc* below):

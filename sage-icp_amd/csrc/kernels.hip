@@ -165,20 +165,12 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 
-// One map point.  Maps under 4 GiB go through the buffer path: `off` is the point's byte offset,
-// the resource carries the 64-bit base, so a load costs no 64-bit address arithmetic.  Bigger maps
-// (BIG: `off` is the point's index) pay one 64-bit shift-add per load.
-template <bool BIG>
-__device__ __forceinline__ Point4 load_point(__amdgpu_buffer_rsrc_t pts, const Point4 *base, uint32_t off) {
-    v4u a, b;
-    if (BIG) {
-        const v4u *g = reinterpret_cast<const v4u *>(base + off);
-        a = g[0];
-        b = g[1];
-    } else {
-        a = __builtin_amdgcn_raw_buffer_load_b128(pts, off, 0, 0);
-        b = __builtin_amdgcn_raw_buffer_load_b128(pts, off + 16u, 0, 0);
-    }
+// One map point through the buffer path: `off` is the point's byte offset, the resource carries the
+// 64-bit base, so a load costs no 64-bit address arithmetic.  (The point array stays under 4 GiB:
+// 2^24 storage units of 128 B, capi.hip.)
+__device__ __forceinline__ Point4 load_point(__amdgpu_buffer_rsrc_t pts, uint32_t off) {
+    const v4u a = __builtin_amdgcn_raw_buffer_load_b128(pts, off, 0, 0);
+    const v4u b = __builtin_amdgcn_raw_buffer_load_b128(pts, off + 16u, 0, 0);
     Point4 q;
     q.x = __hiloint2double(static_cast<int>(a.y), static_cast<int>(a.x));
     q.y = __hiloint2double(static_cast<int>(a.w), static_cast<int>(a.z));
@@ -187,13 +179,9 @@ __device__ __forceinline__ Point4 load_point(__amdgpu_buffer_rsrc_t pts, const P
     return q;
 }
 
-// One compact candidate record (16 B): fp32 x, y, z, label.  `off` is its byte offset (index when
-// BIG).
-template <bool BIG>
-__device__ __forceinline__ uint4 load_cand(__amdgpu_buffer_rsrc_t cands, const uint4 *base, uint32_t off) {
-    v4u a;
-    if (BIG) a = *reinterpret_cast<const v4u *>(base + off);
-    else a = __builtin_amdgcn_raw_buffer_load_b128(cands, off, 0, 0);
+// One compact candidate record (16 B): fp32 x, y, z, label.  `off` is its byte offset.
+__device__ __forceinline__ uint4 load_cand(__amdgpu_buffer_rsrc_t cands, uint32_t off) {
+    const v4u a = __builtin_amdgcn_raw_buffer_load_b128(cands, off, 0, 0);
     return make_uint4(a.x, a.y, a.z, a.w);
 }
 
@@ -342,7 +330,7 @@ __host__ __device__ constexpr unsigned icp_wave_words(int lw) {
     return static_cast<unsigned>(kRowLdsStride * (64 >> lw) + 64);
 }
 
-template <int LW, bool FUSED, bool BIG, bool FILT>
+template <int LW, bool FUSED, bool FILT>
 __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem);
 
 // a pair of scanned points in flight: compact records (FILT) or full ones
@@ -357,27 +345,27 @@ struct PairFull {
     bool ha, hb;
 };
 
-template <int LW, bool FUSED, bool BIG, bool FILT>
+template <int LW, bool FUSED, bool FILT>
 __global__ __launch_bounds__(64 * kIcpWavesPerBlock) __attribute__((amdgpu_waves_per_eu(SAGE_ICP_OCC, 8)))
 void k_icp(IcpParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     if (P.check_done && P.st->done) return;
-    icp_body<LW, FUSED, BIG, FILT>(P, smem);
+    icp_body<LW, FUSED, FILT>(P, smem);
 #ifdef SAGE_ICP_DELAY_PROBE
     // probe: the same pass again inside the launch — what an iteration costs on L2s that were not
     // emptied by a kernel boundary (its sums are added a second time: the solve does not care)
     for (unsigned r = 0; r < P.dbg_repeat; ++r) {
         __syncthreads();
-        icp_body<LW, FUSED, BIG, FILT>(P, smem);
+        icp_body<LW, FUSED, FILT>(P, smem);
     }
 #endif
 }
 
-template <int LW, bool FUSED, bool BIG, bool FILT>
+template <int LW, bool FUSED, bool FILT>
 __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
     constexpr int W = 1 << LW;                 // lanes per query
     constexpr int QW = 64 >> LW;               // queries per wave
-    constexpr int SH = BIG ? 0 : 5;            // points are addressed by byte offset, or by index (BIG)
+    constexpr int SH = 5;                      // points are addressed by byte offset
 #ifdef SAGE_NN_TIMING
     unsigned long long tph[5] = {0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
@@ -418,7 +406,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
 
     const __amdgpu_buffer_rsrc_t cands = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint4 *>(P.cand), 0, static_cast<int>(P.cand_bytes), 0x00020000);
-    constexpr int SHC = BIG ? 0 : (FILT ? 4 : 5);   // the scan's records (compact or full): byte offset, or index (BIG)
+    constexpr int SHC = FILT ? 4 : 5;          // the scan's records (compact or full), by byte offset
 
     // ---- prologue: the query, its home voxel, its neighbourhood row ------------------------------
     // Everything the prologue needs is requested at once (one memory round trip): the row key, the
@@ -555,7 +543,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
 
     // voxel cursor of this lane: it takes points ci, ci + W, ... of the open voxel.  k = (voxel <<
     // 8) | slot of its next point, kend = (voxel << 8) | points in the voxel, off = where the
-    // compact record of point k lives (bytes, or points when BIG).  Only the key of the winner is
+    // compact record of point k lives (bytes).  Only the key of the winner is
     // tracked; its offset is rebuilt from the row once per query.
     unsigned k = ci, kend = 0u, off = 0u;
     // The reference's comparison, fp64, on a full record.  Branch-free: a lane that holds no
@@ -644,7 +632,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
                 const uint32_t w = lrow[v];
                 kend = (v << 8) | (w & 255u);
                 k = (v << 8) | ci;
-                off = (((w >> 8) * P.cap_points) + ci) << SHC;
+                off = (((w >> 8) * kUnitPoints) + ci) << SHC;
                 npairs += w & 255u;
             }
             n.ha = k < kend;
@@ -655,11 +643,11 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
             // the compiler drain the whole queue before the other set is looked at
             const unsigned oa = n.ha ? off : 0u, ob = n.hb ? off + (static_cast<unsigned>(W) << SHC) : 0u;
             if constexpr (FILT) {
-                n.a = load_cand<BIG>(cands, P.cand, oa);
-                n.b = load_cand<BIG>(cands, P.cand, ob);
+                n.a = load_cand(cands, oa);
+                n.b = load_cand(cands, ob);
             } else {
-                n.a = load_point<BIG>(pts, P.pts, oa);
-                n.b = load_point<BIG>(pts, P.pts, ob);
+                n.a = load_point(pts, oa);
+                n.b = load_point(pts, ob);
             }
             // the filtering of the other set stays below these loads (the scheduler would
             // otherwise sink them under the arithmetic it believes is ready)
@@ -688,8 +676,8 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
                 n_exact_lanes += static_cast<unsigned>(__popcll(__ballot(pa)) + __popcll(__ballot(pb)));
 #endif
                 const unsigned ob = n.oa + (static_cast<unsigned>(W) << SHC);
-                const Point4 ea = load_point<BIG>(pts, P.pts, pa ? (BIG ? n.oa : n.oa << 1) : 0u);
-                const Point4 eb = load_point<BIG>(pts, P.pts, pb ? (BIG ? ob : ob << 1) : 0u);
+                const Point4 ea = load_point(pts, pa ? n.oa << 1 : 0u);
+                const Point4 eb = load_point(pts, pb ? ob << 1 : 0u);
                 evaluate(ea, pa, n.ka);
                 evaluate(eb, pb, n.ka + W);
                 fb = min_f64(fb, best);
@@ -727,7 +715,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
     constexpr unsigned kHome = 13u;
     if (FUSED) {
         const bool seeded = valid && !stale && prev.x != 0xFFFFFFFFu;
-        const Point4 pp = load_point<BIG>(pts, P.pts, seeded ? prev.y : 0u);      // the full record
+        const Point4 pp = load_point(pts, seeded ? prev.y : 0u);      // the full record
         scan(occ & (1u << kHome), &pp, seeded, prev.x);
     } else {
         scan(occ & (1u << kHome), nullptr, false, 0u);
@@ -776,7 +764,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
     const unsigned mine = (best == m) ? bkey : 0xFFFFFFFFu;
     const unsigned mkey = seg_min_u32<W>(mine);
     const bool found = valid && mkey != 0xFFFFFFFFu;       // else: empty neighbourhood (hazard H1)
-    const unsigned woff = (lrow[found ? mkey >> 8 : 0u] >> 8) * (BIG ? P.cap_points : P.cap_bytes) +
+    const unsigned woff = (lrow[found ? mkey >> 8 : 0u] >> 8) * (kUnitPoints * 32u) +
                           ((mkey & 255u) << SH);
     NN_T(3);
 
@@ -818,7 +806,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
         for (int c = 0; c < kCount; ++c) t[c] = 0.0;
         bool use = false;
         if (found && ci == 0u) {
-            const Point4 g = load_point<BIG>(pts, P.pts, woff);
+            const Point4 g = load_point(pts, woff);
             const double rx = s.x - g.x, ry = s.y - g.y, rz = s.z - g.z;
             const double r2 = SAGE_SQNORM3(rx * rx, ry * ry, rz * rz);
             // (closest_neighboor - point).norm() < max_correspondance_distance (VoxelHashMap.cpp:111)
@@ -1498,19 +1486,11 @@ static void launch_icp_lw(const IcpParams &p, bool fused, hipStream_t s) {
     const size_t lds = icp_lds_bytes(LW);
     const dim3 g(grid), b(64 * kIcpWavesPerBlock);
     if (p.filter) {
-        if (p.big) {
-            if (fused) hipLaunchKernelGGL((k_icp<LW, true, true, true>), g, b, lds, s, p);
-            else hipLaunchKernelGGL((k_icp<LW, false, true, true>), g, b, lds, s, p);
-        } else {
-            if (fused) hipLaunchKernelGGL((k_icp<LW, true, false, true>), g, b, lds, s, p);
-            else hipLaunchKernelGGL((k_icp<LW, false, false, true>), g, b, lds, s, p);
-        }
-    } else if (p.big) {
-        if (fused) hipLaunchKernelGGL((k_icp<LW, true, true, false>), g, b, lds, s, p);
-        else hipLaunchKernelGGL((k_icp<LW, false, true, false>), g, b, lds, s, p);
+        if (fused) hipLaunchKernelGGL((k_icp<LW, true, true>), g, b, lds, s, p);
+        else hipLaunchKernelGGL((k_icp<LW, false, true>), g, b, lds, s, p);
     } else {
-        if (fused) hipLaunchKernelGGL((k_icp<LW, true, false, false>), g, b, lds, s, p);
-        else hipLaunchKernelGGL((k_icp<LW, false, false, false>), g, b, lds, s, p);
+        if (fused) hipLaunchKernelGGL((k_icp<LW, true, false>), g, b, lds, s, p);
+        else hipLaunchKernelGGL((k_icp<LW, false, false>), g, b, lds, s, p);
     }
 }
 void launch_icp(const IcpParams &p, int lw, bool fused, hipStream_t s) {

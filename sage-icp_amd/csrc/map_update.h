@@ -54,8 +54,8 @@ struct DevMap {
     uint32_t class_points[4];
     int n_classes;
 };
-constexpr uint32_t kDevUnitPoints = 4;
-constexpr uint32_t kDevNoRegion = 0xFFFFFFFFu;
+constexpr uint32_t kDevUnitPoints = kUnitPoints;
+constexpr uint32_t kDevNoRegion = kNoRegion;
 
 struct UpdatePolicy {
     double voxel_size;

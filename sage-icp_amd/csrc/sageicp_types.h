@@ -49,6 +49,13 @@ constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 constexpr int kMaxBlockBits = 24;   // block_index < 2^24 - 2 (the slot word keeps 8 bits for the count;
                                     // the two top block numbers would collide with the empty / tombstone marks)
 constexpr int kMaxCap = 255;        // basic + critical points per voxel
+// Voxel storage: the point array is cut into units of kUnitPoints points (128 B); a voxel's points
+// are one region of whole units whose size class follows its count (host_map.hpp).  regions[block] =
+// (class << 28) | first unit; the search's rows carry (unit << 8) | count, hence 24 bits of units.
+constexpr uint32_t kUnitPoints = 4;
+constexpr uint32_t kMaxUnits = (1u << 24) - 2;
+constexpr int kMaxClasses = 4;
+constexpr uint32_t kNoRegion = 0xFFFFFFFFu;
 
 // Any hash works (the reference's 20-bit hash, VoxelHashMap.hpp:72-77, only shapes bucket
 // order, never results).  This one mixes all 96 key bits so linear-probe runs stay short.

@@ -248,11 +248,13 @@ def test_mirror_refresh_after_updates(gpu_sage, oracle, scan_form):
     assert len(c2.GetCorrespondences(q, 3.0, 0.4)[0]) == len(oidx)
 
 
-def test_map_of_ten_million_voxels_beyond_4_gib(gpu_sage, oracle):
+def test_map_of_ten_million_voxels_in_under_3_gb(gpu_sage, oracle):
     """A 0.1 m voxel map of more than 10 M voxels (KITTI-360-at-0.1-m scale; round 1 stopped at
-    2^23 voxels / 4 GiB of points): 13+ GB of voxel blocks addressed through 64-bit loads.
-    Correspondences index-exact against the oracle, a planted offset recovered, and the per-frame
-    device-side update works at that size."""
+    2^23 voxels, round 2 spent 13.8 GB of 40-point blocks on it): with size-classed regions a
+    one-point voxel holds 4 point slots.  Correspondences index-exact against the oracle, a planted
+    offset recovered, and the per-frame device-side update works at that size."""
+    import torch
+    free0 = torch.cuda.mem_get_info()[0]
     n = 222                                   # 222^3 = 10.9 M lattice points, one per 0.1 m voxel
     g = (np.arange(n, dtype=np.float64) - n // 2) * 0.1 + 0.031
     rng = np.random.default_rng(123)
@@ -266,6 +268,11 @@ def test_map_of_ten_million_voxels_beyond_4_gib(gpu_sage, oracle):
     a.AddPoints(mp)
     # (truncation toward zero: the two lattice layers around 0 share voxel 0 on every axis)
     assert a.num_voxels() == (n - 1) ** 3 > 10_000_000 and a.size() == len(mp)
+    assert a.point_slots() * 32 < 1.6e9                 # 4 slots of 32 B per voxel, a few of 8
+    a.sync()
+    torch.cuda.synchronize()
+    # the map in HBM: table (2^26 slots of 16 B = 1.07 GB) + points + block->region words
+    assert free0 - torch.cuda.mem_get_info()[0] < 3.0e9
     b = oracle.Map(0.1, 100.0)
     b.add_points(mp)
     sel = rng.choice(len(mp), 60000, replace=False)
@@ -287,6 +294,9 @@ def test_map_of_ten_million_voxels_beyond_4_gib(gpu_sage, oracle):
     a.UpdateOnDevice(scan[:20000], pose)
     b.update(scan[:20000], pose)
     assert a.size() == b.size() >= before
+    # ... with the scratch of a search, a registration and a device-side update on top
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] < 3.5e9
 
 
 def test_maximum_voxel_capacity(gpu_sage, oracle, scan_form):
@@ -406,11 +416,12 @@ def test_every_lanes_per_query_variant(gpu_sage, oracle, scan_form, lw, monkeypa
     assert st.compact_scan == (1 if scan_form == "compact" else 0)
 
 
-def test_wide_addressing_in_both_scan_forms(gpu_sage, oracle, scan_form, monkeypatch):
-    """the k_icp variant for point arrays of 4 GiB and more (64-bit addressed records, compact
-    and full), forced onto a small map: index-exact search and the same registration"""
+def test_full_size_regions_in_both_scan_forms(gpu_sage, oracle, scan_form, monkeypatch):
+    """SAGEICP_SIZE_CLASSES=0: every voxel owns a region of max_points_per_voxel points (the
+    layout of rounds 1-2) — the same index-exact search and the same registration as with size
+    classes, in both scan forms"""
     from sage_icp_amd import synthetic as syn
-    monkeypatch.setenv("SAGEICP_FORCE_BIG", "1")
+    monkeypatch.setenv("SAGEICP_SIZE_CLASSES", "0")
     mp, q = random_scene(21)
     a, b = both_maps(gpu_sage, oracle, mp)
     for th in (0.4, 1.0):
