@@ -18,7 +18,30 @@ def used():
     return total - free
 
 
+def lattice():
+    """the 10.9 M-voxel 0.1 m test map of tests/test_gpu_parity.py: one point per voxel"""
+    import numpy as np
+    n = 222
+    g = (np.arange(n, dtype=np.float64) - n // 2) * 0.1 + 0.031
+    mp = np.empty((n * n * n, 4))
+    mp[:, 0] = np.repeat(g, n * n)
+    mp[:, 1] = np.tile(np.repeat(g, n), n)
+    mp[:, 2] = np.tile(g, n * n)
+    mp[:, 3] = 40
+    torch.zeros(1, device="cuda")
+    base = used()
+    m = sage.VoxelHashMap(0.1, 100.0)
+    m.AddPoints(mp)
+    m.sync()
+    print("lattice: %d voxels, %d points, %d point slots (%.2f GB); device memory: map mirror %.2f GB (size classes %s)"
+          % (m.num_voxels(), m.size(), m.point_slots(), m.point_slots() * 32 / 1e9, (used() - base) / 1e9,
+             os.environ.get("SAGEICP_SIZE_CLASSES", "on")))
+
+
 for name in (sys.argv[1:] or ["c5"]):
+    if name == "lattice":
+        lattice()
+        continue
     wl = syn.WORKLOADS[name]
     torch.zeros(1, device="cuda")
     base = used()
@@ -33,3 +56,6 @@ for name in (sys.argv[1:] or ["c5"]):
     print("%s: %d voxels, %d points; device memory: map mirror %.2f GB, after one RegisterFrame %.2f GB "
           "(size classes %s)" % (name, vmap.num_voxels(), vmap.size(), (m_sync - base) / 1e9, (m_reg - base) / 1e9,
                                  os.environ.get("SAGEICP_SIZE_CLASSES", "on")))
+    del w, vmap, scan              # (the next workload's baseline must not include this map)
+    import gc
+    gc.collect()

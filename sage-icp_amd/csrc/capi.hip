@@ -592,6 +592,8 @@ struct sageicp_map {
     mutable size_t d_free_units_cap[kMaxClasses] = {};
     mutable uint32_t *d_freed = nullptr;                // regions released by one insertion pass
     mutable size_t d_freed_cap = 0;
+    mutable uint32_t *d_block_of = nullptr;             // device-side update: unit -> block (slot words carry units)
+    mutable size_t d_block_of_cap = 0;
     mutable bool mirror_stale_all = true;
     // compact copy of d_pts for k_icp's scan (fp32 x, y, z, label), derived on the device whenever
     // the HBM copy of the map has changed since the last search
@@ -850,6 +852,7 @@ int ensure_cand(const sageicp_map *m, bool derive = true) {
         HIPCHK(hipMalloc(&m->d_cand_flags, 16));
         HIPCHK(hipMemsetAsync(m->d_cand_flags, 0, 16, s));
     }
+    if (!derive) return SAGEICP_OK;             // (this search reads the full records: no copy is made for it)
     if (slots > m->d_cand_slots) {
         if (m->d_cand) HIPCHK(hipFree(m->d_cand));
         m->d_cand = nullptr; m->d_cand_slots = 0;
@@ -857,11 +860,11 @@ int ensure_cand(const sageicp_map *m, bool derive = true) {
         m->d_cand_slots = slots;
         m->cand_stale = true;
     }
-    if (!m->cand_stale || !derive) return SAGEICP_OK;
+    if (!m->cand_stale) return SAGEICP_OK;
     HIPCHK(hipMemsetAsync(m->d_cand_flags, 0, 16, s));
     if (m->d_table && m->d_pts && slots)
-        launch_derive_cand(m->d_table, static_cast<uint32_t>(m->d_table_cap), m->d_regions, m->d_pts, m->d_cand,
-                           slots, m->d_cand_flags, s);
+        launch_derive_cand(m->d_table, static_cast<uint32_t>(m->d_table_cap), m->d_pts, m->d_cand, slots,
+                           m->d_cand_flags, s);
     HIPCHK(hipGetLastError());
     m->cand_stale = false;
     return SAGEICP_OK;
@@ -1012,6 +1015,18 @@ static int reserve_unit_stacks(const sageicp_map *m, size_t n) {
         m->d_free_units[k] = nf;
         m->d_free_units_cap[k] = need;
     }
+    if (m->d_units_cap > m->d_block_of_cap) {
+        uint32_t *nb = nullptr;
+        HIPCHK(hipMalloc(&nb, m->d_units_cap * sizeof(uint32_t)));
+        if (m->on_device && m->d_block_of && m->ctr.units_hi)
+            HIPCHK(hipMemcpyAsync(nb, m->d_block_of, static_cast<size_t>(m->ctr.units_hi) * sizeof(uint32_t),
+                                  hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (m->d_block_of) HIPCHK(hipFree(m->d_block_of));
+        m->d_block_of = nb;
+        m->d_block_of_cap = m->d_units_cap;
+        if (!m->on_device) m->aux_valid = false;        // (derived from the host's view below)
+    }
     if (n > m->d_freed_cap) {
         if (m->d_freed) HIPCHK(hipFree(m->d_freed));
         m->d_freed = nullptr; m->d_freed_cap = 0;
@@ -1033,6 +1048,7 @@ static DevMap dev_map(const sageicp_map *m) {
     dm.free_list = m->d_free;
     dm.ctr = m->d_ctr;
     dm.regions = m->d_regions;
+    dm.block_of = m->d_block_of;
     for (int k = 0; k < kMaxClasses; ++k) {
         dm.free_units[k] = m->d_free_units[k];
         dm.class_points[k] = k < m->host.n_classes ? static_cast<uint32_t>(m->host.class_points[k]) : 0u;
@@ -1069,14 +1085,14 @@ int device_update(sageicp_map *m, const double *xyzl, uint64_t n, const double p
     const uint64_t need_blocks = static_cast<uint64_t>(m->ctr.blocks_hi) + n;
     if (need_blocks + 3 >= (1ull << kMaxBlockBits)) return fail(SAGEICP_ERR_CAPACITY, "more than 2^24 voxels");
     size_t blocks = m->d_blocks_cap;
-    if (need_blocks > blocks) blocks = std::max<size_t>(need_blocks, std::max<size_t>(1024, 2 * blocks));
+    if (need_blocks > blocks) blocks = std::max<size_t>(need_blocks, std::max<size_t>(1024, blocks + blocks / 4));
     if ((rc = grow_device_blocks(m, blocks, m->ctr.blocks_hi))) return rc;
     // ... and of units: a point opens a voxel (one unit) or, at worst, moves a full voxel into a
     // region of the last class
     const uint64_t need_units = static_cast<uint64_t>(m->ctr.units_hi) + n * static_cast<uint64_t>(h.class_units(h.n_classes - 1));
     if (need_units > kMaxUnits) return fail(SAGEICP_ERR_CAPACITY, "voxel storage beyond 2^24 units of 4 points");
     if (need_units > m->d_units_cap) {
-        const size_t units = std::min<size_t>(kMaxUnits, std::max<size_t>(need_units, std::max<size_t>(4096, 2 * m->d_units_cap)));
+        const size_t units = std::min<size_t>(kMaxUnits, std::max<size_t>(need_units, std::max<size_t>(4096, m->d_units_cap + m->d_units_cap / 4)));
         if ((rc = reserve_device_points(m, units, m->ctr.units_hi))) return rc;
     }
     if ((rc = reserve_unit_stacks(m, n))) return rc;
@@ -1096,6 +1112,7 @@ int device_update(sageicp_map *m, const double *xyzl, uint64_t n, const double p
             if (!h.free_units[k].empty())
                 HIPCHK(hipMemcpyAsync(m->d_free_units[k], h.free_units[k].data(),
                                       h.free_units[k].size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        map_derive_block_of(dev_map(m), h.blocks_hi, s);
         HIPCHK(hipStreamSynchronize(s));
         m->aux_valid = true;
         m->aux_generation = h.generation;
@@ -1229,7 +1246,7 @@ IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, 
     const uint64_t pts_bytes = (static_cast<uint64_t>(m->d_units_cap) * kUnitPoints + 1) * sizeof(Point4);
     ip.pts_bytes = static_cast<uint32_t>(pts_bytes);        // (< 4 GiB: kMaxUnits units of 128 B)
     ip.cand = m->d_cand;
-    ip.cand_bytes = static_cast<uint32_t>(pts_bytes / 2);
+    ip.cand_bytes = m->d_cand_slots >= m->d_units_cap * kUnitPoints ? static_cast<uint32_t>(pts_bytes / 2) : 0u;
     ip.cand_flags = m->d_cand_flags;
     // fp32 thresholds of the scan's filter (kernels.hip): off (infinite) for a negative or NaN
     // sem_th, where a larger distance can scale to a smaller one
@@ -1242,7 +1259,6 @@ IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, 
         ip.filt_inv_same = filt ? (sem_th > 0.0 ? k1 / sem_th : inf) : inf;
         ip.filt_slack = std::ldexp(1.0, -44) * 1025.0 * (1.0 + 1e-6);
     }
-    ip.regions = m->d_regions;      // (rows address storage units of 4 points: kernels.hip's row_word())
     ip.sem_th = sem_th;
     ip.dist_init = DBL_MAX;
     // scaled distance = d2 * sem_th for matching labels, d2 otherwise: >= min(sem_th, 1) * d2.
@@ -1759,6 +1775,7 @@ void sageicp_map_destroy(sageicp_map *m) {
             if (m->d_free_units[k]) (void)hipFree(m->d_free_units[k]);
         if (m->d_regions) (void)hipFree(m->d_regions);
         if (m->d_freed) (void)hipFree(m->d_freed);
+        if (m->d_block_of) (void)hipFree(m->d_block_of);
         void *aux[] = {m->d_zeros, m->d_slot_of, m->d_free, m->d_ctr, m->up.raw, m->up.w, m->up.keys,
                        m->up.keys_alt, m->up.idx, m->up.idx_alt, m->up.head_slot, m->up.flag, m->up.rank, m->up.want,
                        m->up.far_flag, m->up.far_sel, m->up.n_sel, m->up.temp};
@@ -1800,6 +1817,9 @@ static int clone_on_device(const sageicp_map *src, sageicp_map *m) {
             HIPCHK(hipMemcpyAsync(m->d_free_units[k], src->d_free_units[k],
                                   static_cast<size_t>(m->ctr.free_units_count[k]) * sizeof(uint32_t),
                                   hipMemcpyDeviceToDevice, s));
+    if (m->ctr.units_hi)
+        HIPCHK(hipMemcpyAsync(m->d_block_of, src->d_block_of, static_cast<size_t>(m->ctr.units_hi) * sizeof(uint32_t),
+                              hipMemcpyDeviceToDevice, s));
     if (m->ctr.blocks_hi) {
         HIPCHK(hipMemcpyAsync(m->d_regions, src->d_regions, m->ctr.blocks_hi * sizeof(uint32_t),
                               hipMemcpyDeviceToDevice, s));

@@ -15,8 +15,10 @@
 // (128 B).  A region holds 4, 8, 16 or (basic + critical) points — the smallest class that holds
 // the voxel's count; when a voxel outgrows its region its points move to one of the next class and
 // the old region goes to that class's free list.  A two-point voxel of a 0.1 m map then costs
-// 128 B instead of 1,280 B.  Readers never need the class: a region starts at unit x kUnitPoints
-// and the count says how far it is filled (the device's neighbourhood rows carry (unit << 8) | count).
+// 128 B instead of 1,280 B.  The SLOT WORD of a voxel is (first unit << 8) | count: a search goes
+// from the hash slot straight to the points, without the block (readers never need the class: a
+// region starts at unit x kUnitPoints and the count says how far it is filled); the map's own
+// bookkeeping gets from a slot to its block through `block_of[unit]`.
 //
 // Iteration order (Pointcloud(), far-voxel sweep) is block-pool order, not tsl::robin_map
 // bucket order; the far-voxel sweep removes EVERY voxel whose first point is out of range
@@ -124,6 +126,7 @@ public:
     uint32_t num_voxels = 0;
     PointStore pts;                   // block b owns pts[unit(b) * kUnitPoints ..) for class_size(class(b)) points
     std::vector<uint32_t> regions;    // per block: (class << 28) | first unit of its region (kNoRegion: free block)
+    std::vector<uint32_t> block_of;   // per unit: the block whose region starts there (stale for free regions)
     int n_classes = 1;                // region sizes in points, ascending; the last one is >= cap
     uint32_t class_points[kMaxClasses] = {40, 0, 0, 0};
     std::vector<uint32_t> free_units[kMaxClasses];   // per class: first units of free regions (stacks)
@@ -174,6 +177,7 @@ public:
         pts.clear();
         regions.clear();
         for (auto &f : free_units) f.clear();
+        block_of.clear();
         units_hi = 0;
         regions_all_dirty = true;
         dirty_regions.clear();
@@ -212,10 +216,10 @@ public:
                                                  static_cast<int32_t>(p[1] / voxel_size),
                                                  static_cast<int32_t>(p[2] / voxel_size)) & mask];
                 if (e.blk != kEmptySlot) {       // a hint only: the home slot may hold another voxel
-                    const size_t b = e.blk >> 8, c = e.blk & 255u;
-                    if (b < cnt.size() && regions[b] != kNoRegion) {
-                        __builtin_prefetch(&cnt[b]);
-                        const size_t f0 = first_point(static_cast<uint32_t>(b));
+                    const size_t u = e.blk >> 8, c = e.blk & 255u;
+                    if (u < block_of.size()) {
+                        __builtin_prefetch(&block_of[u]);
+                        const size_t f0 = u * kUnitPoints;
                         __builtin_prefetch(&pts[f0]);
                         __builtin_prefetch(&pts[f0 + (c < static_cast<size_t>(cap) ? c : 0)]);
                     }
@@ -279,10 +283,13 @@ public:
         regions_all_dirty = false;
         dirty_regions.clear();
         pts.resize(units_cap * kUnitPoints, static_cast<size_t>(uhi) * kUnitPoints);   // units [0, uhi) filled by the caller
+        block_of.assign(units_cap, 0);
+        for (uint32_t b = 0; b < bhi; ++b)
+            if (regions[b] != kNoRegion) block_of[region_unit(regions[b])] = b;
         for (const Slot &e : dtab) {
             if (e.blk == kEmptySlot || e.blk == kTombstone) continue;
             table[probe(e.x, e.y, e.z)] = e;
-            const uint32_t b = e.blk >> 8;
+            const uint32_t b = block_of[e.blk >> 8];
             cnt[b] = static_cast<uint8_t>(e.blk & 255u);
             keys[3 * b] = e.x; keys[3 * b + 1] = e.y; keys[3 * b + 2] = e.z;
         }
@@ -302,7 +309,7 @@ public:
     std::vector<uint32_t> slot_of_blocks() const {
         std::vector<uint32_t> so(cnt.size(), kNoSlot);
         for (uint32_t s = 0; s <= mask; ++s)
-            if (table[s].blk != kEmptySlot) so[table[s].blk >> 8] = s;
+            if (table[s].blk != kEmptySlot) so[block_of[table[s].blk >> 8]] = s;
         return so;
     }
 
@@ -410,6 +417,7 @@ private:
             const size_t need = static_cast<size_t>(units_hi) * kUnitPoints;
             if (need > pts.size()) pts.resize(std::max<size_t>(4096 * kUnitPoints, std::max(need, pts.size() * 2)), need);
             pts.set_used(need);                    // what a copy of the map carries
+            if (units_hi > block_of.size()) block_of.resize(pts.size() / kUnitPoints, 0);
         }
         return (k << 28) | u;
     }
@@ -425,6 +433,7 @@ private:
         for (int j = 0; j < c; ++j) mark_point(to + j);
         free_region(old);
         regions[b] = nr;
+        block_of[region_unit(nr)] = b;
         mark_region(b);
         return true;
     }
@@ -448,19 +457,20 @@ private:
             }
             const uint32_t b = alloc_block();
             regions[b] = alloc_region(0);
+            block_of[region_unit(regions[b])] = b;
             mark_region(b);
             pts[first_point(b)] = np;
             cnt[b] = 1;
             zeros[b] = static_cast<int>(p[3]) == 0 ? 1 : 0;
             keys[3 * b] = vx; keys[3 * b + 1] = vy; keys[3 * b + 2] = vz;
-            table[s] = Slot{vx, vy, vz, (b << 8) | 1u};
+            table[s] = Slot{vx, vy, vz, (region_unit(regions[b]) << 8) | 1u};
             ++num_voxels;
             ++total_points;
             mark_slot(s);
             mark_point(first_point(b));
             return 0;
         }
-        const uint32_t b = table[s].blk >> 8;
+        const uint32_t b = block_of[table[s].blk >> 8];
         Point4 *blk = &pts[first_point(b)];
         int c = cnt[b];
         bool full = false;                   // the map's point array (not the voxel) is out of room
@@ -472,7 +482,7 @@ private:
             blk[c] = np;
             if (static_cast<int>(p[3]) == 0) ++zeros[b];
             cnt[b] = static_cast<uint8_t>(c + 1);
-            table[s].blk = (b << 8) | static_cast<uint32_t>(c + 1);
+            table[s].blk = (region_unit(regions[b]) << 8) | static_cast<uint32_t>(c + 1);
             ++total_points;
             mark_slot(s);
             mark_point(first_point(b) + c);

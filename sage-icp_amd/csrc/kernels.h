@@ -29,9 +29,8 @@ struct IcpParams {
     int apply_pose;
     double voxel_size;
     uint32_t *rows;           // [n][kRowWords] cached neighbourhood rows
-    const Slot *table;        // the open-addressed voxel hash
-    const uint32_t *regions;  // per voxel block: (class << 28) | first unit (4 points) of its region of the
-                              // point array (host_map.hpp); a row word is (unit << 8) | count
+    const Slot *table;        // the open-addressed voxel hash; a slot word — and a row word — is
+                              // (first unit (4 points) of the voxel's region << 8) | count (host_map.hpp)
     uint32_t mask;
     const Point4 *pts;
     uint32_t pts_bytes;       // size of the point array: under 4 GiB (2^24 units of 128 B), read with 32-bit
@@ -80,8 +79,8 @@ int icp_blocks_for(int n, int lw);
 size_t icp_lds_bytes(int lw);
 void launch_rows(const IcpParams &p, hipStream_t s);                     // (re)build every row
 // the compact copy of the map's points the scan reads (see kernels.hip)
-void launch_derive_cand(const Slot *table, uint32_t nslots, const uint32_t *regions, const Point4 *pts,
-                        uint4 *cand, uint64_t nslots_pts, uint32_t *flags, hipStream_t s);
+void launch_derive_cand(const Slot *table, uint32_t nslots, const Point4 *pts, uint4 *cand, uint64_t nslots_pts,
+                        uint32_t *flags, hipStream_t s);
 void launch_icp(const IcpParams &p, int lw, bool fused, hipStream_t s);
 
 struct GnParams {             // stand-alone AlignClouds on explicit pairs

@@ -189,15 +189,14 @@ __device__ __forceinline__ uint4 load_cand(__amdgpu_buffer_rsrc_t cands, uint32_
 // The compact copy of the map: one thread per hash slot converts the points of its voxel.  A label
 // that is not an integer of magnitude < 2^24 cannot be classified in fp32: it is stored as a NaN
 // and raises bit 0 of *flags, which makes k_icp use the looser of its two thresholds everywhere.
-__global__ __launch_bounds__(256) void k_derive_cand(const Slot *table, uint32_t nslots, const uint32_t *regions,
-                                                     const Point4 *pts, uint4 *cand, uint64_t nslots_pts,
-                                                     uint32_t *flags) {
+__global__ __launch_bounds__(256) void k_derive_cand(const Slot *table, uint32_t nslots, const Point4 *pts,
+                                                     uint4 *cand, uint64_t nslots_pts, uint32_t *flags) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= nslots) return;
     const uint32_t w = table[i].blk;
     if (w == kEmptySlot || w == kTombstone) return;
     const uint32_t cnt = w & 255u;
-    const uint64_t first = static_cast<uint64_t>(regions[w >> 8] & 0x0FFFFFFFu) * 4u;     // the voxel's region
+    const uint64_t first = static_cast<uint64_t>(w >> 8) * kUnitPoints;      // the voxel's region
     bool inexact = false;
     for (uint32_t j = 0; j < cnt && first + j < nslots_pts; ++j) {
         const Point4 q = pts[first + j];
@@ -211,15 +210,16 @@ __global__ __launch_bounds__(256) void k_derive_cand(const Slot *table, uint32_t
     }
     if (inexact) atomicOr(flags, 1u);
 }
-void launch_derive_cand(const Slot *table, uint32_t nslots, const uint32_t *regions, const Point4 *pts,
-                        uint4 *cand, uint64_t nslots_pts, uint32_t *flags, hipStream_t s) {
+void launch_derive_cand(const Slot *table, uint32_t nslots, const Point4 *pts, uint4 *cand, uint64_t nslots_pts,
+                        uint32_t *flags, hipStream_t s) {
     if (nslots) hipLaunchKernelGGL(k_derive_cand, dim3((nslots + 255u) / 256u), dim3(256), 0, s, table, nslots,
-                                   regions, pts, cand, nslots_pts, flags);
+                                   pts, cand, nslots_pts, flags);
 }
 
 // --------------------------------------------------------------------------------- hash probing
 // The GPU-resident open-addressed hash: linear probing, 16-B slots, load factor <= 0.25, one 16-B
-// load per step.  Returns the slot's packed word (block << 8) | count, or kEmptySlot.
+// load per step.  Returns the slot's packed word (first unit of the voxel's points << 8) | count —
+// what a neighbourhood row keeps of a found voxel — or kEmptySlot.
 __device__ __forceinline__ uint32_t probe_resolve(const Slot *table, uint32_t mask, uint32_t sl,
                                                   int4 e, int vx, int vy, int vz) {
     for (;;) {
@@ -228,12 +228,6 @@ __device__ __forceinline__ uint32_t probe_resolve(const Slot *table, uint32_t ma
         sl = (sl + 1u) & mask;                    // tombstones (map_update.hip) never match
         e = reinterpret_cast<const int4 *>(table)[sl];
     }
-}
-// what a neighbourhood row keeps of a found voxel: where its points start (in units of 4 points:
-// the voxel's region, host_map.hpp) and how many there are
-__device__ __forceinline__ uint32_t row_word(const uint32_t *regions, uint32_t slot_word) {
-    if (slot_word == kEmptySlot) return kEmptySlot;
-    return ((regions[slot_word >> 8] & 0x0FFFFFFFu) << 8) | (slot_word & 255u);
 }
 __device__ __forceinline__ uint32_t probe_voxel(const Slot *table, uint32_t mask, int vx, int vy,
                                                 int vz) {
@@ -291,9 +285,8 @@ __global__ __launch_bounds__(256) void k_rows(IcpParams P) {
     const Query s = make_query(f, P.st, P.apply_pose, P.voxel_size);
     uint32_t w = kEmptySlot;
     if (valid && v < 27u)
-        w = row_word(P.regions, probe_voxel(P.table, P.mask, s.kx + static_cast<int>(v / 9u) - 1,
-                                            s.ky + static_cast<int>((v / 3u) % 3u) - 1,
-                                            s.kz + static_cast<int>(v % 3u) - 1));
+        w = probe_voxel(P.table, P.mask, s.kx + static_cast<int>(v / 9u) - 1,
+                        s.ky + static_cast<int>((v / 3u) % 3u) - 1, s.kz + static_cast<int>(v % 3u) - 1);
     const unsigned c = (w == kEmptySlot) ? 0u : (w & 255u);
     const unsigned long long b = __ballot(c != 0u);
     const unsigned occ = static_cast<unsigned>(b >> (lane & 32));
@@ -471,8 +464,8 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
             };
             auto finish = [&](int v, uint32_t sl, const int4 &e) {
                 if (v >= 27) return;
-                const uint32_t w = row_word(P.regions, probe_resolve(P.table, P.mask, sl, e, s.kx + v / 9 - 1,
-                                                                     s.ky + (v / 3) % 3 - 1, s.kz + v % 3 - 1));
+                const uint32_t w = probe_resolve(P.table, P.mask, sl, e, s.kx + v / 9 - 1, s.ky + (v / 3) % 3 - 1,
+                                                 s.kz + v % 3 - 1);
                 const unsigned c = (w == kEmptySlot) ? 0u : (w & 255u);
                 lrow[v] = w;
                 P.rows[static_cast<size_t>(q) * kRowWords + static_cast<unsigned>(v)] = w;

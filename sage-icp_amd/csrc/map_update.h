@@ -49,6 +49,7 @@ struct DevMap {
     MapCounters *ctr;
     // size-classed regions: block b's points start at unit (regions[b] & 0x0FFFFFFF), class in the top 4 bits
     uint32_t *regions;
+    uint32_t *block_of;      // unit -> the block whose region starts there (a slot word carries the unit)
     uint32_t *free_units[4]; // per class: stack of the first units of free regions
     uint32_t *freed;         // scratch: regions released during an insertion pass
     uint32_t class_points[4];
@@ -90,6 +91,10 @@ struct UpdateScratch {       // device buffers sized for n points / nb blocks (c
 };
 
 size_t map_update_temp_bytes(int n, int nb);
+
+// block_of[] from regions[] (blocks [0, blocks_hi)): when the device-side bookkeeping is set up from
+// the host's view of the map
+void map_derive_block_of(const DevMap &M, uint32_t blocks_hi, hipStream_t s);
 
 // Update(points, pose): w = pose * raw, insert in order, evict voxels far from pose.translation.
 // `blocks_hi_bound` >= the map's block high-water mark after the insert (grid size only).

@@ -268,16 +268,17 @@ __global__ __launch_bounds__(256) void k_up_insert(const unsigned long long *key
             b = (j < fc) ? M.free_list[fc - 1u - j] : M.ctr->blocks_hi + (j - fc);
             s = voxel_hash(vx, vy, vz) & M.mask;
             for (;;) {     // no key is compared in this phase: the first free slot of the chain is ours
-                if (atomicCAS(&M.table[s].blk, kEmptySlot, b << 8) == kEmptySlot) break;
+                if (atomicCAS(&M.table[s].blk, kEmptySlot, (nreg & 0x0FFFFFFFu) << 8) == kEmptySlot) break;
                 s = (s + 1) & M.mask;
             }
             M.table[s].x = vx;
             M.table[s].y = vy;
             M.table[s].z = vz;
             reg = nreg;
+            M.block_of[reg & 0x0FFFFFFFu] = b;
         } else {
             const uint32_t blk = M.table[s].blk;
-            b = blk >> 8;
+            b = M.block_of[blk >> 8];
             c = static_cast<int>(blk & 255u);
             z = M.zeros[b];
             reg = M.regions[b];
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(256) void k_up_insert(const unsigned long long *key
                 }
                 M.freed[my.mg] = reg;
                 reg = nreg;
+                M.block_of[reg & 0x0FFFFFFFu] = b;
             }
         }
         Point4 *blkp = M.pts + static_cast<size_t>(reg & 0x0FFFFFFFu) * kDevUnitPoints;
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(256) void k_up_insert(const unsigned long long *key
                 }
             }
         }
-        M.table[s].blk = (b << 8) | static_cast<uint32_t>(c);
+        M.table[s].blk = ((reg & 0x0FFFFFFFu) << 8) | static_cast<uint32_t>(c);
         M.zeros[b] = static_cast<uint8_t>(z);
         M.slot_of[b] = s;
         M.regions[b] = reg;
@@ -499,12 +501,23 @@ __global__ __launch_bounds__(256) void k_pc_gather_regions(DevMap M, uint32_t bl
     out[static_cast<size_t>(offsets[b]) + j] =
         M.pts[static_cast<size_t>(M.regions[b] & 0x0FFFFFFFu) * kDevUnitPoints + j];
 }
+__global__ __launch_bounds__(256) void k_derive_block_of(DevMap M, uint32_t blocks_hi) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= blocks_hi) return;
+    const uint32_t r = M.regions[b];
+    if (r != kDevNoRegion) M.block_of[r & 0x0FFFFFFFu] = b;
+}
 __global__ void k_rebuild_after(MapCounters *ctr) {
     if (threadIdx.x || blockIdx.x) return;
     ctr->used_slots = ctr->num_voxels;
 }
 
 }  // namespace
+
+void map_derive_block_of(const DevMap &M, uint32_t blocks_hi, hipStream_t s) {
+    if (blocks_hi)
+        hipLaunchKernelGGL(k_derive_block_of, dim3((blocks_hi + 255u) / 256u), dim3(256), 0, s, M, blocks_hi);
+}
 
 size_t map_update_temp_bytes(int n, int nb) {
     size_t a = 0, b = 0, c = 0;

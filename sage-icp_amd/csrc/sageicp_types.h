@@ -33,8 +33,9 @@
 
 namespace sageicp {
 
-// One open-addressed hash slot, 16 B.  `blk` packs (block_index << 8) | point_count so a probe
-// returns the candidate count without a second load; kEmptySlot marks a free slot.  Linear
+// One open-addressed hash slot, 16 B.  `blk` packs (first storage unit of the voxel's points << 8) |
+// point_count, so a probe returns where the candidates are and how many without a second load;
+// kEmptySlot marks a free slot.  Linear
 // probing, power-of-two capacity, load factor <= 0.25 (misses dominate the 27-voxel probe).
 struct alignas(16) Slot {
     int32_t x, y, z;
@@ -46,8 +47,9 @@ constexpr uint32_t kEmptySlot = 0xFFFFFFFFu;
 constexpr uint32_t kTombstone = 0xFFFFFFFEu;
 constexpr int32_t kTombKey = 0x7F7F7F7F;
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
-constexpr int kMaxBlockBits = 24;   // block_index < 2^24 - 2 (the slot word keeps 8 bits for the count;
-                                    // the two top block numbers would collide with the empty / tombstone marks)
+constexpr int kMaxBlockBits = 24;   // voxels (blocks) < 2^24 - 2; the slot word keeps 24 bits for the unit and 8
+                                    // for the count (the two top unit numbers would collide with the empty /
+                                    // tombstone marks: kMaxUnits)
 constexpr int kMaxCap = 255;        // basic + critical points per voxel
 // Voxel storage: the point array is cut into units of kUnitPoints points (128 B); a voxel's points
 // are one region of whole units whose size class follows its count (host_map.hpp).  regions[block] =
