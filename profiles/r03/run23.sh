@@ -9,10 +9,10 @@ for a in "c1 cold" "c2 steady" "c4 cold" "c5 dense" "c5 dense_nosem"; do set -- 
   timeout 600 python bench.py --workload $1 --params $2 --no-cpu-baseline --steps 10 2>/dev/null | grep '^{' > gpurun_out/bench_$1_$2.json; python -c "
 import json; d=json.load(open('gpurun_out/bench_$1_$2.json')); print('$1 $2:', d['value'], d['ms_per_step'], d['config']['iterations_per_frame'], d['roofline']['avg_launch_us'])"
 done
-timeout 300 python profiles/stream_probe.py > gpurun_out/stream_final2.txt 2>&1; grep "per frame" gpurun_out/stream_final.txt
-STREAM_LOCALMAP=1 timeout 300 python profiles/stream_probe.py > gpurun_out/stream_localmap_final2.txt 2>&1; grep "per frame\|LocalMap() per" gpurun_out/stream_localmap_final.txt
-STREAM_PREFETCH=1 timeout 300 python profiles/stream_probe.py > gpurun_out/stream_prefetch_final2.txt 2>&1; grep "per frame" gpurun_out/stream_prefetch_final.txt
-timeout 600 python profiles/fin_phases.py c2 c4 > gpurun_out/fin_phases_final2.txt 2>&1; grep "sum (" gpurun_out/fin_phases_final.txt
-timeout 600 python profiles/shard_probe.py c2 cold > gpurun_out/shard_c2_final2.txt 2>&1; cat gpurun_out/shard_c2_final.txt
-timeout 900 python profiles/shard_probe.py c4 steady > gpurun_out/shard_c4_final2.txt 2>&1; cat gpurun_out/shard_c4_final.txt
-timeout 600 python profiles/map_memory.py c5 c4 2>&1 | grep "device memory"
+timeout 300 python profiles/stream_probe.py > gpurun_out/stream_final2.txt 2>&1; grep "per frame" gpurun_out/stream_final2.txt
+STREAM_LOCALMAP=1 timeout 300 python profiles/stream_probe.py > gpurun_out/stream_localmap_final2.txt 2>&1; grep "per frame\|LocalMap() per" gpurun_out/stream_localmap_final2.txt
+STREAM_PREFETCH=1 timeout 300 python profiles/stream_probe.py > gpurun_out/stream_prefetch_final2.txt 2>&1; grep "per frame" gpurun_out/stream_prefetch_final2.txt
+timeout 600 python profiles/fin_phases.py c2 c4 > gpurun_out/fin_phases_final2.txt 2>&1; grep "sum (" gpurun_out/fin_phases_final2.txt
+timeout 600 python profiles/shard_probe.py c2 cold > gpurun_out/shard_c2_final2.txt 2>&1; cat gpurun_out/shard_c2_final2.txt
+timeout 900 python profiles/shard_probe.py c4 steady > gpurun_out/shard_c4_final2.txt 2>&1; cat gpurun_out/shard_c4_final2.txt
+timeout 900 python profiles/map_memory.py c5 c4 lattice 2>&1 | grep "device memory"

@@ -772,10 +772,13 @@ int sync_mirror(const sageicp_map *m) {
     }
     // (the host arrays grow by doubling; the map itself never holds more than 2^24 units of 4
     // points — HostMap::add_point refuses the point that would cross the limit)
-    // (sized by what the map holds, not by the host vector's doubled capacity)
+    // (a small map gets the host vector's doubled capacity — a growing map re-allocates rarely —, a
+    // big one what it holds and an eighth)
     bool points_full = h.points_all_dirty || m->mirror_stale_all;
     if (h.units_hi > m->d_units_cap) {
-        const size_t want = std::min<size_t>(kMaxUnits, static_cast<size_t>(h.units_hi) + h.units_hi / 8 + 1024);
+        const size_t want = h.units_hi < (1u << 22)
+                                ? std::max<size_t>(h.pts.size() / kUnitPoints, h.units_hi)
+                                : std::min<size_t>(kMaxUnits, static_cast<size_t>(h.units_hi) + h.units_hi / 8 + 1024);
         if ((rc = reserve_device_points(m, want, 0))) return rc;
         points_full = true;
     }
@@ -1085,14 +1088,17 @@ int device_update(sageicp_map *m, const double *xyzl, uint64_t n, const double p
     const uint64_t need_blocks = static_cast<uint64_t>(m->ctr.blocks_hi) + n;
     if (need_blocks + 3 >= (1ull << kMaxBlockBits)) return fail(SAGEICP_ERR_CAPACITY, "more than 2^24 voxels");
     size_t blocks = m->d_blocks_cap;
-    if (need_blocks > blocks) blocks = std::max<size_t>(need_blocks, std::max<size_t>(1024, blocks + blocks / 4));
+    // (growth: doubling while the arrays are small — a growing map re-allocates rarely —, by a quarter
+    // beyond 4 M blocks / units, where a doubled array would be most of the map's footprint)
+    auto grown = [](size_t cap) { return cap < (size_t{1} << 22) ? 2 * cap : cap + cap / 4; };
+    if (need_blocks > blocks) blocks = std::max<size_t>(need_blocks, std::max<size_t>(1024, grown(blocks)));
     if ((rc = grow_device_blocks(m, blocks, m->ctr.blocks_hi))) return rc;
     // ... and of units: a point opens a voxel (one unit) or, at worst, moves a full voxel into a
     // region of the last class
     const uint64_t need_units = static_cast<uint64_t>(m->ctr.units_hi) + n * static_cast<uint64_t>(h.class_units(h.n_classes - 1));
     if (need_units > kMaxUnits) return fail(SAGEICP_ERR_CAPACITY, "voxel storage beyond 2^24 units of 4 points");
     if (need_units > m->d_units_cap) {
-        const size_t units = std::min<size_t>(kMaxUnits, std::max<size_t>(need_units, std::max<size_t>(4096, m->d_units_cap + m->d_units_cap / 4)));
+        const size_t units = std::min<size_t>(kMaxUnits, std::max<size_t>(need_units, std::max<size_t>(4096, grown(m->d_units_cap))));
         if ((rc = reserve_device_points(m, units, m->ctr.units_hi))) return rc;
     }
     if ((rc = reserve_unit_stacks(m, n))) return rc;
