@@ -45,7 +45,8 @@ typedef struct sageicp_comm sageicp_comm;     /* opaque: RCCL communicator for q
  * below are part of it.   2: sageicp_stats without the three fields that had become constant
  * zeros (us_group, us_gn, resorts), with pairs_evaluated / lanes_per_query / compact_scan;
  * capacity limits 2^24 voxels / 2^26 point slots (sageicp_map_point_slots) / |voxel index| < 2^20 (SAGEICP_ERR_CAPACITY);
- * sageicp_comm_describe, sageicp_map_pointcloud served from the HBM copy. */
+ * sageicp_comm_describe, sageicp_map_pointcloud served from the HBM copy, sageicp_map_point_slots
+ * (size-classed voxel storage). */
 #define SAGEICP_ABI_VERSION 2
 
 /* Filled by sageicp_register_frame*.  Times are microseconds. */
