@@ -1,0 +1,1 @@
+timeout 900 python -m pytest tests/test_map_update_device.py -m gpu -x -q 2>&1 | tail -15

@@ -37,6 +37,17 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(HERE, f)) > t for f in SOURCES + HEADERS)
 
 
+def _prune(keep, newest=6):
+    """object directories of header / flag sets that are no longer built: the newest few stay (the
+    default build, the squared-norm variant, a probe build or two), the rest go — every edit of a
+    header opens a new directory of 9 MB"""
+    import shutil
+    dirs = [os.path.join(OBJ_DIR, d) for d in os.listdir(OBJ_DIR)]
+    dirs = sorted((d for d in dirs if os.path.isdir(d) and d != keep), key=os.path.getmtime, reverse=True)
+    for d in dirs[newest - 1:]:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def build(force=False, verbose=False, out=OUT, defines=(), jobs=None):
     """defines: extra -D flags (instrumented probe builds keep their objects apart)."""
     if not force and out == OUT and not defines and not needs_build():
@@ -46,6 +57,7 @@ def build(force=False, verbose=False, out=OUT, defines=(), jobs=None):
     tag = _stamp(extra)
     odir = os.path.join(OBJ_DIR, tag)
     os.makedirs(odir, exist_ok=True)
+    _prune(keep=odir)
 
     def compile_one(src):
         path = os.path.join(HERE, src)

@@ -190,3 +190,49 @@ def test_pointcloud_of_a_resident_map_keeps_it_resident(gpu_sage, oracle):
     assert not dev.resident() and np.array_equal(dev.Pointcloud(), host.Pointcloud())
     dev.Clear()
     assert dev.Pointcloud().shape == (0, 4)
+
+
+def test_regions_follow_the_counts_and_are_reused(gpu_sage, oracle, monkeypatch):
+    """size-classed storage under the device-side update: voxels climb 4 -> 8 -> 16 -> cap as a
+    dense clump fills up, evicted and outgrown regions are handed out again, the map stays
+    block-for-block the host's (and the map with one full-size class, SAGEICP_SIZE_CLASSES=0) and
+    its footprint follows what it holds"""
+    sage = gpu_sage
+    dev, host, _ = _maps(sage, oracle, 0.5, 14.0, 20, 20)
+    monkeypatch.setenv("SAGEICP_SIZE_CLASSES", "0")
+    flat = sage.VoxelHashMap(0.5, 14.0, basic_points_per_voxel=20, critical_points_per_voxel=20)
+    monkeypatch.delenv("SAGEICP_SIZE_CLASSES")
+    rng = np.random.default_rng(44)
+    peak = 0
+    for k in range(14):
+        pose = np.array([0.0, 0.0, 0.0, 1.0, 2.5 * k, 0.0, 0.0])
+        # a clump that keeps receiving points (voxels move up a class between and inside passes),
+        # a sparse cloud around it (one- and two-point voxels), and long runs into single voxels
+        p = np.concatenate([rng.normal(size=(2500, 4)) * 0.7, rng.uniform(-9, 9, size=(2500, 4)),
+                            rng.uniform(0.0, 0.45, size=(300, 4)) + np.array([3.0, 3.0, 0.0, 0.0])])
+        p[:, 3] = rng.choice(LABELS, size=len(p))
+        for m in (dev, flat):
+            m.UpdateOnDevice(p, pose)
+        host.Update(p, pose)
+        assert dev.resident() and dev.size() == host.size() == flat.size()
+        assert dev.point_slots() >= dev.size() and flat.point_slots() >= 40 * flat.num_voxels()
+        peak = max(peak, dev.point_slots())
+    a = dev.Pointcloud()
+    assert np.array_equal(a, host.Pointcloud()) and np.array_equal(a, flat.Pointcloud())
+    # the high-water mark of the allocator stays near what the map held at its fullest: freed
+    # regions are reused, not leaked (the eviction radius keeps about five frames alive)
+    assert dev.point_slots() == peak and peak < 0.55 * flat.point_slots()
+    later = dev.point_slots()
+    for k in range(14, 20):
+        pose = np.array([0.0, 0.0, 0.0, 1.0, 2.5 * k, 0.0, 0.0])
+        p = rng.uniform(-9, 9, size=(3000, 4))
+        p[:, 3] = rng.choice(LABELS, size=len(p))
+        dev.UpdateOnDevice(p, pose)
+        host.Update(p, pose)
+    assert np.array_equal(dev.Pointcloud(), host.Pointcloud())
+    assert dev.point_slots() <= later + 4 * 3000          # sparse frames into a map that is shedding its clump
+    # authority back to the host (download of table, regions, free stacks) and on
+    extra = rng.uniform(-4, 4, size=(500, 4)) + np.array([2.5 * 19, 0, 0, 0])
+    dev.AddPoints(extra)
+    host.AddPoints(extra)
+    assert not dev.resident() and np.array_equal(dev.Pointcloud(), host.Pointcloud())
