@@ -1093,10 +1093,21 @@ int device_update(sageicp_map *m, const double *xyzl, uint64_t n, const double p
     auto grown = [](size_t cap) { return cap < (size_t{1} << 22) ? 2 * cap : cap + cap / 4; };
     if (need_blocks > blocks) blocks = std::max<size_t>(need_blocks, std::max<size_t>(1024, grown(blocks)));
     if ((rc = grow_device_blocks(m, blocks, m->ctr.blocks_hi))) return rc;
-    // ... and of units: a point opens a voxel (one unit) or, at worst, moves a full voxel into a
-    // region of the last class
-    const uint64_t need_units = static_cast<uint64_t>(m->ctr.units_hi) + n * static_cast<uint64_t>(h.class_units(h.n_classes - 1));
-    if (need_units > kMaxUnits) return fail(SAGEICP_ERR_CAPACITY, "voxel storage beyond 2^24 units of 4 points");
+    // ... and of units.  One region per voxel run at most: a run into a new voxel takes at most
+    // `per_point` units per point of it (one with the reference's capacities: 1 unit for 1-4
+    // points, 2 for 5-8, 4 for 9-16, 10 beyond), a run into
+    // an existing voxel at worst moves it into a region of the last class — and there are no more
+    // such runs than voxels.  What the pass really needs is known on the device only
+    // (k_up_heads); should it exceed an array already at its limit of 2^24 units, the pass flags
+    // that before anything is written and the call fails below.
+    uint64_t per_point = 1;      // (a region of class k is first taken by a run of class_points[k-1] + 1 points)
+    for (int k = 0; k < h.n_classes; ++k) {
+        const uint64_t least = k ? h.class_points[k - 1] + 1u : 1u;
+        per_point = std::max<uint64_t>(per_point, (h.class_units(k) + least - 1) / least);
+    }
+    const uint64_t moving = std::min<uint64_t>(n, m->ctr.num_voxels);
+    const uint64_t need_units = std::min<uint64_t>(
+        kMaxUnits, static_cast<uint64_t>(m->ctr.units_hi) + n * per_point + moving * h.class_units(h.n_classes - 1));
     if (need_units > m->d_units_cap) {
         const size_t units = std::min<size_t>(kMaxUnits, std::max<size_t>(need_units, std::max<size_t>(4096, grown(m->d_units_cap))));
         if ((rc = reserve_device_points(m, units, m->ctr.units_hi))) return rc;
@@ -1165,11 +1176,8 @@ int device_update(sageicp_map *m, const double *xyzl, uint64_t n, const double p
         return fail(SAGEICP_ERR_CAPACITY, "voxel index beyond +-2^20 in the device map update");
     }
     if (m->h_ctr->unit_overflow) {
-        // (the reservation above covers the worst case; a set flag means the map's storage is in an
-        // undefined state)
-        m->on_device = false;
-        m->mirror_stale_all = true;
-        return fail(SAGEICP_ERR_CAPACITY, "device map update ran out of storage units");
+        // nothing was inserted or evicted here either
+        return fail(SAGEICP_ERR_CAPACITY, "voxel storage beyond 2^24 units of 4 points");
     }
 #ifdef SAGE_UP_TIMING
     {
@@ -1955,6 +1963,37 @@ int sageicp_map_update_pose_device(sageicp_map *m, const double *xyzl, uint64_t 
 // stays where it is — the node's per-frame LocalMap() (ros/ros2/OdometryServer.cpp:211-220 under
 // publish_frame, the launch files' default) costs the copy of the live points and nothing else:
 // no table rebuild, no re-upload before the next RegisterFrame.
+// Make the pages of [p, p + bytes) exist — the range is about to be overwritten as a whole — from
+// SAGEICP_TOUCH_THREADS (default 4; 0: off) parked threads, each a contiguous share populated with
+// one madvise(MADV_POPULATE_WRITE) call (Linux 5.14) or, where that is refused, by a byte written
+// into every page.  (Measured and not kept: asking for huge pages first — no better; the copy cut
+// in pieces running behind the populating threads — slower than populate-then-copy, 3.1 vs 2.2 ms.)
+static void pretouch(void *p, size_t bytes) {
+    static const int threads = env_int("SAGEICP_TOUCH_THREADS", 4);
+    constexpr size_t kPage = 4096;
+    if (threads <= 0 || bytes < (size_t{4} << 20)) return;
+    static ReplayPool pool;
+    static std::mutex one_at_a_time;
+    std::lock_guard<std::mutex> lk(one_at_a_time);
+    char *base = static_cast<char *>(p);
+    // whole pages inside the range go through madvise; the ragged ends are touched
+    char *lo_al = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(base) + kPage - 1) & ~(kPage - 1));
+    char *hi_al = reinterpret_cast<char *>(reinterpret_cast<uintptr_t>(base + bytes) & ~(kPage - 1));
+    *static_cast<volatile char *>(base) = 0;
+    *static_cast<volatile char *>(base + bytes - 1) = 0;
+    if (hi_al <= lo_al) return;
+    const size_t pages = static_cast<size_t>(hi_al - lo_al) / kPage, share = (pages + threads - 1) / threads;
+    const std::function<void(size_t)> job = [&](size_t t) {
+        const size_t lo = t * share, hi = std::min(pages, lo + share);
+        if (lo >= hi) return;
+#ifdef MADV_POPULATE_WRITE
+        if (madvise(lo_al + lo * kPage, (hi - lo) * kPage, MADV_POPULATE_WRITE) == 0) return;
+#endif
+        for (size_t i = lo; i < hi; ++i) *static_cast<volatile char *>(lo_al + i * kPage) = 0;
+    };
+    pool.run(static_cast<size_t>(threads), job, static_cast<size_t>(threads));
+}
+
 static int pointcloud_from_device(const sageicp_map *m, double *out, uint64_t cap, uint64_t *n_out) {
     HIPCHK(hipSetDevice(m->device));
     hipStream_t s = m->sc.stream;
@@ -1974,9 +2013,13 @@ static int pointcloud_from_device(const sageicp_map *m, double *out, uint64_t ca
     const DevMap dm = dev_map(m);
     HIPCHK(map_pointcloud_device(dm, m->ctr.blocks_hi, m->up.far_flag, m->up.far_sel, m->up.temp,
                                  m->up.temp_bytes, m->d_pc, s));
-    // (the destination is the caller's pageable buffer: the runtime stages the copy itself at
-    // 13 GB/s — 3.5 ms for the 46 MB of a 1.44 M-point local map; a pinned landing buffer read out by
-    // four host threads in pipelined pieces was measured slower, 5.2 ms, and is not kept)
+    // The destination is the caller's pageable buffer, and under the reference's interface a FRESH
+    // one every call (`std::vector<Eigen::Vector4d> Pointcloud()` returns by value: tens of MB
+    // straight from mmap).  The runtime's staged copy moves 63 MB in 1.2 ms into pages that exist —
+    // and in 3.4 ms into pages that do not: two thirds of the call were first-touch faults taken one
+    // by one inside the copy (profiles/pointcloud_probe.py).  So the pages are made to exist first, by a
+    // few parked host threads side by side, while the device packs the points.
+    pretouch(out, want * sizeof(Point4));
     HIPCHK(hipMemcpyAsync(out, m->d_pc, want * sizeof(Point4), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return SAGEICP_OK;
@@ -1989,6 +2032,7 @@ uint64_t sageicp_map_pointcloud(const sageicp_map *m, double *out, uint64_t cap)
         if (pointcloud_from_device(m, out, cap, &n)) return 0;
         return n;
     }
+    if (out) pretouch(out, static_cast<size_t>(std::min<uint64_t>(cap, m->host.total_points)) * sizeof(Point4));
     return m->host.pointcloud(out, out ? cap : 0);
 }
 

@@ -49,7 +49,7 @@ struct IcpParams {
     unsigned keep_all;        // 0x7FFFFFF: visit every occupied voxel (pruning off: sem_th < 0 or
                               // not a number); 0: prune by the cell lower bound
     // search-only mode (GetCorrespondences): the semantic nearest neighbour of every query
-    int32_t *nn_idx;          // out: point index (block * cap + slot) or -1
+    int32_t *nn_idx;          // out: the point's index in the point array (unit * 4 + slot) or -1
     // fused mode (the ICP loop): acceptance + Gauss-Newton accumulation in the same launch
     double kernel;            // robust kernel k: w = k^2 / (k + |r|^2)^2 (Registration.cpp:79)
     double accept_r2;         // largest r2 with sqrt(r2) < max_correspondence_distance (exact form

@@ -26,7 +26,7 @@ struct MapCounters {
     uint32_t n_new;          // voxels created by the last update
     uint32_t n_far;          // voxels evicted by the last update
     uint32_t overflow;       // a voxel index beyond +-2^20 was seen (update rejected)
-    uint32_t unit_overflow;  // the point array ran out of units (cannot happen: the host reserves the worst case)
+    uint32_t unit_overflow;  // the pass asks for more units than the point array holds (update rejected before a write)
     // size-classed regions (host_map.hpp): the unit allocator's state
     uint32_t units_hi;       // high-water mark
     uint32_t units_cap;      // units the point array holds

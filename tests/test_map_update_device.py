@@ -236,3 +236,21 @@ def test_regions_follow_the_counts_and_are_reused(gpu_sage, oracle, monkeypatch)
     dev.AddPoints(extra)
     host.AddPoints(extra)
     assert not dev.resident() and np.array_equal(dev.Pointcloud(), host.Pointcloud())
+
+
+def test_a_two_million_point_batch_into_an_empty_map(gpu_sage, oracle):
+    """the storage reserved for a pass is bounded by what its runs can ask for (a unit per point of
+    a new voxel, a last-class region per voxel that can move), not by a last-class region per POINT:
+    a first scan of millions of points must not hit the 2^24-unit limit"""
+    sage = gpu_sage
+    rng = np.random.default_rng(9)
+    p = rng.uniform(-90, 90, size=(2_000_000, 4))
+    p[:, 2] = rng.uniform(-3, 9, len(p))
+    p[:, 3] = rng.choice(LABELS, size=len(p))
+    dev = sage.VoxelHashMap(1.0, 400.0)
+    host = sage.VoxelHashMap(1.0, 400.0)
+    dev.UpdateOnDevice(p, sage.IDENTITY)
+    host.Update(p, sage.IDENTITY)
+    assert dev.resident() and dev.size() == host.size() and dev.num_voxels() == host.num_voxels()
+    assert np.array_equal(dev.Pointcloud(), host.Pointcloud())
+    assert dev.size() <= dev.point_slots() < 2.2 * dev.size()
