@@ -122,7 +122,10 @@ int sageicp_map_update_pose_device(sageicp_map *map, const double *xyzl, uint64_
 /* Pointcloud(), VoxelHashMap.cpp:132-142.  Returns the number of points the map holds; writes
  * at most `cap` of them (block-pool order; the reference's is its hash map's bucket order).  While
  * the HBM copy is the authority (after a device-side update) the points are packed on the device
- * and only they cross PCIe: the map stays resident, the next RegisterFrame uploads nothing. */
+ * and only they cross PCIe: the map stays resident, the next RegisterFrame uploads nothing.
+ * `out_xyzl` is typically a fresh allocation (the reference's Pointcloud() returns a new vector):
+ * its pages are populated by SAGEICP_TOUCH_THREADS (environment, default 4, 0: off) parked host
+ * threads before the copy, which otherwise spends two thirds of its time in first-touch faults. */
 uint64_t sageicp_map_pointcloud(const sageicp_map *map, double *out_xyzl, uint64_t cap);
 /* 1 while the HBM copy of the map is the authority (device-side updates; Pointcloud() and
  * RegisterFrame keep it so), 0 while the host copy is (AddPoints / Update on the host, Clear). */
