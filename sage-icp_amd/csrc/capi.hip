@@ -65,6 +65,12 @@ static int env_int(const char *name, int dflt) {
 static int icp_lw(uint64_t n, bool sparse_voxels) {
     const int e = env_int("SAGEICP_LW", -1);
     if (e >= 0) return e > 4 ? 4 : e;
+    // the biggest frames are bound by instruction issue, not by the length of a wave's chain: two
+    // lanes per query halve the per-query share of the fixed work (prologue, bounds, epilogue).
+    // Against sparse voxels — scans of a point or two per voxel, little to split — that pays from
+    // 80k queries on (c5, 200k: 188 -> 211 frames/s; 100k: 301 -> 321; 50k: 728 -> 707), against
+    // dense ones only at c4's size (500k: 47.4 -> 47.8, cold 63.3 -> 64.6; c2, 120k: 132 -> 118)
+    if (n >= (sparse_voxels ? 80000u : 400000u)) return 1;
     if (n >= 50000) return 2;
     // against voxels that hold a few points each a scan is two or three points per lane whatever
     // the split: four lanes per query then beat eight from 4k queries on (c1: 632 vs 616 frames/s)
