@@ -450,9 +450,9 @@ def main():
                     "algorithmic_bytes_per_launch": round(executed_bytes),
                     "algorithmic_bytes_model": "448 B x queries + 16 B x (query, map point) pairs evaluated "
                                                "(counted by the kernel) + 32 B x correspondences",
-                    "served_from": "mostly L2 / Infinity Cache (the 32-MB map and the 21 MB of per-query "
-                                   "streams fit the 256-MB Infinity Cache): see traffic / hbm_frac for "
-                                   "what crosses the L2s",
+                    "served_from": "L2 / Infinity Cache for the most part where map and per-query streams fit "
+                                   "the 256-MB Infinity Cache (c2: 32 MB + 21 MB): see traffic / hbm_frac "
+                                   "for what crosses the L2s",
                     "effective_gather_gbs": round(survey_bytes / (avg_us * 1e-6) / 1e9, 1),
                     "effective_gather_bytes_per_launch": round(survey_bytes),
                     "effective_gather_note": "SURVEY 8d's figure: every candidate of the 27 voxels charged "
