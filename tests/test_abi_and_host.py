@@ -7,6 +7,7 @@ import re
 
 import numpy as np
 import pytest
+from hypothesis import given, settings, strategies as st
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -193,6 +194,53 @@ def test_size_classed_storage_is_invisible_and_smaller(sage, oracle, monkeypatch
     small = sage.VoxelHashMap(1.0, 100.0, 2, 1)
     small.AddPoints(rng.uniform(-5, 5, size=(4000, 4)))
     assert small.point_slots() == 4 * small.num_voxels()
+
+
+@settings(max_examples=25, deadline=None, derandomize=True)
+@given(seed=st.integers(0, 2**31 - 1), vs=st.sampled_from([0.25, 1.0, 3.0]), basic=st.sampled_from([0, 1, 3, 6, 20]),
+       critical=st.sampled_from([1, 2, 5, 20, 60]), md=st.sampled_from([4.0, 12.0, 1000.0]),
+       n_pts=st.sampled_from([1, 50, 1500]), frames=st.integers(1, 7))
+def test_size_classes_property(sage, oracle, seed, vs, basic, critical, md, n_pts, frames):
+    """random capacities (below, at and far above the class sizes 4 / 8 / 16), voxel sizes, eviction
+    radii and batch sizes: the map with size-classed regions equals the map with one full-size
+    region per voxel in content AND order, and the oracle's in content; clones and Clear() included"""
+    import os
+    rng = np.random.default_rng(seed)
+    old = os.environ.get("SAGEICP_SIZE_CLASSES")
+    try:
+        os.environ["SAGEICP_SIZE_CLASSES"] = "0"
+        flat = sage.VoxelHashMap(vs, md, basic, critical)
+        os.environ.pop("SAGEICP_SIZE_CLASSES")
+        cls = sage.VoxelHashMap(vs, md, basic, critical)
+    finally:
+        if old is None:
+            os.environ.pop("SAGEICP_SIZE_CLASSES", None)
+        else:
+            os.environ["SAGEICP_SIZE_CLASSES"] = old
+    orc = oracle.Map(vs, md, basic, critical)
+    for k in range(frames):
+        c = rng.uniform(-3 * vs, 3 * vs, size=3)
+        pts = np.concatenate([rng.normal(size=(n_pts, 4)) * 0.8 * vs, rng.uniform(-5 * vs, 5 * vs, size=(n_pts, 4))])
+        pts[:, :3] += c
+        pts[:, 3] = rng.choice([0, 0, 40, 44, 50, 70, 71, 80], size=len(pts))
+        if seed % 3 == 0 and k == 2:
+            cls, keep = cls.clone(), cls          # go on with the copy; the original must stay intact
+            snapshot = keep.Pointcloud()
+        for m in (cls, flat):
+            m.Update(pts, c)
+        orc.add_points(pts)
+        orc.remove_far(c)
+        assert cls.size() == flat.size() == orc.size() and cls.num_voxels() == flat.num_voxels() == orc.num_voxels()
+        if seed % 3 == 0 and k == 2:
+            assert np.array_equal(keep.Pointcloud(), snapshot)
+        if seed % 5 == 0 and k == 3:
+            for m in (cls, flat):
+                m.Clear()
+            orc = oracle.Map(vs, md, basic, critical)
+    a = cls.Pointcloud()
+    assert np.array_equal(a, flat.Pointcloud())
+    assert np.array_equal(_sorted(a), _sorted(orc.pointcloud()))
+    assert cls.point_slots() >= cls.size() and flat.point_slots() >= flat.size()
 
 
 def test_synthetic_workload_is_deterministic_and_exact(sage):
