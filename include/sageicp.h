@@ -64,7 +64,7 @@ typedef struct sageicp_stats {
     double us_nn;               /* k_icp: pose apply + correspondence search + Gauss-Newton sums */
     double us_fin;              /* k_fin: reduction of the partials, solve, pose update */
     uint32_t nn_launches;       /* k_icp launches that were timed (us_nn / nn_launches = mean duration) */
-    uint32_t reserved0;
+    uint32_t single_launch;     /* 1: the whole loop ran inside one launch (k_loop: a frame that fits the machine, one GPU) */
     uint64_t sum_candidates;    /* sum over iterations and queries of C_q: map points stored in the
                                  * <=27 existing neighbour voxels of each query (this rank) */
     uint32_t n_corr_hist[64];   /* accepted correspondences of the first 64 iterations */

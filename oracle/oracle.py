@@ -11,10 +11,11 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# SAGE_SQNORM3_ORDER=1 in the environment selects the build with the other association of the
-# 3-term squared norms (sage_oracle.cpp); the product's loader follows the same variable
-SQNORM3_ORDER = 1 if os.environ.get("SAGE_SQNORM3_ORDER", "0") == "1" else 0
-_LIB_NAME = "libsage_oracle.n1.so" if SQNORM3_ORDER else "libsage_oracle.so"
+# SAGE_SQNORM3_ORDER=0 in the environment selects the build with the rounds-1-3 association of the
+# 3-term squared norms (sage_oracle.cpp; default 2 = Eigen 3.4's reductions, derived per call site);
+# the product's loader follows the same variable
+SQNORM3_ORDER = 0 if os.environ.get("SAGE_SQNORM3_ORDER", "2") == "0" else 2
+_LIB_NAME = "libsage_oracle.v0.so" if SQNORM3_ORDER == 0 else "libsage_oracle.so"
 _LIB_PATH = os.path.join(_HERE, _LIB_NAME)
 
 _dp = C.POINTER(C.c_double)
@@ -48,10 +49,10 @@ def build(force=False):
 
 
 def build_variants(force=False):
-    """both association orders (the checker of the SAGE_SQNORM3_ORDER=1 run of the suite travels
+    """both association orders (the checker of the SAGE_SQNORM3_ORDER=0 run of the suite travels
     to the GPU box prebuilt, like the default one)"""
     src = os.path.join(_HERE, "sage_oracle.cpp")
-    for name in ("libsage_oracle.so", "libsage_oracle.n1.so"):
+    for name in ("libsage_oracle.so", "libsage_oracle.v0.so"):
         path = os.path.join(_HERE, name)
         if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
             subprocess.check_call(["make", "-C", _HERE, "-B", name], stdout=subprocess.DEVNULL)

@@ -1,0 +1,50 @@
+"""Timeline of the one-launch loop (k_loop) from a build with -DSAGE_LOOP_TIMING: per iteration, when the
+workgroups counted themselves in, when the solving wave saw all counts / had the sums / had the step /
+had published, and when the workgroups held the next pose.  100-MHz ticks -> microseconds.
+    python profiles/loop_times.py [divisor of the c2 frame, default 8] [cold|steady]"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.getcwd())
+import numpy as np  # noqa: E402
+import sage_icp_amd as sage  # noqa: E402
+
+sage.LIB_PATH = os.environ.get("LOOP_LIB", os.path.join(os.path.dirname(sage.LIB_PATH), "_probe", "libsageicp_looptiming.so"))
+from sage_icp_amd import synthetic as syn  # noqa: E402
+
+div = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+p = syn.PARAMS[sys.argv[2] if len(sys.argv) > 2 else "cold"]
+w = syn.make_workload("c2", lambda: sage.VoxelHashMap(1.0, 100.0))
+n = len(w["scan"]) // div
+f = sage.Frame(w["map"], w["scan"][:n])
+os.environ["SAGEICP_LOOP"] = "2"
+for _ in range(3):
+    pose, st = sage.register_frame(f, w["map"], sage.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"], return_stats=True)
+assert st.single_launch == 1
+IT, WG = 64, 512
+wg = np.zeros((IT, WG, 2), dtype=np.uint64)
+sv = np.zeros((IT, 4), dtype=np.uint64)
+sage.lib().sageicp_debug_loop_times(wg.ctypes.data_as(C.c_void_p), sv.ctypes.data_as(C.c_void_p))
+wg = wg.astype(np.float64) / 100.0
+sv = sv.astype(np.float64) / 100.0
+used = wg[1, :, 0] > 0
+print("%d queries, %d lanes/query, %d iterations, %d query workgroups" % (n, st.lanes_per_query, st.iterations, used.sum()))
+print("per iteration, us after the previous pose was published:")
+print("  it | counted in: first  median  p90   last | solver: all in   sums   solved  published | pose held: first median last | iteration")
+rows = []
+for it in range(1, min(IT, st.iterations)):
+    t0 = sv[it - 1, 3]
+    a = np.sort(wg[it, used, 0]) - t0
+    h = np.sort(wg[it, used, 1]) - t0
+    s = sv[it] - t0
+    prev_h = np.sort(wg[it - 1, used, 1]) - t0
+    rows.append((prev_h[len(prev_h) // 2], a[0], a[len(a) // 2], a[int(len(a) * 0.9)], a[-1], s[0], s[1], s[2], s[3], h[0], h[len(h) // 2], h[-1]))
+    if it < 6 or it % 16 == 0:
+        print("  %3d |          %6.2f %6.2f %6.2f %6.2f |        %6.2f %6.2f %6.2f %6.2f |         %6.2f %6.2f %6.2f | %6.2f"
+              % (it, a[0], a[len(a) // 2], a[int(len(a) * 0.9)], a[-1], s[0], s[1], s[2], s[3], h[0] - s[3], h[len(h) // 2] - s[3], h[-1] - s[3], s[3]))
+r = np.array(rows[2:]).mean(0)
+print("mean: pose held (median workgroup, previous iteration) %.2f | counted in first %.2f median %.2f p90 %.2f last %.2f | all in %.2f sums %.2f solved %.2f published %.2f"
+      % tuple(r[:9]))
+print("      -> wait for the pose %.2f, search of the median workgroup %.2f, of the last %.2f, last count -> seen %.2f, read sums %.2f, solve %.2f, publish %.2f"
+      % (r[0], r[2] - r[0], r[4] - r[0], r[5] - r[4], r[6] - r[5], r[7] - r[6], r[8] - r[7]))

@@ -20,10 +20,11 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# SAGE_SQNORM3_ORDER=1 in the environment loads the build with the other association of the 3-term
-# squared norms (csrc/sageicp_types.h): libsageicp_hip.n1.so, built by build.py next to the default
-SQNORM3_ORDER = 1 if os.environ.get("SAGE_SQNORM3_ORDER", "0") == "1" else 0
-LIB_PATH = os.path.join(_HERE, "libsageicp_hip.n1.so" if SQNORM3_ORDER else "libsageicp_hip.so")
+# SAGE_SQNORM3_ORDER=0 in the environment loads the build with the rounds-1-3 association of the 3-term
+# squared norms (csrc/sageicp_types.h; default 2 = what Eigen 3.4's reductions evaluate, per call site):
+# libsageicp_hip.v0.so, built by build.py next to the default
+SQNORM3_ORDER = 0 if os.environ.get("SAGE_SQNORM3_ORDER", "2") == "0" else 2
+LIB_PATH = os.path.join(_HERE, "libsageicp_hip.v0.so" if SQNORM3_ORDER == 0 else "libsageicp_hip.so")
 
 _dp = C.POINTER(C.c_double)
 _u64p = C.POINTER(C.c_uint64)
@@ -57,7 +58,7 @@ class Stats(C.Structure):
         ("us_nn", C.c_double),
         ("us_fin", C.c_double),
         ("nn_launches", C.c_uint32),
-        ("reserved0", C.c_uint32),
+        ("single_launch", C.c_uint32),
         ("sum_candidates", C.c_uint64),
         ("n_corr_hist", C.c_uint32 * 64),
         ("pairs_evaluated", C.c_uint64),

@@ -80,15 +80,15 @@ def build(force=False, verbose=False, out=OUT, defines=(), jobs=None):
 
 
 def build_sqnorm3_variant(force=False, verbose=False):
-    """libsageicp_hip.n1.so: the same library with SAGE_SQNORM3_ORDER=1 (sageicp_types.h) — the other
-    association of the 3-term squared norms; `SAGE_SQNORM3_ORDER=1 pytest tests` runs the suite on
+    """libsageicp_hip.v0.so: the same library with SAGE_SQNORM3_ORDER=0 (sageicp_types.h) — the
+    association of the 3-term squared norms rounds 1-3 used; `SAGE_SQNORM3_ORDER=0 pytest tests` runs the suite on
     it against the oracle built the same way."""
-    out = os.path.join(HERE, "libsageicp_hip.n1.so")
+    out = os.path.join(HERE, "libsageicp_hip.v0.so")
     if not force and os.path.exists(out):
         t = os.path.getmtime(out)
         if not any(os.path.getmtime(os.path.join(HERE, f)) > t for f in SOURCES + HEADERS):
             return out
-    return build(force=True, verbose=verbose, out=out, defines=("SAGE_SQNORM3_ORDER=1",))
+    return build(force=True, verbose=verbose, out=out, defines=("SAGE_SQNORM3_ORDER=0",))
 
 
 if __name__ == "__main__":

@@ -26,6 +26,7 @@
 #include <limits>
 #include <memory>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <array>
 #include <string>
@@ -116,6 +117,8 @@ struct Scratch {
     double *d_partials = nullptr; size_t partials_cap = 0;
     double *d_partials2 = nullptr; size_t partials2_cap = 0;   // second stage of the reduction (k_red, big frames)
     long long *d_acc = nullptr;    // fixed-point accumulators of the Gauss-Newton sums (kernels.h, kAcc*)
+    LoopShared *d_loop = nullptr;  // what the workgroups of k_loop share inside its launch (kernels.h)
+    int num_cus = 0;
     unsigned long long *d_cand = nullptr;      // per-wave counters of k_icp [2 x sort_cap]
     IcpState *d_state = nullptr;
     IcpState *h_state = nullptr;   // pinned
@@ -134,6 +137,11 @@ struct Scratch {
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIPCHK(hipMalloc(&d_state, sizeof(IcpState)));
         HIPCHK(hipMalloc(&d_acc, sizeof(long long) * kAccReplicas * kAccWords));
+        HIPCHK(hipMalloc(&d_loop, sizeof(LoopShared)));
+        {
+            int cus = 0;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) num_cus = cus;
+        }
 
         HIPCHK(hipHostMalloc(&h_state, sizeof(IcpState), hipHostMallocDefault));
         HIPCHK(hipHostMalloc(&h_prog, sizeof(IcpProgress), hipHostMallocMapped | hipHostMallocCoherent));
@@ -242,6 +250,7 @@ struct Scratch {
         if (d_partials2) (void)hipFree(d_partials2);
         if (d_state) (void)hipFree(d_state);
         if (d_acc) (void)hipFree(d_acc);
+        if (d_loop) (void)hipFree(d_loop);
         if (d_cand) (void)hipFree(d_cand);
         if (h_state) (void)hipHostFree(h_state);
         if (h_prog) (void)hipHostFree(h_prog);
@@ -1302,8 +1311,62 @@ IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, 
     return ip;
 }
 
+// Shape of the one-launch loop (k_loop) for a frame of n points, or false when the frame does not fit
+// the machine in that form: every wave keeps 64 >> lw queries for the whole call, so all of them have
+// to be resident at once — at most two workgroups of up to eight waves per CU (128 registers a lane),
+// plus the one-wave solving workgroup.
+struct LoopPlan {
+    int lw, nw, grid;          // lanes per query (log2), waves per workgroup, workgroups incl. the solving one
+    bool filter;
+};
+static bool plan_loop(const sageicp_map *m, uint64_t n, double sem_th, LoopPlan *out) {
+    const Scratch &sc = m->sc;
+    const int mode = env_int("SAGEICP_LOOP", 1);       // 0: never, 1: where it fits and pays, 2: wherever it fits
+    if (mode == 0 || n == 0 || sc.num_cus < 8) return false;
+    int lw = icp_lw(n, sparse_voxels(m));
+    bool filter = wants_filter(m, n, sem_th);
+    if (lw < 1) return false;                          // (k_loop is built for 2..16 lanes per query)
+    if (lw > 2 && filter) {                            // (its compact scan for 2 and 4 lanes per query only)
+        if (std::getenv("SAGEICP_FILTER")) return false;
+        filter = false;
+    }
+    const uint64_t cap_waves = 2ull * static_cast<uint64_t>(sc.num_cus) * kLoopMaxWavesHost - kLoopMaxWavesHost;
+    uint64_t waves = (n + (64u >> lw) - 1) / (64u >> lw);
+    if (mode == 2 && env_int("SAGEICP_LW", -1) < 0) {
+        // fewer lanes per query than the launch-per-iteration loop would take, if that is what makes the frame fit
+        while (waves > cap_waves && lw > 1) {
+            --lw;
+            waves = (n + (64u >> lw) - 1) / (64u >> lw);
+        }
+    }
+    if (waves > cap_waves) return false;
+    const uint64_t max_wgs = 2ull * static_cast<uint64_t>(sc.num_cus) - 8;
+    int nw = static_cast<int>((waves + max_wgs - 1) / max_wgs);
+    nw = std::max(nw, std::min(kLoopMaxWavesHost, std::max(1, env_int("SAGEICP_LOOP_WAVES", 4))));
+    if (nw > kLoopMaxWavesHost) return false;
+    const uint64_t wgs = ((waves + nw - 1) / nw + 7) / 8 * 8;
+    // (cached per shape: the occupancy query costs microseconds)
+    static std::mutex mu;
+    static std::map<int, int> cache;
+    int per_cu;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        const int key = (sc.device << 16) | (lw << 8) | (filter ? 128 : 0) | nw;
+        auto it = cache.find(key);
+        if (it == cache.end()) it = cache.emplace(key, loop_blocks_per_cu(lw, filter, nw)).first;
+        per_cu = it->second;
+    }
+    if (std::min(per_cu, 2) * static_cast<uint64_t>(sc.num_cus) < wgs + 1) return false;
+    out->lw = lw;
+    out->nw = nw;
+    out->grid = static_cast<int>(wgs) + 1;
+    out->filter = filter;
+    return true;
+}
+
 // The ICP loop of Registration.cpp:127-138 as a stream of launches: k_icp (search + accumulation)
-// and k_fin (reduce, solve, compose, test) per iteration.
+// and k_fin (reduce, solve, compose, test) per iteration — or, for a frame that fits the machine
+// and is not sharded over GPUs, as ONE launch (k_loop).
 int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const double init[7],
             double max_dist, double kernel, double sem_th, sageicp_comm *comm, double out[7],
             sageicp_stats *stats, double us_upload, double t_begin) {
@@ -1331,7 +1394,10 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     }
     HIPCHK(hipMemcpyAsync(sc.d_state, sc.h_state, sizeof(IcpState), hipMemcpyHostToDevice, s));
 
-    const int lw = icp_lw(n, sparse_voxels(m));
+    int lw = icp_lw(n, sparse_voxels(m));
+    LoopPlan plan{};
+    bool use_loop = !comm && plan_loop(m, n, sem_th, &plan);
+    if (use_loop) lw = plan.lw;
     const int blocks = n ? icp_blocks_for(static_cast<int>(n), lw) : 1;
     if ((rc = ensure_cand(m, wants_filter(m, n, sem_th)))) return rc;
     if ((rc = sc.reserve_sort(n))) return rc;
@@ -1351,10 +1417,60 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     // query crosses a voxel face.  (Round 1 re-sorted when the pose had drifted half a voxel; with a
     // lane per query that no longer pays for its ~90 us: 45.3 against 47.2 us per iteration on the
     // c2 cold start, profiles/README.md.)
-    if (n > 0) {
+    if (n > 0)
         HIPCHK(sort_frame(d_frame, sc.d_sorted, static_cast<int>(n), sc.d_state, true,
                           m->host.voxel_size, sc.d_keys, sc.d_vals, sc.d_sort_temp,
                           sc.sort_temp_bytes_, s));
+
+    double us_nn = 0, us_fin = 0;
+    uint32_t nn_launches = 0;
+    bool looped = false;
+    if (use_loop) {
+        // ---- the whole loop in one launch (kernels.hip, k_loop) ------------------------------------------
+        if (prof && (rc = sc.reserve_events(1))) return rc;
+        IcpParams lp = ip;
+        lp.filter = plan.filter ? ip.filter : 0;
+        lp.nwaves = static_cast<unsigned>((n + (64u >> lw) - 1) / (64u >> lw));
+        LoopParams L{};
+        L.sh = sc.d_loop;
+        L.st = sc.d_state;
+        L.nw = plan.nw;
+        // a wait inside the launch normally takes microseconds; 50 ms of it means the grid is not
+        // resident as a whole (SAGEICP_LOOP_TIMEOUT_MS overrides, e.g. under a debugger)
+        L.timeout_ticks = 100000ull * static_cast<unsigned long long>(std::max(1, env_int("SAGEICP_LOOP_TIMEOUT_MS", 50)));
+        if (const int ticks = env_int("SAGEICP_LOOP_TIMEOUT_TICKS", 0))      // tests: provoke a timeout
+            L.timeout_ticks = static_cast<unsigned long long>(ticks);
+        L.max_iterations = kMaxIterations;
+        HIPCHK(hipMemsetAsync(sc.d_loop, 0, sizeof(LoopShared), s));
+        if (prof) HIPCHK(hipEventRecord(sc.events[1], s));
+        launch_loop(lp, L, lw, plan.grid, s);
+        if (prof) HIPCHK(hipEventRecord(sc.events[2], s));
+        if (stats) launch_sum_counters(sc.d_cand, static_cast<int>(lp.nwaves), sc.d_state, s);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(sc.h_state, sc.d_state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (sc.h_state->loop_aborted || !sc.h_state->done) {
+            // a wait inside the launch timed out (the grid was not resident as a whole: another stream
+            // or process held CUs): the launch-per-iteration loop below registers the frame instead
+            fill_state(sc.h_state, init);
+            if (polled) {
+                std::memset(sc.h_prog, 0, sizeof(IcpProgress));
+                sc.h_state->progress = sc.d_prog;
+            }
+            HIPCHK(hipMemcpyAsync(sc.d_state, sc.h_state, sizeof(IcpState), hipMemcpyHostToDevice, s));
+            if (stats) HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * 2 * (ip.nwaves + 1), s));
+            use_loop = false;
+        } else {
+            looped = true;
+            if (prof) {
+                float a = 0;
+                (void)hipEventElapsedTime(&a, sc.events[1], sc.events[2]);
+                us_nn = 1e3 * a;
+                nn_launches = static_cast<uint32_t>(std::max(1, sc.h_state->iter));   // per iteration
+            }
+        }
+    }
+    if (n > 0 && !looped) {
         launch_rows(ip, s);
         HIPCHK(hipMemsetAsync(sc.d_prev, 0xFF, n * sizeof(uint2), s));     // no previous answers yet
     }
@@ -1389,8 +1505,6 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
             fp.p2p.timeout_ticks = static_cast<unsigned long long>(ticks);
     }
 
-    double us_nn = 0, us_fin = 0;
-    uint32_t nn_launches = 0;
     // one iteration; `slot` indexes its 5 profiling events
     // Profiling level 1 brackets k_icp in one iteration out of 8 (two event records cost ~6 us of
     // stream time): the roofline figure is the mean over that sample; level 2: every kernel of
@@ -1425,7 +1539,9 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     };
     // (nothing the host does depends on WHEN it looks at the progress word: a call repeated gives
     // the same bits)
-    if (polled) {
+    if (looped) {
+        // (the one-launch loop has run; the state is on the host)
+    } else if (polled) {
         const int depth = std::min(8, std::max(1, env_int("SAGEICP_DEPTH", 4)));
         volatile unsigned long long *word = &sc.h_prog->word;
         int enq = 0;
@@ -1506,7 +1622,8 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         stats->sum_candidates = st.sum_candidates;
         stats->pairs_evaluated = st.sum_pairs;
         stats->lanes_per_query = 1u << lw;
-        stats->compact_scan = ip.filter ? 1u : 0u;
+        stats->compact_scan = (looped ? plan.filter && ip.filter : ip.filter != 0) ? 1u : 0u;
+        stats->single_launch = looped ? 1u : 0u;
         for (int i = 0; i < 64 && i < st.iter; ++i) stats->n_corr_hist[i] = st.n_corr[i];
         stats->us_wall = now_us() - t_begin;
     }
@@ -2104,7 +2221,7 @@ int sageicp_get_correspondences(const sageicp_map *m, const double *q, uint64_t 
         // acceptance on the unscaled distance: (nn - point).norm() < max (VoxelHashMap.cpp:111)
         const Point4 &t = m->host.pts[by_query[i]];
         const double dx = t.x - q[4 * i], dy = t.y - q[4 * i + 1], dz = t.z - q[4 * i + 2];
-        if (!(std::sqrt(SAGE_SQNORM3(dx * dx, dy * dy, dz * dz)) < max_dist)) continue;
+        if (!(std::sqrt(SAGE_SQNORM3_ACCEPT(dx * dx, dy * dy, dz * dz)) < max_dist)) continue;
         std::memcpy(src_out + 4 * k, q + 4 * i, 32);
         std::memcpy(tgt_out + 4 * k, &t, 32);
         if (query_idx_out) query_idx_out[k] = static_cast<int64_t>(i);

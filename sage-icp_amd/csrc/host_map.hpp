@@ -242,7 +242,7 @@ public:
             if (cnt[b] == 0) continue;
             const Point4 &p = pts[first_point(b)];
             const double dx = p.x - origin[0], dy = p.y - origin[1], dz = p.z - origin[2];
-            if (SAGE_SQNORM3(dx * dx, dy * dy, dz * dz) > max2) {
+            if (SAGE_SQNORM3_FAR(dx * dx, dy * dy, dz * dz) > max2) {
                 erase_block(b);
                 any = true;
             }

@@ -135,6 +135,36 @@ struct RedParams {
 int red_rows_for(int nparts);                 // 0: single stage
 void launch_red(const RedParams &p, hipStream_t s);
 
+// ---- k_loop: the whole ICP loop of a frame that fits the machine in ONE launch -----------------
+// Every wave keeps its queries (frame point, previous answer and its record in registers, the
+// neighbourhood row in LDS) for the whole call; an iteration ends with the workgroups adding their
+// sums into the fixed-point accumulators and counting themselves in, the last wave of workgroup 0
+// solving and publishing the next pose, and one wave per workgroup waiting for it — no kernel
+// boundary, no k_fin, L2s that stay warm.  Everything the workgroups share inside the launch is
+// accessed with agent-scope atomics only (per-XCD L2s are not coherent with each other); the block
+// is zeroed before every launch.
+constexpr int kLoopReplicas = 8;           // accumulator copies (workgroup b adds into copy b & 7)
+constexpr int kLoopPoseGranules = 25;      // R[9], t[3] as 24 x {tag, 32 bits} + {tag, done}
+struct LoopShared {
+    long long acc[kLoopReplicas][kAccWords];            // as FinParams::acc; word 63 of copy 0: overflow flag
+    unsigned long long arrive[kLoopReplicas][16];       // [r][0]: workgroups counted in, all iterations (one per 128-B line)
+    unsigned long long pose[32];                        // granules (tag << 32) | payload, tag = iteration + 1
+    unsigned long long abort_word[16];                  // [0] != 0: a wait timed out somewhere — everybody leaves
+};
+struct LoopParams {
+    LoopShared *sh;
+    IcpState *st;                  // in: the initial pose; out: the final loop state (written by the solving wave)
+    int nw;                        // waves per workgroup (<= kLoopMaxWaves)
+    unsigned long long timeout_ticks;      // s_memrealtime ticks (100 MHz) any wait may take
+    int max_iterations;            // kMaxIterations (tests: fewer)
+};
+constexpr int kLoopMaxWavesHost = 8;
+size_t loop_lds_bytes(int lw, int nw);
+// workgroups of `nw` waves resident per CU for the variant (lw, filter): 0 = the kernel cannot be
+// used on this device; the grid must not exceed this number x CUs
+int loop_blocks_per_cu(int lw, bool filter, int nw);
+void launch_loop(const IcpParams &p, const LoopParams &l, int lw, int grid, hipStream_t s);
+
 constexpr int kMaxPartials = 1 << 16;
 constexpr uint64_t kMaxQueries = (1ull << 26) - 1;
 

@@ -53,7 +53,7 @@
 // hardware dispatch of many small workgroups in XCD-aware stripes of the spatially sorted frame.
 //
 // Built with -ffp-contract=off: distances are the plain IEEE sequence
-// SAGE_SQNORM3(dx*dx, dy*dy, dz*dz) (sageicp_types.h) the CPU evaluates, so the argmin is
+// SAGE_SQNORM3_*(dx*dx, dy*dy, dz*dz) (sageicp_types.h) the CPU evaluates, so the argmin is
 // index-exact against the oracle.
 
 #include <hip/hip_runtime.h>
@@ -248,16 +248,14 @@ struct Query {
 // instructions) and the three voxel indices are handed round by quad broadcasts — the same
 // divisions, a third of them per lane.
 template <bool QUAD = false>
-__device__ __forceinline__ Query make_query(const Point4 &f, const IcpState *st, int apply_pose,
+__device__ __forceinline__ Query make_query(const Point4 &f, const double *R, const double *t, int apply_pose,
                                             double voxel_size) {
     Query q;
     q.x = f.x; q.y = f.y; q.z = f.z; q.l = f.l;
     if (apply_pose) {
-        const double *R = st->R;
-        const double *T = st->T;
-        q.x = R[0] * f.x + R[1] * f.y + R[2] * f.z + T[4];
-        q.y = R[3] * f.x + R[4] * f.y + R[5] * f.z + T[5];
-        q.z = R[6] * f.x + R[7] * f.y + R[8] * f.z + T[6];
+        q.x = R[0] * f.x + R[1] * f.y + R[2] * f.z + t[0];
+        q.y = R[3] * f.x + R[4] * f.y + R[5] * f.z + t[1];
+        q.z = R[6] * f.x + R[7] * f.y + R[8] * f.z + t[2];
     }
     if constexpr (QUAD) {
         const unsigned a = threadIdx.x & 3u;
@@ -282,7 +280,7 @@ __global__ __launch_bounds__(256) void k_rows(IcpParams P) {
     const unsigned q = blockIdx.x * 8u + (threadIdx.x >> 5);
     const bool valid = q < static_cast<unsigned>(P.n);
     const Point4 f = P.frame[valid ? q : 0u];
-    const Query s = make_query(f, P.st, P.apply_pose, P.voxel_size);
+    const Query s = make_query(f, P.st->R, P.st->T + 4, P.apply_pose, P.voxel_size);
     uint32_t w = kEmptySlot;
     if (valid && v < 27u)
         w = probe_voxel(P.table, P.mask, s.kx + static_cast<int>(v / 9u) - 1,
@@ -323,8 +321,85 @@ __host__ __device__ constexpr unsigned icp_wave_words(int lw) {
     return static_cast<unsigned>(kRowLdsStride * (64 >> lw) + 64);
 }
 
-template <int LW, bool FUSED, bool FILT>
-__device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem);
+// The sums of a workgroup's waves and its pair count go into shared fixed-point accumulators
+// (kernels.h): one wave, lane l handles digit l % 3 of value l / 3 — converts every WAVE's fp64 sum
+// to that digit, adds the digits as integers, and sends ONE fire-and-forget 64-bit integer atomic.
+// Nothing is rounded after a wave's own fixed-order reduction, so the accumulated bits depend on
+// how the queries are cut into waves (lanes per query) and on nothing else: not on the order of
+// arrival, not on the waves per workgroup, not on which loop (k_icp + k_fin or k_loop) ran.
+// `ws` = [nw][16] fp64 sums of the workgroup's waves, `pairs` = [nw] accepted pairs (LDS); `dst` = the
+// replica this workgroup adds into.
+__device__ __forceinline__ void wg_sums_to_acc(const double *ws, const uint32_t *pairs, int nw, long long *dst,
+                                               long long *overflow) {
+    const int lane = static_cast<int>(threadIdx.x & 63u);
+    const int c = min(lane / 3, kAccValues - 1), digit = lane % 3;
+    long long x = 0;
+    bool ok = true;
+    if (c < kCount) {
+        for (int k = 0; k < nw; ++k) {
+            const double v = ws[k * kCount + c];
+            // exact split v = a + b 2^-40 + c2 2^-80 (+ what lies below 2^-80, dropped): three
+            // integers of at most 40 bits and a sign, each exactly representable
+            const double a = __builtin_rint(v);
+            const double r1 = (v - a) * 1099511627776.0;             // 2^40, exact
+            const double b = __builtin_rint(r1);
+            const double c2 = __builtin_rint((r1 - b) * 1099511627776.0);
+            const double d = digit == 0 ? a : (digit == 1 ? b : c2);
+            ok &= fabs(a) < 1125899906842624.0;                       // 2^50 (coordinates of 10^6 m stay far below)
+            // integer of magnitude < 2^51 held in a double -> int64 through the 2^52 + 2^51 trick
+            // (both numbers lie in [2^52, 2^53): their bit patterns differ by exactly d)
+            x += __double_as_longlong(d + 6755399441055744.0) - 0x4338000000000000ll;
+        }
+    } else if (digit == 0) {
+        unsigned n = 0u;
+        for (int k = 0; k < nw; ++k) n += pairs[k];
+        x = static_cast<long long>(n);
+    }
+    if (lane < 3 * kAccValues) {
+        if (ok) (void)__hip_atomic_fetch_add(dst + lane, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else (void)__hip_atomic_fetch_or(overflow, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---- k_loop (the whole ICP loop in one launch, below) shares the body --------------------------
+// What a lane of k_loop keeps in registers across the iterations of a call: its query's pristine
+// frame point, the previous iteration's answer and that point's record (the seed of the next
+// search and, while the answer stays, the target of the pair: no load), and the home voxel its
+// neighbourhood row — which stays in LDS for the whole call — was built for.
+struct LoopLane {
+    Point4 f;
+    Point4 pp;
+    uint2 prev;
+    int kx, ky, kz;
+    unsigned occ;
+};
+constexpr int kLoopMaxWaves = kLoopMaxWavesHost;   // waves per workgroup of k_loop (<= 512 threads)
+constexpr int kNoVoxel = 0x7FFFFFFF;        // a home voxel no point has (|index| < 2^20): row not built yet
+// LDS header of a k_loop workgroup (words): ws[8][16] fp64 sums | accepted pairs [8] | arrival
+// counter | the pose of this iteration (R[9], t[3]) | done | loop state of the solving workgroup
+constexpr unsigned kLpSums = 0, kLpPairs = 2u * 16u * kLoopMaxWaves, kLpArrive = kLpPairs + kLoopMaxWaves;
+constexpr unsigned kLpPose = (kLpArrive + 1u + 3u) & ~3u;          // 12 doubles, 16-B aligned
+constexpr unsigned kLpDone = kLpPose + 24u;
+// (used by workgroup 0 only) T[7] | T_icp[7] | the reduced sums S[kNumSums] | the pose being published
+// [12] | the 64 accumulator words
+constexpr unsigned kLpT = (kLpDone + 1u + 1u) & ~1u;
+constexpr unsigned kLpS = kLpT + 28u;
+constexpr unsigned kLpPub = kLpS + 2u * kNumSums;
+constexpr unsigned kLpDigits = kLpPub + 24u;
+constexpr unsigned kLpHeaderWords = (kLpDigits + 2u * kAccWords + 15u) & ~15u;
+__host__ __device__ constexpr unsigned loop_wave_words(int lw) {
+    // the rows of the wave's queries (they stay for the whole call) + the epilogue's transposed
+    // reduction, 16 components x (queries + 2) fp64
+    return static_cast<unsigned>(kRowLdsStride * (64 >> lw) + 64 + 2 * 16 * ((64 >> lw) + 2));
+}
+
+// PERSIST (k_loop): the per-query state comes from / goes back to `LL` (registers), the pose from
+// `pose` (LDS: R[9], t[3]); nothing is read from or written to the global rows / nn_prev arrays;
+// the body ends with the wave's sums parked in the workgroup's LDS header and returns true on the
+// last wave of the workgroup to arrive (`nw` waves), which the caller lets finish the iteration.
+template <int LW, bool FUSED, bool FILT, bool PERSIST = false>
+__device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, LoopLane *LL = nullptr,
+                                         const double *pose = nullptr, int nw = kIcpWavesPerBlock);
 
 // a pair of scanned points in flight: compact records (FILT) or full ones
 struct PairCompact {
@@ -354,8 +429,10 @@ void k_icp(IcpParams P) {
 #endif
 }
 
-template <int LW, bool FUSED, bool FILT>
-__device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
+template <int LW, bool FUSED, bool FILT, bool PERSIST>
+__device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, LoopLane *LL, const double *pose,
+                                         int nw) {
+    static_assert(!PERSIST || FUSED, "the persistent loop always accumulates");
     constexpr int W = 1 << LW;                 // lanes per query
     constexpr int QW = 64 >> LW;               // queries per wave
     constexpr int SH = 5;                      // points are addressed by byte offset
@@ -370,20 +447,24 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
 #endif
     const int lane = static_cast<int>(threadIdx.x & 63u);
     const int wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-    if (FUSED) {
+    if (FUSED && !PERSIST) {
         if (threadIdx.x == 0) smem[kWgArrive] = 0u;
         __syncthreads();
     }
-    uint32_t *wl = smem + kWgHeaderWords + static_cast<unsigned>(wv) * icp_wave_words(LW);
+    uint32_t *wl = PERSIST ? smem + kLpHeaderWords + static_cast<unsigned>(wv) * loop_wave_words(LW)
+                           : smem + kWgHeaderWords + static_cast<unsigned>(wv) * icp_wave_words(LW);
 
     // Workgroup b is dispatched to XCD b % 8 (observed; speed only): XCD x serves the stripes
     // x, x+8, x+16, ... of kStripe consecutive workgroups' worth of the spatially sorted frame,
     // so each private L2 sees a few compact regions of the map and every XCD gets the same mix
-    // of dense and sparse regions.
+    // of dense and sparse regions.  (k_loop: XCD x serves one contiguous eighth of the frame for
+    // the whole call — its L2 keeps that region of the map warm across the iterations.)
     constexpr unsigned kStripe = SAGE_ICP_STRIPE;
     const unsigned xcd = blockIdx.x & 7u, jb = blockIdx.x >> 3;
-    const unsigned wg = ((jb / kStripe) * 8u + xcd) * kStripe + (jb % kStripe);
-    const unsigned wave_id = wg * kIcpWavesPerBlock + static_cast<unsigned>(wv);   // wave-uniform
+    const unsigned wg = PERSIST ? xcd * ((gridDim.x - 1u) >> 3) + jb
+                                : ((jb / kStripe) * 8u + xcd) * kStripe + (jb % kStripe);
+    const unsigned wave_id = wg * static_cast<unsigned>(PERSIST ? nw : kIcpWavesPerBlock) +
+                             static_cast<unsigned>(wv);                            // wave-uniform
 
     const int qw = lane >> LW;                 // this lane's query within the wave
     const unsigned ci = static_cast<unsigned>(lane) & (W - 1u);
@@ -406,22 +487,33 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
     // frame point, the previous iteration's record and — speculatively, before the key has been
     // checked — this lane's share of the cached row (words 0..27 in seven 16-B pieces).
     constexpr int NP = (7 + W - 1) / W;        // pieces per lane
-    const uint4 rk = *reinterpret_cast<const uint4 *>(grow + kRowKey);     // key x, y, z | occupancy
+    uint4 rk;                                  // key x, y, z | occupancy
     uint2 prev = make_uint2(0xFFFFFFFFu, 0u);     // the previous iteration's record of this query
-    if (FUSED) prev = P.nn_prev[qc];
-    const Point4 f = P.frame[qc];
+    Point4 f;
     // (named registers, not an array: the compiler leaves a uint4 array in scratch memory)
-    auto row_piece = [&](int k) {
-        const unsigned p = min(ci + static_cast<unsigned>(W * k), 6u);
-        return *reinterpret_cast<const uint4 *>(grow + 4u * p);
-    };
-    uint4 pc0 = row_piece(0), pc1 = pc0, pc2 = pc0, pc3 = pc0, pc4 = pc0, pc5 = pc0, pc6 = pc0;
-    if (NP > 1) pc1 = row_piece(1);
-    if (NP > 2) pc2 = row_piece(2);
-    if (NP > 3) pc3 = row_piece(3);
-    if (NP > 4) pc4 = row_piece(4);
-    if (NP > 5) pc5 = row_piece(5);
-    if (NP > 6) pc6 = row_piece(6);
+    uint4 pc0 = make_uint4(0u, 0u, 0u, 0u), pc1 = pc0, pc2 = pc0, pc3 = pc0, pc4 = pc0, pc5 = pc0, pc6 = pc0;
+    if constexpr (PERSIST) {
+        // k_loop: everything is already here — registers and the row in LDS
+        f = LL->f;
+        prev = LL->prev;
+        rk = make_uint4(static_cast<uint32_t>(LL->kx), static_cast<uint32_t>(LL->ky),
+                        static_cast<uint32_t>(LL->kz), LL->occ);
+    } else {
+        rk = *reinterpret_cast<const uint4 *>(grow + kRowKey);
+        if (FUSED) prev = P.nn_prev[qc];
+        f = P.frame[qc];
+        auto row_piece = [&](int k) {
+            const unsigned p = min(ci + static_cast<unsigned>(W * k), 6u);
+            return *reinterpret_cast<const uint4 *>(grow + 4u * p);
+        };
+        pc0 = row_piece(0); pc1 = pc0; pc2 = pc0; pc3 = pc0; pc4 = pc0; pc5 = pc0; pc6 = pc0;
+        if (NP > 1) pc1 = row_piece(1);
+        if (NP > 2) pc2 = row_piece(2);
+        if (NP > 3) pc3 = row_piece(3);
+        if (NP > 4) pc4 = row_piece(4);
+        if (NP > 5) pc5 = row_piece(5);
+        if (NP > 6) pc6 = row_piece(6);
+    }
 #ifdef SAGE_ICP_DELAY_PROBE
     // probe: the pose becomes available `dbg_delay` ticks (100 MHz) after this wave started, with
     // the prologue loads above already in flight — what hiding k_fin under the prologue would cost
@@ -431,23 +523,26 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
         __builtin_amdgcn_sched_barrier(0);
     }
 #endif
-    const Query s = make_query<(W >= 4)>(f, P.st, P.apply_pose, P.voxel_size);
+    const Query s = PERSIST ? make_query<(W >= 4)>(f, pose, pose + 9, 1, P.voxel_size)
+                            : make_query<(W >= 4)>(f, P.st->R, P.st->T + 4, P.apply_pose, P.voxel_size);
     const bool stale = valid && (static_cast<uint32_t>(s.kx) != rk.x || static_cast<uint32_t>(s.ky) != rk.y ||
                                  static_cast<uint32_t>(s.kz) != rk.z);
     unsigned occ = rk.w;
     NN_T(0);
-    // stage the row in LDS (a stale one is overwritten below)
-    auto stage = [&](int k, const uint4 &v) {
-        const unsigned p = ci + static_cast<unsigned>(W * k);
-        if (p < 7u) *reinterpret_cast<uint4 *>(lrow + 4u * p) = v;
-    };
-    stage(0, pc0);
-    if (NP > 1) stage(1, pc1);
-    if (NP > 2) stage(2, pc2);
-    if (NP > 3) stage(3, pc3);
-    if (NP > 4) stage(4, pc4);
-    if (NP > 5) stage(5, pc5);
-    if (NP > 6) stage(6, pc6);
+    if constexpr (!PERSIST) {
+        // stage the row in LDS (a stale one is overwritten below)
+        auto stage = [&](int k, const uint4 &v) {
+            const unsigned p = ci + static_cast<unsigned>(W * k);
+            if (p < 7u) *reinterpret_cast<uint4 *>(lrow + 4u * p) = v;
+        };
+        stage(0, pc0);
+        if (NP > 1) stage(1, pc1);
+        if (NP > 2) stage(2, pc2);
+        if (NP > 3) stage(3, pc3);
+        if (NP > 4) stage(4, pc4);
+        if (NP > 5) stage(5, pc5);
+        if (NP > 6) stage(6, pc6);
+    }
     if (__ballot(stale)) {
         // Rare (a query crossed a voxel face since its row was built, a few % of the queries per
         // iteration at the start of a cold registration, almost none near convergence): the lanes
@@ -468,7 +563,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
                                                  s.kz + v % 3 - 1);
                 const unsigned c = (w == kEmptySlot) ? 0u : (w & 255u);
                 lrow[v] = w;
-                P.rows[static_cast<size_t>(q) * kRowWords + static_cast<unsigned>(v)] = w;
+                if constexpr (!PERSIST) P.rows[static_cast<size_t>(q) * kRowWords + static_cast<unsigned>(v)] = w;
                 o |= (c != 0u ? 1u : 0u) << v;
                 cq += c;
             };
@@ -490,11 +585,17 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
             occ = o;
             if (ci == 0u) {
                 lrow[kRowCq] = cq;
-                uint4 t;
-                t.x = static_cast<uint32_t>(s.kx); t.y = static_cast<uint32_t>(s.ky);
-                t.z = static_cast<uint32_t>(s.kz); t.w = o;
-                *reinterpret_cast<uint4 *>(P.rows + static_cast<size_t>(q) * kRowWords + kRowKey) = t;
-                P.rows[static_cast<size_t>(q) * kRowWords + kRowCq] = cq;
+                if constexpr (!PERSIST) {
+                    uint4 t;
+                    t.x = static_cast<uint32_t>(s.kx); t.y = static_cast<uint32_t>(s.ky);
+                    t.z = static_cast<uint32_t>(s.kz); t.w = o;
+                    *reinterpret_cast<uint4 *>(P.rows + static_cast<size_t>(q) * kRowWords + kRowKey) = t;
+                    P.rows[static_cast<size_t>(q) * kRowWords + kRowCq] = cq;
+                }
+            }
+            if constexpr (PERSIST) {
+                LL->kx = s.kx; LL->ky = s.ky; LL->kz = s.kz;
+                LL->occ = o;
             }
         }
     }
@@ -543,7 +644,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
     // candidate here (`on` false) turns its distance into a NaN, which loses every comparison.
     auto evaluate = [&](const Point4 &nb, bool on, unsigned key) {
         const double dx = nb.x - s.x, dy = nb.y - s.y, dz = nb.z - s.z;
-        double d = SAGE_SQNORM3(dx * dx, dy * dy, dz * dz);
+        double d = SAGE_SQNORM3_NN(dx * dx, dy * dy, dz * dz);
         // same label, or either side unlabelled (VoxelHashMap.cpp:87-88)
         // ((int)(a * b) == 0  <=>  |a * b| < 1 under truncation toward zero)
         const bool same = static_cast<int>(nb.l) == pli || fabs(nb.l * s.l) < 1.0;
@@ -606,7 +707,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
     };
     auto passes = [&](const uint4 &c, bool on) {
         const float dx = __uint_as_float(c.x) - qx, dy = __uint_as_float(c.y) - qy, dz = __uint_as_float(c.z) - qz;
-        const float d = SAGE_SQNORM3(dx * dx, dy * dy, dz * dz);
+        const float d = SAGE_SQNORM3_NN(dx * dx, dy * dy, dz * dz);   // (any association: the filter's bound covers it)
         const float lab = __uint_as_float(c.w);
         const bool same = (lab == plab) | (lab == 0.0f) | q_zero;
         return on & !(d > (same ? Ts : Td));
@@ -708,7 +809,9 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
     constexpr unsigned kHome = 13u;
     if (FUSED) {
         const bool seeded = valid && !stale && prev.x != 0xFFFFFFFFu;
-        const Point4 pp = load_point(pts, seeded ? prev.y : 0u);      // the full record
+        Point4 pp;                                                    // the full record
+        if constexpr (PERSIST) pp = LL->pp;
+        else pp = load_point(pts, seeded ? prev.y : 0u);
         scan(occ & (1u << kHome), &pp, seeded, prev.x);
     } else {
         scan(occ & (1u << kHome), nullptr, false, 0u);
@@ -790,7 +893,24 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
         if (valid && ci == 0u) P.nn_idx[q] = found ? static_cast<int>(woff >> SH) : -1;
     } else {
         // ---- fused epilogue: acceptance + Gauss-Newton terms of this query's pair -----------------
-        if (valid && ci == 0u) P.nn_prev[q] = make_uint2(found ? mkey : 0xFFFFFFFFu, woff);
+        if constexpr (!PERSIST) {
+            if (valid && ci == 0u) P.nn_prev[q] = make_uint2(found ? mkey : 0xFFFFFFFFu, woff);
+        }
+        Point4 g;
+        if constexpr (PERSIST) {
+            // The answer of most queries is the previous iteration's (and then so is its record: the
+            // map is constant during a call, and an unchanged row gives a key the same meaning): only
+            // a query whose answer changed — or whose row was rebuilt — fetches a record, on all of
+            // its lanes (one request: the same address), since every lane evaluates the seed.
+            const bool changed = found && (stale || mkey != prev.x);
+            g = LL->pp;
+            if (__ballot(changed)) {
+                const Point4 t = load_point(pts, changed ? woff : 0u);
+                if (changed) g = t;
+            }
+            LL->pp = g;
+            LL->prev = make_uint2(found ? mkey : 0xFFFFFFFFu, woff);
+        }
 #ifdef SAGE_NN_TIMING
         if (valid && ci == 0u && P.work) P.work[q] = npairs;
 #endif
@@ -799,11 +919,12 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
         for (int c = 0; c < kCount; ++c) t[c] = 0.0;
         bool use = false;
         if (found && ci == 0u) {
-            const Point4 g = load_point(pts, woff);
+            if constexpr (!PERSIST) g = load_point(pts, woff);
             const double rx = s.x - g.x, ry = s.y - g.y, rz = s.z - g.z;
-            const double r2 = SAGE_SQNORM3(rx * rx, ry * ry, rz * rz);
-            // (closest_neighboor - point).norm() < max_correspondance_distance (VoxelHashMap.cpp:111)
-            use = r2 <= P.accept_r2;
+            // (closest_neighboor - point).head<3>().norm() < max_correspondance_distance (VoxelHashMap.cpp:111)
+            use = SAGE_SQNORM3_ACCEPT(rx * rx, ry * ry, rz * rz) <= P.accept_r2;
+            // residual.squaredNorm() (Registration.cpp:79): its own reduction (sageicp_types.h)
+            const double r2 = SAGE_SQNORM3_RESID(rx * rx, ry * ry, rz * rz);
             if (use) {
                 const double k = P.kernel;
                 const double den = k + r2;
@@ -823,7 +944,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
         // Wave reduction in a fixed order (bit-reproducible): the query lanes park their 16 terms
         // transposed in LDS (the rows are no longer needed), four lanes per component add QW / 4
         // parked values each and finish with two DPP exchanges.
-        double *red = reinterpret_cast<double *>(wl);
+        double *red = reinterpret_cast<double *>(PERSIST ? wl + kRowLdsStride * QW + 64 : wl);
         constexpr int S = QW + 2;              // fp64 stride of one component
         if (ci == 0u) {
 #pragma unroll
@@ -836,48 +957,27 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
             for (int e = 0; e < QW / 4; ++e) v += red[c * S + r + 4 * e];
             v += dpp_f64<kDppXor1>(v);
             v += dpp_f64<kDppXor2>(v);
-            double *ws = reinterpret_cast<double *>(smem + kWgSums) + wv * kCount;
+            double *ws = reinterpret_cast<double *>(smem + (PERSIST ? kLpSums : kWgSums)) + wv * kCount;
             if (r == 0) ws[c] = v;
-            if (lane == 0) smem[kWgPairs + wv] = pairs;
+            if (lane == 0) smem[(PERSIST ? kLpPairs : kWgPairs) + wv] = pairs;
         }
         // Workgroup partial: the last wave to arrive adds the four rows in wave order.
         unsigned prior = 0u;
         if (lane == 0)
-            prior = __hip_atomic_fetch_add(&smem[kWgArrive], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            prior = __hip_atomic_fetch_add(&smem[PERSIST ? kLpArrive : kWgArrive], 1u, __ATOMIC_ACQ_REL,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
         prior = __builtin_amdgcn_readfirstlane(prior);
+        if constexpr (PERSIST) {
+            // k_loop finishes the iteration itself (wg_sums_to_acc, arrival, solve)
+            const bool last = prior == static_cast<unsigned>(nw) - 1u;
+            if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            return last;
+        }
         if (prior == kIcpWavesPerBlock - 1u && P.acc) {
-            // The workgroup's 16 sums and its pair count go into the shared fixed-point accumulators
-            // (kernels.h): lane l adds digit l % 3 of value l / 3 with one fire-and-forget 64-bit
-            // integer atomic — any order of arrival gives the same bits.
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const double *ws = reinterpret_cast<const double *>(smem + kWgSums);
-            const int c = min(lane / 3, kAccValues - 1), digit = lane % 3;
-            double v = 0.0;
-            if (c < kCount) {
-#pragma unroll
-                for (int k = 0; k < kIcpWavesPerBlock; ++k) v += ws[k * kCount + c];
-            } else {
-                unsigned n = 0u;
-#pragma unroll
-                for (int k = 0; k < kIcpWavesPerBlock; ++k) n += smem[kWgPairs + k];
-                v = static_cast<double>(n);
-            }
-            // exact split v = a + b 2^-40 + c2 2^-80 (+ what lies below 2^-80, dropped): three
-            // integers of at most 40 bits and a sign, each exactly representable
-            const double a = __builtin_rint(v);
-            const double r1 = (v - a) * 1099511627776.0;             // 2^40, exact
-            const double b = __builtin_rint(r1);
-            const double c2 = __builtin_rint((r1 - b) * 1099511627776.0);
-            const double d = digit == 0 ? a : (digit == 1 ? b : c2);
-            // integer of magnitude < 2^51 held in a double -> int64 through the 2^52 + 2^51 trick
-            const bool ok = fabs(a) < 1125899906842624.0;             // 2^50 (coordinates of 10^6 m stay far below)
-            // (both numbers lie in [2^52, 2^53): their bit patterns differ by exactly d)
-            const long long x = __double_as_longlong(d + 6755399441055744.0) - 0x4338000000000000ll;
-            if (lane < 3 * kAccValues) {
-                long long *dst = P.acc + static_cast<size_t>(blockIdx.x & (kAccReplicas - 1)) * kAccWords + lane;
-                if (ok) (void)__hip_atomic_fetch_add(dst, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else (void)__hip_atomic_fetch_or(P.acc + kAccWords - 1, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            wg_sums_to_acc(reinterpret_cast<const double *>(smem + kWgSums), smem + kWgPairs, kIcpWavesPerBlock,
+                           P.acc + static_cast<size_t>(blockIdx.x & (kAccReplicas - 1)) * kAccWords,
+                           P.acc + kAccWords - 1);
         } else if (prior == kIcpWavesPerBlock - 1u) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             const double *ws = reinterpret_cast<const double *>(smem + kWgSums);
@@ -926,6 +1026,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem) {
         }
     }
 #endif
+    return false;
 }
 
 // ------------------------------------------------------------------------------------ WaveLanes
@@ -1134,17 +1235,12 @@ __device__ __forceinline__ void solve_and_publish(IcpState *st, const double *S,
     // round trip on one serial lane — except where those ulps could matter: a step within 1e-12
     // (relative 1e-8; the two differ by ~1e-19 there) of the stop threshold, or |omega| >= 3,
     // goes through the exact log so that the stop iteration is the reference's in every case.
-    double nrm = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) nrm += x[i] * x[i];
-    nrm = sqrt(nrm);
+    double nrm = sqrt(SAGE_SQNORM6(x));
     if (!(x[3] * x[3] + x[4] * x[4] + x[5] * x[5] < 9.0) ||
         fabs(nrm - kEstimationThreshold) < 1e-12) {
         double lg[6];
         se3_log(est, lg);
-        nrm = 0.0;
-        for (int i = 0; i < 6; ++i) nrm += lg[i] * lg[i];
-        nrm = sqrt(nrm);
+        nrm = sqrt(SAGE_SQNORM6(lg));          // the reduction order of a 6-vector's norm(): sageicp_types.h
     }
     st->last_step_norm = nrm;
     const int it = pre.iter;
@@ -1276,6 +1372,264 @@ __global__ __launch_bounds__(kFinThreads) void k_fin(FinParams P) {
     solve_and_publish(st, S, pre);
 }
 
+// ------------------------------------------------------------------------------------ k_loop
+// The whole loop of Registration.cpp:127-138 in one launch (kernels.h, LoopShared).  Per iteration:
+//   every wave        icp_body<PERSIST> on the queries it keeps — pose from LDS, state in registers,
+//                     rows in LDS — and parks its sums in the workgroup's LDS header;
+//   last wave of a    adds the workgroup's sums into the fixed-point accumulators, waits until its
+//   workgroup         atomics are performed (vmcnt) and counts the workgroup in;
+//   the solving       (one wave, the last workgroup of the grid, no queries) waits for every workgroup's
+//   workgroup         count, takes the accumulators (atomic exchange: read and clear in one operation at
+//                     the memory side), solves, composes, tests, and publishes the next pose as 25
+//                     self-tagged 8-byte granules (tag = iteration + 1: the data is the flag, no fence
+//                     on either side);
+//   wave 0 of every   polls the granules (one relaxed agent-scope load per lane and pass), hands the
+//   workgroup         pose to its workgroup through LDS;  __syncthreads();  next iteration.
+// Every word the workgroups share is accessed with agent-scope atomics only.  Every wait is bounded:
+// a timeout raises LoopShared::abort_word and IcpState::loop_aborted, everybody leaves, and the host
+// registers the frame through the launch-per-iteration loop instead (a grid that is not fully
+// resident — another process or stream holding CUs — ends this way, not in a hang).
+#ifdef SAGE_LOOP_TIMING
+// probe builds: 100-MHz stamps of the first kLoopTimedIters iterations — per workgroup when it counted
+// itself in and when it had the next pose; for the solving wave when all counts were in, the sums
+// read, the step solved, the pose published
+constexpr int kLoopTimedIters = 64, kLoopTimedWgs = 512;
+__device__ unsigned long long g_loop_wg[kLoopTimedIters][kLoopTimedWgs][2];
+__device__ unsigned long long g_loop_solver[kLoopTimedIters][4];
+#define LOOP_STAMP_SOLVER(it, k) do { if ((it) < kLoopTimedIters && (threadIdx.x & 63u) == 0u) g_loop_solver[it][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define LOOP_STAMP_WG(it, k) do { if ((it) < kLoopTimedIters && blockIdx.x < kLoopTimedWgs && (threadIdx.x & 63u) == 0u) g_loop_wg[it][blockIdx.x][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" void sageicp_debug_loop_times(unsigned long long *wg, unsigned long long *solver) {
+    (void)hipMemcpyFromSymbol(wg, HIP_SYMBOL(g_loop_wg), sizeof(unsigned long long) * kLoopTimedIters * kLoopTimedWgs * 2);
+    (void)hipMemcpyFromSymbol(solver, HIP_SYMBOL(g_loop_solver), sizeof(unsigned long long) * kLoopTimedIters * 4);
+}
+#else
+#define LOOP_STAMP_SOLVER(it, k) do { } while (0)
+#define LOOP_STAMP_WG(it, k) do { } while (0)
+#endif
+
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The solving wave (all 64 lanes, uniform data).  Returns the value of the done granule it
+// published: 0 go on, 1 finished, 2 aborted.
+__device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, uint32_t *smem, int it) {
+    LoopShared *sh = L.sh;
+    IcpState *st = L.st;
+    const int lane = static_cast<int>(threadIdx.x & 63u);
+    double *sT = reinterpret_cast<double *>(smem + kLpT);
+    double *S = reinterpret_cast<double *>(smem + kLpS);
+    double *pub = reinterpret_cast<double *>(smem + kLpPub);
+    long long *digits = reinterpret_cast<long long *>(smem + kLpDigits);
+    const unsigned long long tag = static_cast<unsigned long long>(it) + 1ull;
+
+    // 1. every workgroup has counted itself in for this iteration (its sums are in the accumulators)
+    {
+        // (the grid is 8 k query workgroups + this one: k of them add into each copy)
+        const unsigned long long per = (static_cast<unsigned long long>(gridDim.x) - 1ull) >> 3;
+        const unsigned long long target = tag * per;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            bool ok = true;
+            unsigned long long ab = 0ull;
+            if (lane < kLoopReplicas) ok = ld_agent(&sh->arrive[lane][0]) >= target;
+            else if (lane == kLoopReplicas) ab = ld_agent(&sh->abort_word[0]);
+            if (__all(ok)) break;
+            const bool late = __builtin_amdgcn_s_memrealtime() - t0 > L.timeout_ticks;
+            if (__any(ab != 0ull) || late) {
+                if (lane == 0) {
+                    st_agent(&sh->abort_word[0], 1ull);
+                    st->loop_aborted = 1;
+                    st_agent(&sh->pose[24], (tag << 32) | 2ull);
+                }
+                return 2u;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    LOOP_STAMP_SOLVER(it, 0);
+    // 2. the sums: read and clear in one operation per word
+    {
+        long long d = 0;
+#pragma unroll
+        for (int r = 0; r < kLoopReplicas; ++r)
+            d += __hip_atomic_exchange(&sh->acc[r][lane], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        digits[lane] = d;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < kNumSums) {
+            double r = 0.0;
+            if (lane < kAccValues) {
+                const double a = static_cast<double>(digits[3 * lane]);
+                const double b = static_cast<double>(digits[3 * lane + 1]);
+                const double c = static_cast<double>(digits[3 * lane + 2]);
+                r = a + (b * 9.094947017729282e-13 + c * 8.271806125530277e-25);      // 2^-40, 2^-80
+            }
+            S[lane] = r;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const bool overflow = digits[kAccWords - 1] != 0;
+    LOOP_STAMP_SOLVER(it, 1);
+
+    // 3. solve, compose, test (Registration.cpp:92-93,135-137) — as k_fin's solve_and_publish
+    double JTJ[36], JTr[6], neg[6], x[6], est[7];
+    assemble_normal_equations(S, JTJ, JTr);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) neg[i] = -JTr[i];
+    ldlt_solve6_t<WaveLanes>(JTJ, neg, x);
+    se3_exp_t<WaveLanes>(x, est);
+    double rhs[7], Tn[7];
+    {
+        const double *src = sT + (lane == 1 ? 7 : 0);      // lane 1: T_icp, the other lanes: T
+#pragma unroll
+        for (int i = 0; i < 7; ++i) rhs[i] = src[i];
+    }
+    se3_mul(est, rhs, Tn);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 2) {
+        double *dst = sT + (lane == 1 ? 7 : 0);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) dst[i] = Tn[i];
+    }
+    double Rn[9];
+    quat_to_mat(Tn, Rn);
+    double nrm = sqrt(SAGE_SQNORM6(x));
+    if (!(x[3] * x[3] + x[4] * x[4] + x[5] * x[5] < 9.0) || fabs(nrm - kEstimationThreshold) < 1e-12) {
+        double lg[6];                                      // see solve_and_publish
+        se3_log(est, lg);
+        nrm = sqrt(SAGE_SQNORM6(lg));
+    }
+    const bool converged = nrm < kEstimationThreshold;
+    unsigned done = (converged || it + 1 >= L.max_iterations) ? 1u : 0u;
+    if (overflow) done = 1u;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) pub[i] = Rn[i];
+        pub[9] = Tn[4]; pub[10] = Tn[5]; pub[11] = Tn[6];
+        if (it < kHistory) st->n_corr[it] = static_cast<uint32_t>(S[kCount]);
+        if (done) {
+            // the final loop state, for the host (ordinary stores: the end of the kernel publishes them)
+#pragma unroll
+            for (int i = 0; i < 7; ++i) st->T[i] = Tn[i];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) st->R[i] = Rn[i];
+            st->last_step_norm = nrm;
+            st->iter = it + 1;
+            st->done = 1;
+            st->converged = converged ? 1 : 0;
+            if (overflow) st->acc_overflow = 1;
+        }
+    }
+    if (done && lane == 1) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) st->T_icp[i] = Tn[i];
+    }
+    if (done && lane < kNumSums) st->sums[lane] = S[lane];
+    __builtin_amdgcn_wave_barrier();
+    LOOP_STAMP_SOLVER(it, 2);
+    // 4. publish: 24 halves of R, t and the done word, each with its tag
+    if (lane < 24) st_agent(&sh->pose[lane], (tag << 32) | reinterpret_cast<const uint32_t *>(pub)[lane]);
+    if (lane == 24) st_agent(&sh->pose[24], (tag << 32) | done);
+    LOOP_STAMP_SOLVER(it, 3);
+    return done;
+}
+
+template <int LW, bool FILT>
+__global__ __launch_bounds__(64 * kLoopMaxWaves) __attribute__((amdgpu_waves_per_eu(4, 8)))
+void k_loop(IcpParams P, LoopParams L) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    constexpr int QW = 64 >> LW;
+    const int lane = static_cast<int>(threadIdx.x & 63u);
+    const int wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const int nw = L.nw;
+    LoopShared *sh = L.sh;
+    double *s_pose = reinterpret_cast<double *>(smem + kLpPose);
+
+    // ---- the solving workgroup: the last one of the grid, one wave, no queries --------------------------
+    // (its own path through the kernel: the solve needs ~120 registers, the search ~95 with the state
+    // it keeps, and neither is live in the other)
+    if (blockIdx.x == gridDim.x - 1u) {
+        if (threadIdx.x >= 64u) return;
+        double *sT = reinterpret_cast<double *>(smem + kLpT);
+        if (lane < 14) sT[lane] = lane < 7 ? P.st->T[lane] : P.st->T_icp[lane - 7];
+        __builtin_amdgcn_wave_barrier();
+        for (int it = 0;; ++it)
+            if (loop_finish_iteration(L, smem, it)) return;
+    }
+
+    // ---- set-up: the initial pose, this lane's query -------------------------------------------------
+    if (threadIdx.x < 9) s_pose[threadIdx.x] = P.st->R[threadIdx.x];
+    else if (threadIdx.x < 12) s_pose[threadIdx.x] = P.st->T[4 + threadIdx.x - 9];
+    if (threadIdx.x == 0) {
+        smem[kLpArrive] = 0u;
+        smem[kLpDone] = 0u;
+    }
+    LoopLane LL;
+    {
+        const unsigned xcd = blockIdx.x & 7u, jb = blockIdx.x >> 3;
+        const unsigned wg = xcd * ((gridDim.x - 1u) >> 3) + jb;        // as icp_body<PERSIST>
+        const unsigned q = (wg * static_cast<unsigned>(nw) + static_cast<unsigned>(wv)) * QW +
+                           static_cast<unsigned>(lane >> LW);
+        LL.f = P.frame[q < static_cast<unsigned>(P.n) ? q : 0u];
+        LL.pp.x = LL.pp.y = LL.pp.z = LL.pp.l = 0.0;
+        LL.prev = make_uint2(0xFFFFFFFFu, 0u);
+        LL.kx = LL.ky = LL.kz = kNoVoxel;                               // no row yet: the first pass builds it
+        LL.occ = 0u;
+    }
+    __syncthreads();
+
+    for (int it = 0;; ++it) {
+        const bool last = icp_body<LW, true, FILT, true>(P, smem, &LL, s_pose, nw);
+        if (last) {
+            // this wave closes the workgroup's iteration
+            wg_sums_to_acc(reinterpret_cast<const double *>(smem + kLpSums), smem + kLpPairs, nw,
+                           &sh->acc[blockIdx.x & (kLoopReplicas - 1)][0], &sh->acc[0][kAccWords - 1]);
+            if (lane == 0) smem[kLpArrive] = 0u;          // everybody is in: ready for the next iteration
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the adds are performed before the count
+            if (lane == 0)
+                (void)__hip_atomic_fetch_add(&sh->arrive[blockIdx.x & (kLoopReplicas - 1)][0], 1ull, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+            LOOP_STAMP_WG(it, 0);
+        }
+        if (wv == 0) {
+            // the next pose, for this workgroup
+            const unsigned long long tag = static_cast<unsigned long long>(it) + 1ull;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            unsigned long long g = tag << 32;
+            bool aborted = false;
+            for (;;) {
+                if (lane < kLoopPoseGranules) g = ld_agent(&sh->pose[lane]);
+                const bool ok = (g >> 32) == tag;
+                if (__all(ok)) break;
+                unsigned long long ab = 0ull;
+                if (lane == 0) ab = ld_agent(&sh->abort_word[0]);
+                const bool late = __builtin_amdgcn_s_memrealtime() - t0 > L.timeout_ticks;
+                if (__any(ab != 0ull) || late) {
+                    if (lane == 0 && late) {
+                        st_agent(&sh->abort_word[0], 1ull);
+                        L.st->loop_aborted = 1;
+                    }
+                    aborted = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (aborted) {
+                if (lane == 0) smem[kLpDone] = 2u;
+            } else {
+                if (lane < 24) reinterpret_cast<uint32_t *>(s_pose)[lane] = static_cast<uint32_t>(g);
+                if (lane == 24) smem[kLpDone] = static_cast<uint32_t>(g);
+            }
+            LOOP_STAMP_WG(it, 1);
+        }
+        __syncthreads();
+        if (smem[kLpDone]) break;
+    }
+}
+
 // ------------------------------------------------------------------------------------ k_gn
 // AlignClouds' accumulation (Registration.cpp:62-90) on explicit pairs: every pair is taken.
 __global__ __launch_bounds__(256) void k_gn(GnParams P) {
@@ -1292,7 +1646,7 @@ __global__ __launch_bounds__(256) void k_gn(GnParams P) {
         const Point4 s = P.src[q], g = P.tgt[q];
         const double sx = s.x, sy = s.y, sz = s.z;
         const double rx = sx - g.x, ry = sy - g.y, rz = sz - g.z;
-        const double r2 = SAGE_SQNORM3(rx * rx, ry * ry, rz * rz);
+        const double r2 = SAGE_SQNORM3_RESID(rx * rx, ry * ry, rz * rz);
         const double den = k + r2;
         const double w = k2 / (den * den);   // square(th) / square(th + residual2)
         const double wsx = w * sx, wsy = w * sy, wsz = w * sz;
@@ -1494,6 +1848,43 @@ void launch_icp(const IcpParams &p, int lw, bool fused, hipStream_t s) {
         case 2: launch_icp_lw<2>(p, fused, s); break;
         case 3: launch_icp_lw<3>(p, fused, s); break;
         default: launch_icp_lw<4>(p, fused, s); break;
+    }
+}
+
+size_t loop_lds_bytes(int lw, int nw) {
+    return sizeof(uint32_t) * (kLpHeaderWords + static_cast<size_t>(nw) * loop_wave_words(lw));
+}
+template <int LW, bool FILT>
+static int loop_blocks_lw(int nw) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_loop<LW, FILT>, 64 * nw, loop_lds_bytes(LW, nw)) != hipSuccess)
+        return 0;
+    return nb;
+}
+int loop_blocks_per_cu(int lw, bool filter, int nw) {
+    if (nw < 1 || nw > kLoopMaxWaves) return 0;
+    switch (lw) {
+        case 1: return filter ? loop_blocks_lw<1, true>(nw) : loop_blocks_lw<1, false>(nw);
+        case 2: return filter ? loop_blocks_lw<2, true>(nw) : loop_blocks_lw<2, false>(nw);
+        case 3: return filter ? 0 : loop_blocks_lw<3, false>(nw);
+        case 4: return filter ? 0 : loop_blocks_lw<4, false>(nw);
+        default: return 0;
+    }
+}
+void launch_loop(const IcpParams &p, const LoopParams &l, int lw, int grid, hipStream_t s) {
+    const dim3 g(grid), b(64 * l.nw);
+    const size_t lds = loop_lds_bytes(lw, l.nw);
+    switch (lw) {
+        case 1:
+            if (p.filter) hipLaunchKernelGGL((k_loop<1, true>), g, b, lds, s, p, l);
+            else hipLaunchKernelGGL((k_loop<1, false>), g, b, lds, s, p, l);
+            break;
+        case 2:
+            if (p.filter) hipLaunchKernelGGL((k_loop<2, true>), g, b, lds, s, p, l);
+            else hipLaunchKernelGGL((k_loop<2, false>), g, b, lds, s, p, l);
+            break;
+        case 3: hipLaunchKernelGGL((k_loop<3, false>), g, b, lds, s, p, l); break;
+        default: hipLaunchKernelGGL((k_loop<4, false>), g, b, lds, s, p, l); break;
     }
 }
 

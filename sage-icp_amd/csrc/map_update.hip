@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void k_far_flags(DevMap M, UpdatePolicy P, dou
     if (!M.ctr->overflow && !M.ctr->unit_overflow && b < M.ctr->blocks_hi && M.slot_of[b] != kNoSlot) {
         const Point4 p = M.pts[static_cast<size_t>(M.regions[b] & 0x0FFFFFFFu) * kDevUnitPoints];
         const double dx = p.x - ox, dy = p.y - oy, dz = p.z - oz;
-        far = (SAGE_SQNORM3(dx * dx, dy * dy, dz * dz) > P.max_dist2) ? 1u : 0u;
+        far = (SAGE_SQNORM3_FAR(dx * dx, dy * dy, dz * dz) > P.max_dist2) ? 1u : 0u;
     }
     far_flag[b] = far;
 }

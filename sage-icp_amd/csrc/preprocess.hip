@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void k_vds_insert(VdsParams P) {
     bool valid = true;
     if (P.do_crop) {
         // Preprocessing.cpp:176-178: norm < max_range && norm > min_range; label zeroed beyond
-        const double norm = sqrt(p.x * p.x + (p.y * p.y + p.z * p.z));   // Eigen's unrolled reduction order
+        const double norm = sqrt(SAGE_SQNORM3_CROP(p.x * p.x, p.y * p.y, p.z * p.z));   // point.head<3>().norm()
         valid = norm < P.max_range && norm > P.min_range;
         if (norm > P.label_max_range) p.l = 0.0;
     }

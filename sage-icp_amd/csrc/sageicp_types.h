@@ -11,24 +11,55 @@
 #define SAGE_HD
 #endif
 
-// Every squared norm of a 3-vector on the path — (v3neighbor - v3point).squaredNorm()
-// (VoxelHashMap.cpp:87), (closest - point).head<3>().norm() (:111), residual.squaredNorm()
-// (Registration.cpp:79), (pt - origin).squaredNorm() (VoxelHashMap.cpp:178) — is a three-term sum
-// whose association Eigen chooses, and the nearest-neighbour decision is a strict `<` on such
-// sums: 1 ulp decides exact near-ties.  Eigen cannot be compiled in this image, so which of the
-// two orders its unrolled reduction takes is not verified; ONE switch, shared in name and meaning
-// with the CPU checker the tests compare against, selects it for the whole path (the variant
-// libsageicp_hip.n1.so is built by build.py's build_sqnorm3_variant(); SAGE_SQNORM3_ORDER=1 in the
-// environment makes the loader and the test-suite use it):
-//   0 (default)  x^2 + (y^2 + z^2)
-//   1            (x^2 + y^2) + z^2
+// Every squared norm of a 3-vector on the path is a three-term sum whose association Eigen chooses,
+// and the nearest-neighbour decision is a strict `<` on such sums: 1 ulp decides exact near-ties.
+// Eigen cannot be compiled in this image; the orders below are DERIVED from Eigen 3.4's Redux.h
+//  and selected by ONE switch shared in name and meaning with the CPU checker:
+//   SAGE_SQNORM3_ORDER = 2 (default)  what Eigen 3.4 evaluates on an SSE2 / NEON build, per call site:
+//       NN     (v3neighbor - v3point).squaredNorm()          VoxelHashMap.cpp:87    (x^2 + y^2) + z^2
+//       RESID  residual.squaredNorm()                        Registration.cpp:79    (x^2 + y^2) + z^2
+//       FAR    (pt - origin).squaredNorm()                   VoxelHashMap.cpp:178   (x^2 + y^2) + z^2
+//              — fixed-size-3 double expressions with packet access: linear vectorised reduction,
+//              predux(packet(e0, e1)) first, then + e2 (redux_impl<LinearVectorizedTraversal, CompleteUnrolling>);
+//       ACCEPT (closest - point).head<3>().norm()            VoxelHashMap.cpp:111   x^2 + (y^2 + z^2)
+//              — a Block of an expression has no packet access: scalar unrolled reduction, which splits
+//              3 terms as 1 + 2 (redux_novec_unroller: HalfLength = 3 / 2 = 1)
+//   0  x^2 + (y^2 + z^2) everywhere (the default of rounds 1-3)      1  (x^2 + y^2) + z^2 everywhere
+// build.py's build_sqnorm3_variant() builds order 0 as libsageicp_hip.v0.so; SAGE_SQNORM3_ORDER=0 in the
+// environment makes the loader and the test-suite use it against the checker built the same way.
 #ifndef SAGE_SQNORM3_ORDER
-#define SAGE_SQNORM3_ORDER 0
+#define SAGE_SQNORM3_ORDER 2
 #endif
+#define SAGE_SQNORM3_A(xx, yy, zz) ((xx) + ((yy) + (zz)))
+#define SAGE_SQNORM3_B(xx, yy, zz) (((xx) + (yy)) + (zz))
 #if SAGE_SQNORM3_ORDER == 0
-#define SAGE_SQNORM3(xx, yy, zz) ((xx) + ((yy) + (zz)))
+#define SAGE_SQNORM3_NN SAGE_SQNORM3_A
+#define SAGE_SQNORM3_RESID SAGE_SQNORM3_A
+#define SAGE_SQNORM3_FAR SAGE_SQNORM3_A
+#define SAGE_SQNORM3_ACCEPT SAGE_SQNORM3_A
+#define SAGE_SQNORM3_CROP SAGE_SQNORM3_A
+#elif SAGE_SQNORM3_ORDER == 1
+#define SAGE_SQNORM3_NN SAGE_SQNORM3_B
+#define SAGE_SQNORM3_RESID SAGE_SQNORM3_B
+#define SAGE_SQNORM3_FAR SAGE_SQNORM3_B
+#define SAGE_SQNORM3_ACCEPT SAGE_SQNORM3_B
+#define SAGE_SQNORM3_CROP SAGE_SQNORM3_B
 #else
-#define SAGE_SQNORM3(xx, yy, zz) (((xx) + (yy)) + (zz))
+#define SAGE_SQNORM3_NN SAGE_SQNORM3_B
+#define SAGE_SQNORM3_RESID SAGE_SQNORM3_B
+#define SAGE_SQNORM3_FAR SAGE_SQNORM3_B
+#define SAGE_SQNORM3_ACCEPT SAGE_SQNORM3_A
+#define SAGE_SQNORM3_CROP SAGE_SQNORM3_B
+#endif
+// point.head<3>().norm() of the range crop (Preprocessing.cpp:176): CROP, packet access -> (x^2 + y^2) + z^2.
+// estimation.log().norm() (Registration.cpp:137), a 6-vector: three packets p0 + (p1 + p2), then the two
+// lanes (order 2); summed left to right in orders 0 / 1.
+#if SAGE_SQNORM3_ORDER == 2
+#define SAGE_SQNORM6(a) ((((a)[0] * (a)[0]) + (((a)[2] * (a)[2]) + ((a)[4] * (a)[4]))) + \
+                         (((a)[1] * (a)[1]) + (((a)[3] * (a)[3]) + ((a)[5] * (a)[5]))))
+#else
+#define SAGE_SQNORM6(a) ((((((a)[0] * (a)[0] + (a)[1] * (a)[1]) + (a)[2] * (a)[2]) + (a)[3] * (a)[3]) + \
+                          (a)[4] * (a)[4]) + (a)[5] * (a)[5])
 #endif
 
 namespace sageicp {
@@ -129,6 +160,8 @@ struct IcpState {
     IcpProgress *progress;          // host-mapped progress block (nullptr: not published)
     int32_t exchange_failed;        // a peer's sums did not arrive in time (multi-GPU direct exchange)
     int32_t acc_overflow;           // a workgroup's sum did not fit the fixed-point accumulators (|value| >= 2^50)
+    int32_t loop_aborted;           // k_loop: a wait inside the launch timed out (the host falls back to the launch-per-iteration loop)
+    int32_t pad1_;
 };
 
 // Index into the 16 closed-form sums of AlignClouds (Registration.cpp:59-94):

@@ -36,7 +36,7 @@ def _ensure_product_library():
     spec.loader.exec_module(mod)
     if mod.needs_build():
         mod.build()
-    if os.environ.get("SAGE_SQNORM3_ORDER", "0") == "1":
+    if os.environ.get("SAGE_SQNORM3_ORDER", "2") == "0":
         # the suite on the other association of the 3-term squared norms (csrc/sageicp_types.h);
         # product and oracle both follow the variable
         mod.build_sqnorm3_variant()

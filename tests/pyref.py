@@ -69,7 +69,7 @@ class PyMap:
                         for nb in self.vox.get((i, j, k), ()):
                             ncand += 1
                             dx, dy, dz = nb[0] - p[0], nb[1] - p[1], nb[2] - p[2]
-                            d = dx * dx + (dy * dy + dz * dz)
+                            d = (dx * dx + dy * dy) + dz * dz     # (v3neighbor - v3point).squaredNorm(): packet reduction
                             if int(nb[3]) == int(p[3]) or int(nb[3] * p[3]) == 0:
                                 d = d * th
                             if d < best_d:
@@ -77,6 +77,7 @@ class PyMap:
             if best is None:
                 continue
             dx, dy, dz = best[0] - p[0], best[1] - p[1], best[2] - p[2]
+            # (closest - point).head<3>().norm(): a Block of an expression, scalar reduction 1 + 2 terms
             if math.sqrt(dx * dx + (dy * dy + dz * dz)) < max_dist:
                 res.append((qi, best.copy()))
         self.last_candidates = ncand

@@ -21,10 +21,10 @@ def test_oracle_reproduces_golden(oracle, path):
     T, JTJ, JTr = oracle.align_clouds(src, tgt, kernel, nthreads=1)
     pose, st = m.register_frame(g["scan"], oracle.IDENTITY, max_dist, kernel, th, nthreads=1)
     assert st.iterations == g["reg_iterations"][0]
-    if oracle.SQNORM3_ORDER == 0:       # the vectors are bit pins of the default association
+    if oracle.SQNORM3_ORDER == 2:       # the vectors are bit pins of the default association
         assert np.array_equal(JTJ, g["align_JTJ"]) and np.array_equal(T, g["align_pose"])
         assert np.array_equal(pose, g["reg_pose"])
-    else:                               # (x^2 + y^2) + z^2: 1 ulp in a residual's weight
+    else:                               # x^2 + (y^2 + z^2): 1 ulp in a residual's weight
         assert np.allclose(JTJ, g["align_JTJ"], rtol=1e-12) and np.allclose(T, g["align_pose"], atol=1e-12)
         assert np.allclose(pose, g["reg_pose"], atol=1e-10)
     # multi-threaded summation order differs at the 1e-13 level only

@@ -1,0 +1,190 @@
+"""The one-launch ICP loop (k_loop, kernels.hip) against the launch-per-iteration loop (k_icp + k_fin)
+and the oracle.  Both loops evaluate the same arithmetic on the same data and add their Gauss-Newton
+sums into order-independent fixed-point accumulators, so their poses must be BIT-identical, whatever
+shape the launch has; the oracle comparison is the usual parity bar.
+
+Needs a real MI355X:  python -m pytest tests -m gpu"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def pose_error(oracle, A, B):
+    e = oracle.se3_log(oracle.se3_mul(oracle.se3_inv(A), B))
+    return np.linalg.norm(e[:3]), np.linalg.norm(e[3:])
+
+
+class Env:
+    def __init__(self, **kv):
+        self.kv = {k: str(v) for k, v in kv.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _workload(gpu_sage, oracle, name, scale):
+    from sage_icp_amd import synthetic as syn
+    w = syn.make_workload(name, lambda: gpu_sage.VoxelHashMap(syn.WORKLOADS[name]["voxel"], 100.0), scale=scale)
+    om = oracle.Map(w["voxel"], 100.0)
+    om.add_points(w["stream"])
+    return w, om
+
+
+def _both_loops(gpu_sage, w, p, init=None, **env):
+    init = gpu_sage.IDENTITY if init is None else init
+    with Env(SAGEICP_LOOP=0, **env):
+        a, sa = gpu_sage.register_frame(w["scan"], w["map"], init, p["max_dist"], p["kernel"], p["sem_th"],
+                                        return_stats=True)
+    with Env(SAGEICP_LOOP=2, **env):
+        b, sb = gpu_sage.register_frame(w["scan"], w["map"], init, p["max_dist"], p["kernel"], p["sem_th"],
+                                        return_stats=True)
+    assert sa.single_launch == 0
+    return a, sa, b, sb
+
+
+def _same(sa, sb):
+    assert sa.iterations == sb.iterations and sa.converged == sb.converged
+    assert sa.n_corr_first == sb.n_corr_first and sa.n_corr_last == sb.n_corr_last
+    assert list(sa.n_corr_hist) == list(sb.n_corr_hist)
+    assert sa.last_step_norm == sb.last_step_norm
+    assert sa.sum_candidates == sb.sum_candidates
+
+
+@pytest.mark.parametrize("name,scale,params", [
+    ("c1", 1.0, "cold"), ("c2", 0.1, "cold"), ("c2", 0.1, "steady"), ("c2", 0.25, "cold"),
+    ("c5", 0.05, "dense"), ("c5", 0.05, "dense_nosem"), ("c4", 0.05, "steady"),
+])
+def test_one_launch_loop_is_bit_identical_and_matches_oracle(gpu_sage, oracle, name, scale, params):
+    from sage_icp_amd import synthetic as syn
+    w, om = _workload(gpu_sage, oracle, name, scale)
+    p = syn.PARAMS[params]
+    a, sa, b, sb = _both_loops(gpu_sage, w, p)
+    assert sb.single_launch == 1, "the frame was expected to fit the one-launch loop"
+    assert np.array_equal(a, b)
+    _same(sa, sb)
+    opose, ost = om.register_frame(w["scan"], oracle.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"])
+    dt, dr = pose_error(oracle, opose, b)
+    assert dt < 1e-7 and dr < 1e-7
+    assert sb.iterations == ost.iterations and sb.converged == ost.converged
+    assert sb.n_corr_first == ost.n_corr_first and sb.n_corr_last == ost.n_corr_last
+    assert sb.sum_candidates == ost.sum_candidates_total
+
+
+@pytest.mark.parametrize("lw", [1, 2, 3, 4])
+@pytest.mark.parametrize("compact", [0, 1])
+@pytest.mark.parametrize("waves", [1, 3, 8])
+def test_every_shape_of_the_one_launch_loop(gpu_sage, oracle, lw, compact, waves):
+    """lanes per query x scan form x waves per workgroup (incl. counts that are not powers of two)"""
+    if compact and lw > 2:
+        pytest.skip("the compact scan of k_loop exists for 2 and 4 lanes per query")
+    from sage_icp_amd import synthetic as syn
+    w, om = _workload(gpu_sage, oracle, "c2", 0.05)
+    p = syn.PARAMS["cold"]
+    a, sa, b, sb = _both_loops(gpu_sage, w, p, SAGEICP_LW=lw, SAGEICP_FILTER=compact, SAGEICP_LOOP_WAVES=waves)
+    assert sb.single_launch == 1 and sb.lanes_per_query == 1 << lw and sb.compact_scan == compact
+    assert np.array_equal(a, b)
+    _same(sa, sb)
+    opose, ost = om.register_frame(w["scan"], oracle.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"])
+    dt, dr = pose_error(oracle, opose, b)
+    assert dt < 1e-7 and dr < 1e-7 and sb.iterations == ost.iterations
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 511, 4097])
+def test_ragged_frame_sizes(gpu_sage, oracle, n):
+    from sage_icp_amd import synthetic as syn
+    w, om = _workload(gpu_sage, oracle, "c2", 0.05)
+    w = dict(w, scan=np.ascontiguousarray(w["scan"][:n]))
+    p = syn.PARAMS["cold"]
+    a, sa, b, sb = _both_loops(gpu_sage, w, p)
+    assert sb.single_launch == 1
+    assert np.array_equal(a, b)
+    _same(sa, sb)
+    opose, ost = om.register_frame(w["scan"], oracle.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"])
+    dt, dr = pose_error(oracle, opose, b)
+    assert dt < 1e-6 and dr < 1e-6 and sb.iterations == ost.iterations
+
+
+def test_no_correspondence_and_far_frames(gpu_sage, oracle):
+    """a frame with no map point in reach: zero pairs, the zero system solves to a zero step, the loop
+    ends after one iteration with the guess (Registration.cpp:92,137)"""
+    from sage_icp_amd import synthetic as syn
+    w, om = _workload(gpu_sage, oracle, "c2", 0.05)
+    far = w["scan"].copy()
+    far[:, :3] += 5000.0
+    w = dict(w, scan=far)
+    p = syn.PARAMS["cold"]
+    a, sa, b, sb = _both_loops(gpu_sage, w, p)
+    assert sb.single_launch == 1 and sb.iterations == 1 and sb.n_corr_first == 0
+    assert np.array_equal(a, b) and np.array_equal(b, gpu_sage.IDENTITY)
+
+
+def test_initial_guess_and_repeated_calls(gpu_sage, oracle):
+    from sage_icp_amd import synthetic as syn
+    w, om = _workload(gpu_sage, oracle, "c2", 0.1)
+    p = syn.PARAMS["steady"]
+    guess = syn.pose_from_rpy_t([0.05, -0.02, 0.8], [0.45, 0.12, 0.0])
+    a, sa, b, sb = _both_loops(gpu_sage, w, p, init=guess)
+    assert sb.single_launch == 1 and np.array_equal(a, b)
+    _same(sa, sb)
+    opose, ost = om.register_frame(w["scan"], guess, p["max_dist"], p["kernel"], p["sem_th"])
+    dt, dr = pose_error(oracle, opose, b)
+    assert dt < 1e-7 and dr < 1e-7 and sb.iterations == ost.iterations
+    # the shared block is re-initialised before every launch: the same call again, and again
+    with Env(SAGEICP_LOOP=2):
+        for _ in range(3):
+            c = gpu_sage.register_frame(w["scan"], w["map"], guess, p["max_dist"], p["kernel"], p["sem_th"])
+            assert np.array_equal(b, c)
+
+
+def test_frame_that_does_not_fit_uses_the_launch_per_iteration_loop(gpu_sage, oracle):
+    from sage_icp_amd import synthetic as syn
+    w, om = _workload(gpu_sage, oracle, "c2", 0.1)
+    big = np.ascontiguousarray(np.tile(w["scan"], (12, 1)))         # 144k points at 8 lanes each: 18k waves
+    p = syn.PARAMS["steady"]
+    with Env(SAGEICP_LOOP=2, SAGEICP_LW=3):
+        _, st = gpu_sage.register_frame(big, w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"],
+                                        return_stats=True)
+    assert st.single_launch == 0 and st.converged == 1
+
+
+def test_timeout_inside_the_launch_falls_back(gpu_sage, oracle):
+    """SAGEICP_LOOP_TIMEOUT_TICKS=1: every wait inside the launch gives up at once; the kernel must end
+    (no hang) and the frame must still be registered — by the other loop — with the same pose"""
+    from sage_icp_amd import synthetic as syn
+    w, om = _workload(gpu_sage, oracle, "c2", 0.05)
+    p = syn.PARAMS["cold"]
+    with Env(SAGEICP_LOOP=0):
+        a = gpu_sage.register_frame(w["scan"], w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"])
+    with Env(SAGEICP_LOOP=2, SAGEICP_LOOP_TIMEOUT_TICKS=1):
+        b, sb = gpu_sage.register_frame(w["scan"], w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"],
+                                        p["sem_th"], return_stats=True)
+    assert np.array_equal(a, b)
+    # (a tick is 10 ns: a wait that long never succeeds on a grid of this size)
+    assert sb.single_launch == 0
+
+
+def test_streamed_frames_through_the_pipeline(gpu_sage, oracle):
+    """the per-frame pipeline (sageicp_pipeline_*) registers 24k-point sources: both loops, same poses"""
+    from sage_icp_amd import synthetic as syn
+    frames, _ = syn.make_stream(7, 8, points_per_frame=60000)
+    poses = {}
+    for mode in (0, 2):
+        with Env(SAGEICP_LOOP=mode):
+            pipe = gpu_sage.SageICP()
+            out = [pipe.RegisterFrame(f) for f in frames]
+            poses[mode] = [o[0].copy() for o in out]
+            if mode == 2:
+                assert all(o[4].single_launch == 1 for o in out[1:]), "streamed sources fit the one-launch loop"
+    for a, b in zip(poses[0], poses[2]):
+        assert np.array_equal(a, b)
