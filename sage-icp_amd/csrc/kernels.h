@@ -146,7 +146,7 @@ void launch_red(const RedParams &p, hipStream_t s);
 constexpr int kLoopReplicas = 8;           // accumulator copies (workgroup b adds into copy b & 7)
 constexpr int kLoopPoseGranules = 25;      // R[9], t[3] as 24 x {tag, 32 bits} + {tag, done}
 struct LoopShared {
-    long long acc[kLoopReplicas][kAccWords];            // as FinParams::acc; word 63 of copy 0: overflow flag
+    long long acc[2][kLoopReplicas][kAccWords];         // as FinParams::acc, one set per iteration parity; word 63 of copy 0: overflow flag
     unsigned long long arrive[kLoopReplicas][16];       // [r][0]: workgroups counted in, all iterations (one per 128-B line)
     unsigned long long pose[32];                        // granules (tag << 32) | payload, tag = iteration + 1
     unsigned long long abort_word[16];                  // [0] != 0: a wait timed out somewhere — everybody leaves

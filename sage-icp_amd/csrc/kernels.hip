@@ -807,17 +807,29 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
     // home voxel is empty — a tight bound before anything is scanned.  It is an ordinary
     // candidate: meeting it again in the scan changes nothing.
     constexpr unsigned kHome = 13u;
-    if (FUSED) {
+    bool merged = false;                       // this query's home voxel is scanned with its neighbours
+    if constexpr (PERSIST) {
+        // k_loop holds the seed's record in registers: a seeded query takes its bound from the seed
+        // alone — no memory — and scans its home voxel together with the neighbours that survive
+        // that bound, in ONE pass (any bound at or above the final best prunes exactly; after the
+        // first iterations the seed IS the answer for most queries and the bound is the final
+        // one).  Only queries without a seed (the first pass of a call, a rebuilt row) scan their
+        // home voxel first; a wave without such a query skips that pass altogether.
         const bool seeded = valid && !stale && prev.x != 0xFFFFFFFFu;
-        Point4 pp;                                                    // the full record
-        if constexpr (PERSIST) pp = LL->pp;
-        else pp = load_point(pts, seeded ? prev.y : 0u);
+        const Point4 pp = LL->pp;
+        evaluate(pp, seeded, prev.x);
+        merged = seeded;
+        const unsigned first = seeded ? 0u : (occ & (1u << kHome));
+        if (__ballot(first != 0u)) scan(first, nullptr, false, 0u);
+    } else if (FUSED) {
+        const bool seeded = valid && !stale && prev.x != 0xFFFFFFFFu;
+        const Point4 pp = load_point(pts, seeded ? prev.y : 0u);      // the full record
         scan(occ & (1u << kHome), &pp, seeded, prev.x);
     } else {
         scan(occ & (1u << kHome), nullptr, false, 0u);
     }
     NN_T(2);
-    // what the query holds after its home voxel bounds the rest of its search
+    // what the query holds after its home voxel (or its seed) bounds the rest of its search
     const double bound = seg_min_f64<W>(best);
     fb = bound;                                // (set_thresholds runs at the start of the scan)
     unsigned need = P.keep_all;
@@ -851,7 +863,7 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
             need |= (lb <= bound) ? (1u << v) : 0u;
         }
     }
-    scan(need & occ & ~(1u << kHome), nullptr, false, 0u);
+    scan((merged ? (need | (1u << kHome)) : (need & ~(1u << kHome))) & occ, nullptr, false, 0u);
 
     // argmin over the W lanes of the query: first the minimum distance (never NaN: a NaN distance
     // fails every comparison), then the smallest key among the lanes that hold it; the winner's
@@ -1379,8 +1391,9 @@ __global__ __launch_bounds__(kFinThreads) void k_fin(FinParams P) {
 //   last wave of a    adds the workgroup's sums into the fixed-point accumulators, waits until its
 //   workgroup         atomics are performed (vmcnt) and counts the workgroup in;
 //   the solving       (one wave, the last workgroup of the grid, no queries) waits for every workgroup's
-//   workgroup         count, takes the accumulators (atomic exchange: read and clear in one operation at
-//                     the memory side), solves, composes, tests, and publishes the next pose as 25
+//   workgroup         count, reads this iteration's set of accumulators (two sets alternate; the one just
+//                     read is cleared for the iteration after the next), solves, composes, tests, and
+//                     publishes the next pose as 25
 //                     self-tagged 8-byte granules (tag = iteration + 1: the data is the flag, no fence
 //                     on either side);
 //   wave 0 of every   polls the granules (one relaxed agent-scope load per lane and pass), hands the
@@ -1451,12 +1464,21 @@ __device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, u
         }
     }
     LOOP_STAMP_SOLVER(it, 0);
-    // 2. the sums: read and clear in one operation per word
+    // 2. the sums of this iteration's set of accumulators (one round trip), which is then cleared for
+    // the iteration after the next (the clears are complete long before that pose is published: the
+    // wait for the next iteration's loads covers them)
     {
-        long long d = 0;
+        long long (*acc)[kAccWords] = sh->acc[it & 1];
+        long long v[kLoopReplicas];
 #pragma unroll
         for (int r = 0; r < kLoopReplicas; ++r)
-            d += __hip_atomic_exchange(&sh->acc[r][lane], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[r] = __hip_atomic_load(&acc[r][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long long d = 0;
+#pragma unroll
+        for (int r = 0; r < kLoopReplicas; ++r) d += v[r];
+#pragma unroll
+        for (int r = 0; r < kLoopReplicas; ++r)
+            __hip_atomic_store(&acc[r][lane], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         digits[lane] = d;
         __builtin_amdgcn_wave_barrier();
         if (lane < kNumSums) {
@@ -1531,6 +1553,7 @@ __device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, u
     __builtin_amdgcn_wave_barrier();
     LOOP_STAMP_SOLVER(it, 2);
     // 4. publish: 24 halves of R, t and the done word, each with its tag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the clears of step 2, issued microseconds ago)
     if (lane < 24) st_agent(&sh->pose[lane], (tag << 32) | reinterpret_cast<const uint32_t *>(pub)[lane]);
     if (lane == 24) st_agent(&sh->pose[24], (tag << 32) | done);
     LOOP_STAMP_SOLVER(it, 3);
@@ -1586,7 +1609,7 @@ void k_loop(IcpParams P, LoopParams L) {
         if (last) {
             // this wave closes the workgroup's iteration
             wg_sums_to_acc(reinterpret_cast<const double *>(smem + kLpSums), smem + kLpPairs, nw,
-                           &sh->acc[blockIdx.x & (kLoopReplicas - 1)][0], &sh->acc[0][kAccWords - 1]);
+                           &sh->acc[it & 1][blockIdx.x & (kLoopReplicas - 1)][0], &sh->acc[it & 1][0][kAccWords - 1]);
             if (lane == 0) smem[kLpArrive] = 0u;          // everybody is in: ready for the next iteration
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the adds are performed before the count
             if (lane == 0)
@@ -1615,7 +1638,7 @@ void k_loop(IcpParams P, LoopParams L) {
                     aborted = true;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
             }
             if (aborted) {
                 if (lane == 0) smem[kLpDone] = 2u;

@@ -796,7 +796,8 @@ def test_direct_exchange_timeout_is_reported_not_hung(gpu_sage):
     assert "did not arrive in time" in run.stderr and "no RCCL side to fall back to" in run.stderr
 
 
-def test_profiling_stats(gpu_sage, oracle):
+def test_profiling_stats(gpu_sage, oracle, monkeypatch):
+    monkeypatch.setenv("SAGEICP_LOOP", "0")       # per-kernel times of the launch-per-iteration loop (k_loop: tests/test_loop_kernel.py)
     w, om = _workload(gpu_sage, oracle, "c2", 0.05)
     gpu_sage.set_profiling(2)
     try:
