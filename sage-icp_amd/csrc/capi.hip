@@ -1326,10 +1326,6 @@ static bool plan_loop(const sageicp_map *m, uint64_t n, double sem_th, LoopPlan 
     int lw = icp_lw(n, sparse_voxels(m));
     bool filter = wants_filter(m, n, sem_th);
     if (lw < 1) return false;                          // (k_loop is built for 2..16 lanes per query)
-    if (lw > 2 && filter) {                            // (its compact scan for 2 and 4 lanes per query only)
-        if (std::getenv("SAGEICP_FILTER")) return false;
-        filter = false;
-    }
     const uint64_t cap_waves = 2ull * static_cast<uint64_t>(sc.num_cus) * kLoopMaxWavesHost - kLoopMaxWavesHost;
     uint64_t waves = (n + (64u >> lw) - 1) / (64u >> lw);
     if (mode == 2 && env_int("SAGEICP_LW", -1) < 0) {

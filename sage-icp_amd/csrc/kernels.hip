@@ -70,6 +70,14 @@
 #ifndef SAGE_ICP_OCC
 #define SAGE_ICP_OCC 6         // waves per SIMD the register allocation of k_icp is held to
 #endif
+// pairs of candidates a lane of k_loop keeps in flight while it scans: of full records / of compact ones
+#ifndef SAGE_LOOP_DEPTH_FULL
+#define SAGE_LOOP_DEPTH_FULL 3
+#endif
+#ifndef SAGE_LOOP_DEPTH_COMPACT
+#define SAGE_LOOP_DEPTH_COMPACT 4
+#endif
+#define SAGE_LOOP_DEPTH_OF(filt) ((filt) ? SAGE_LOOP_DEPTH_COMPACT : SAGE_LOOP_DEPTH_FULL)
 
 #include "kernels.h"
 #include "se3_math.h"
@@ -779,25 +787,66 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
             }
             }
         };
+        // k_loop runs a few waves per SIMD with 128 registers each, and an iteration ends with its
+        // SLOWEST wave — the one that holds a query with a couple of hundred points to look at: its
+        // scan keeps more sets in flight (three of full records, four of compact ones), so that a
+        // load has two or three evaluations to hide under instead of one.  A short scan pays an idle
+        // step or two more; it is not what the iteration waits for.
+        constexpr int DEPTH = !PERSIST ? 2 : SAGE_LOOP_DEPTH_OF(FILT);
         Pair A, B;
         bool more = false;
         issue(A, more);
-        // the seed's load is older than A's: waiting for it leaves A's loads in flight
-        if (seed) evaluate(*seed, seeded, seed_key);
-        fb = min_f64(fb, best);
-        set_thresholds();
-        // One exit per double step: an exit between the two halves gives the loop header a
-        // predecessor with B's loads pending, and the compiler then drains the queue (vmcnt(0))
-        // before every issue(B) — the overlap this loop exists for.  A scan that ends after the
-        // first half pays one idle half step instead.
-        // (Peeling short scans out of the loop — one pair step, or none — was tried: the extra
-        // paths cost 10 registers and spills, every workload lost 5-10 %.)
-        for (;;) {
+        if constexpr (DEPTH == 2) {
+            // the seed's load is older than A's: waiting for it leaves A's loads in flight
+            if (seed) evaluate(*seed, seeded, seed_key);
+            fb = min_f64(fb, best);
+            set_thresholds();
+            // One exit per double step: an exit between the two halves gives the loop header a
+            // predecessor with B's loads pending, and the compiler then drains the queue (vmcnt(0))
+            // before every issue(B) — the overlap this loop exists for.  A scan that ends after the
+            // first half pays one idle half step instead.
+            // (Peeling short scans out of the loop — one pair step, or none — was tried: the extra
+            // paths cost 10 registers and spills, every workload lost 5-10 %.)
+            for (;;) {
+                issue(B, more);
+                consume(A);
+                issue(A, more);
+                consume(B);
+                if (!__ballot(A.ha | more)) break;
+            }
+        } else if constexpr (DEPTH == 3) {
+            Pair C;
             issue(B, more);
-            consume(A);
-            issue(A, more);
-            consume(B);
-            if (!__ballot(A.ha | more)) break;
+            if (seed) evaluate(*seed, seeded, seed_key);
+            fb = min_f64(fb, best);
+            set_thresholds();
+            for (;;) {
+                issue(C, more);
+                consume(A);
+                issue(A, more);
+                consume(B);
+                issue(B, more);
+                consume(C);
+                if (!__ballot(A.ha | B.ha | more)) break;
+            }
+        } else {
+            Pair C, D;
+            issue(B, more);
+            issue(C, more);
+            if (seed) evaluate(*seed, seeded, seed_key);
+            fb = min_f64(fb, best);
+            set_thresholds();
+            for (;;) {
+                issue(D, more);
+                consume(A);
+                issue(A, more);
+                consume(B);
+                issue(B, more);
+                consume(C);
+                issue(C, more);
+                consume(D);
+                if (!__ballot(A.ha | B.ha | C.ha | more)) break;
+            }
         }
     };
 
@@ -1889,8 +1938,8 @@ int loop_blocks_per_cu(int lw, bool filter, int nw) {
     switch (lw) {
         case 1: return filter ? loop_blocks_lw<1, true>(nw) : loop_blocks_lw<1, false>(nw);
         case 2: return filter ? loop_blocks_lw<2, true>(nw) : loop_blocks_lw<2, false>(nw);
-        case 3: return filter ? 0 : loop_blocks_lw<3, false>(nw);
-        case 4: return filter ? 0 : loop_blocks_lw<4, false>(nw);
+        case 3: return filter ? loop_blocks_lw<3, true>(nw) : loop_blocks_lw<3, false>(nw);
+        case 4: return filter ? loop_blocks_lw<4, true>(nw) : loop_blocks_lw<4, false>(nw);
         default: return 0;
     }
 }
@@ -1906,8 +1955,14 @@ void launch_loop(const IcpParams &p, const LoopParams &l, int lw, int grid, hipS
             if (p.filter) hipLaunchKernelGGL((k_loop<2, true>), g, b, lds, s, p, l);
             else hipLaunchKernelGGL((k_loop<2, false>), g, b, lds, s, p, l);
             break;
-        case 3: hipLaunchKernelGGL((k_loop<3, false>), g, b, lds, s, p, l); break;
-        default: hipLaunchKernelGGL((k_loop<4, false>), g, b, lds, s, p, l); break;
+        case 3:
+            if (p.filter) hipLaunchKernelGGL((k_loop<3, true>), g, b, lds, s, p, l);
+            else hipLaunchKernelGGL((k_loop<3, false>), g, b, lds, s, p, l);
+            break;
+        default:
+            if (p.filter) hipLaunchKernelGGL((k_loop<4, true>), g, b, lds, s, p, l);
+            else hipLaunchKernelGGL((k_loop<4, false>), g, b, lds, s, p, l);
+            break;
     }
 }
 

@@ -86,8 +86,6 @@ def test_one_launch_loop_is_bit_identical_and_matches_oracle(gpu_sage, oracle, n
 @pytest.mark.parametrize("waves", [1, 3, 8])
 def test_every_shape_of_the_one_launch_loop(gpu_sage, oracle, lw, compact, waves):
     """lanes per query x scan form x waves per workgroup (incl. counts that are not powers of two)"""
-    if compact and lw > 2:
-        pytest.skip("the compact scan of k_loop exists for 2 and 4 lanes per query")
     from sage_icp_amd import synthetic as syn
     w, om = _workload(gpu_sage, oracle, "c2", 0.05)
     p = syn.PARAMS["cold"]
