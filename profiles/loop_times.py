@@ -48,3 +48,29 @@ print("mean: pose held (median workgroup, previous iteration) %.2f | counted in 
       % tuple(r[:9]))
 print("      -> wait for the pose %.2f, search of the median workgroup %.2f, of the last %.2f, last count -> seen %.2f, read sums %.2f, solve %.2f, publish %.2f"
       % (r[0], r[2] - r[0], r[4] - r[0], r[5] - r[4], r[6] - r[5], r[7] - r[6], r[8] - r[7]))
+
+# ---- which workgroups are the slow ones?
+info = np.zeros((IT, WG, 4), dtype=np.uint32)
+if hasattr(sage.lib(), "sageicp_debug_loop_info"):
+    sage.lib().sageicp_debug_loop_info(info.ctypes.data_as(C.c_void_p))
+    its = [k for k in (8, 24, 40) if k < min(IT, st.iterations)]
+    for it in its:
+        t0 = sv[it - 1, 3]
+        arr = wg[it, used, 0] - t0
+        held = wg[it - 1, used, 1] - t0
+        mx, stl, sm = info[it, used, 1].astype(float), info[it, used, 2].astype(float), info[it, used, 3].astype(float)
+        xcc = info[it, used, 0] >> 28
+        cu = (info[it, used, 0] >> 8) & 0xF
+        se = (info[it, used, 0] >> 13) & 0x7
+        dur = arr - held
+        print("iteration %d: search time of a workgroup (pose held -> counted in): mean %.2f  p50 %.2f  p90 %.2f  max %.2f"
+              % (it, dur.mean(), np.median(dur), np.quantile(dur, 0.9), dur.max()))
+        print("   correlation with: max points of one query %.2f | points of the workgroup %.2f | stale queries %.2f"
+              % (np.corrcoef(dur, mx)[0, 1], np.corrcoef(dur, sm)[0, 1], np.corrcoef(dur, stl)[0, 1] if stl.std() > 0 else 0.0))
+        print("   per XCD: mean search time " + " ".join("%.2f" % dur[xcc == x].mean() for x in range(8) if (xcc == x).any())
+              + " | points " + " ".join("%.0f" % sm[xcc == x].sum() for x in range(8) if (xcc == x).any()))
+        order = np.argsort(-dur)[:8]
+        print("   slowest: " + "; ".join("%.1f us (xcd %d se %d cu %d, max %d pts, %d stale, %d pts)" % (dur[o], xcc[o], se[o], cu[o], mx[o], stl[o], sm[o]) for o in order))
+        q = np.quantile(sm, [0.2, 0.4, 0.6, 0.8])
+        b = np.digitize(sm, q)
+        print("   search time by quintile of the workgroup's points: " + " ".join("%.2f" % dur[b == k].mean() for k in range(5)))

@@ -72,10 +72,10 @@
 #endif
 // pairs of candidates a lane of k_loop keeps in flight while it scans: of full records / of compact ones
 #ifndef SAGE_LOOP_DEPTH_FULL
-#define SAGE_LOOP_DEPTH_FULL 3
+#define SAGE_LOOP_DEPTH_FULL 2
 #endif
 #ifndef SAGE_LOOP_DEPTH_COMPACT
-#define SAGE_LOOP_DEPTH_COMPACT 4
+#define SAGE_LOOP_DEPTH_COMPACT 2
 #endif
 #define SAGE_LOOP_DEPTH_OF(filt) ((filt) ? SAGE_LOOP_DEPTH_COMPACT : SAGE_LOOP_DEPTH_FULL)
 
@@ -394,7 +394,8 @@ constexpr unsigned kLpT = (kLpDone + 1u + 1u) & ~1u;
 constexpr unsigned kLpS = kLpT + 28u;
 constexpr unsigned kLpPub = kLpS + 2u * kNumSums;
 constexpr unsigned kLpDigits = kLpPub + 24u;
-constexpr unsigned kLpHeaderWords = (kLpDigits + 2u * kAccWords + 15u) & ~15u;
+constexpr unsigned kLpDbg = kLpDigits + 2u * kAccWords;      // probe builds: max points of a query | stale queries | points, per workgroup
+constexpr unsigned kLpHeaderWords = (kLpDbg + 4u + 15u) & ~15u;
 __host__ __device__ constexpr unsigned loop_wave_words(int lw) {
     // the rows of the wave's queries (they stay for the whole call) + the epilogue's transposed
     // reduction, 16 components x (queries + 2) fp64
@@ -787,11 +788,11 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
             }
             }
         };
-        // k_loop runs a few waves per SIMD with 128 registers each, and an iteration ends with its
-        // SLOWEST wave — the one that holds a query with a couple of hundred points to look at: its
-        // scan keeps more sets in flight (three of full records, four of compact ones), so that a
-        // load has two or three evaluations to hide under instead of one.  A short scan pays an idle
-        // step or two more; it is not what the iteration waits for.
+        // (k_loop has registers to spare — a few waves per SIMD, 128 registers each — and an iteration
+        // of it ends with its SLOWEST wave, so three / four sets in flight were tried there
+        // (SAGE_LOOP_DEPTH_FULL / _COMPACT): 15k queries 18.8 -> 19.9 us per iteration with three sets
+        // of full records, 20.6 -> 22.0 with four of compact ones (profiles/r04/loop_depth.txt) — the
+        // slow waves are not waiting for their loads.  Two sets everywhere.)
         constexpr int DEPTH = !PERSIST ? 2 : SAGE_LOOP_DEPTH_OF(FILT);
         Pair A, B;
         bool more = false;
@@ -1028,6 +1029,21 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
             prior = __hip_atomic_fetch_add(&smem[PERSIST ? kLpArrive : kWgArrive], 1u, __ATOMIC_ACQ_REL,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
         prior = __builtin_amdgcn_readfirstlane(prior);
+#ifdef SAGE_LOOP_TIMING
+        if constexpr (PERSIST) {
+            unsigned mx = valid ? npairs : 0u, sm = (valid && ci == 0u) ? npairs : 0u, stl = (stale && ci == 0u) ? 1u : 0u;
+            for (int d = 1; d < 64; d <<= 1) {
+                mx = max(mx, static_cast<unsigned>(__shfl_xor(mx, d, 64)));
+                sm += __shfl_xor(sm, d, 64);
+                stl += __shfl_xor(stl, d, 64);
+            }
+            if (lane == 0) {
+                atomicMax(&smem[kLpDbg], mx);
+                atomicAdd(&smem[kLpDbg + 1], stl);
+                atomicAdd(&smem[kLpDbg + 2], sm);
+            }
+        }
+#endif
         if constexpr (PERSIST) {
             // k_loop finishes the iteration itself (wg_sums_to_acc, arrival, solve)
             const bool last = prior == static_cast<unsigned>(nw) - 1u;
@@ -1457,9 +1473,13 @@ __global__ __launch_bounds__(kFinThreads) void k_fin(FinParams P) {
 // read, the step solved, the pose published
 constexpr int kLoopTimedIters = 64, kLoopTimedWgs = 512;
 __device__ unsigned long long g_loop_wg[kLoopTimedIters][kLoopTimedWgs][2];
+__device__ unsigned g_loop_wginfo[kLoopTimedIters][kLoopTimedWgs][4];     // HW_ID | max points of a query | stale queries | points
 __device__ unsigned long long g_loop_solver[kLoopTimedIters][4];
 #define LOOP_STAMP_SOLVER(it, k) do { if ((it) < kLoopTimedIters && (threadIdx.x & 63u) == 0u) g_loop_solver[it][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define LOOP_STAMP_WG(it, k) do { if ((it) < kLoopTimedIters && blockIdx.x < kLoopTimedWgs && (threadIdx.x & 63u) == 0u) g_loop_wg[it][blockIdx.x][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" void sageicp_debug_loop_info(unsigned *info) {
+    (void)hipMemcpyFromSymbol(info, HIP_SYMBOL(g_loop_wginfo), sizeof(unsigned) * kLoopTimedIters * kLoopTimedWgs * 4);
+}
 extern "C" void sageicp_debug_loop_times(unsigned long long *wg, unsigned long long *solver) {
     (void)hipMemcpyFromSymbol(wg, HIP_SYMBOL(g_loop_wg), sizeof(unsigned long long) * kLoopTimedIters * kLoopTimedWgs * 2);
     (void)hipMemcpyFromSymbol(solver, HIP_SYMBOL(g_loop_solver), sizeof(unsigned long long) * kLoopTimedIters * 4);
@@ -1638,6 +1658,9 @@ void k_loop(IcpParams P, LoopParams L) {
     if (threadIdx.x == 0) {
         smem[kLpArrive] = 0u;
         smem[kLpDone] = 0u;
+#ifdef SAGE_LOOP_TIMING
+        smem[kLpDbg] = 0u; smem[kLpDbg + 1] = 0u; smem[kLpDbg + 2] = 0u;
+#endif
     }
     LoopLane LL;
     {
@@ -1660,6 +1683,18 @@ void k_loop(IcpParams P, LoopParams L) {
             wg_sums_to_acc(reinterpret_cast<const double *>(smem + kLpSums), smem + kLpPairs, nw,
                            &sh->acc[it & 1][blockIdx.x & (kLoopReplicas - 1)][0], &sh->acc[it & 1][0][kAccWords - 1]);
             if (lane == 0) smem[kLpArrive] = 0u;          // everybody is in: ready for the next iteration
+#ifdef SAGE_LOOP_TIMING
+            if (lane == 0 && it < kLoopTimedIters && blockIdx.x < kLoopTimedWgs) {
+                unsigned hw;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+                unsigned xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                unsigned *o = g_loop_wginfo[it][blockIdx.x];
+                o[0] = (xcc << 28) | (hw & 0x0FFFFFFFu);
+                o[1] = smem[kLpDbg]; o[2] = smem[kLpDbg + 1]; o[3] = smem[kLpDbg + 2];
+                smem[kLpDbg] = 0u; smem[kLpDbg + 1] = 0u; smem[kLpDbg + 2] = 0u;
+            }
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the adds are performed before the count
             if (lane == 0)
                 (void)__hip_atomic_fetch_add(&sh->arrive[blockIdx.x & (kLoopReplicas - 1)][0], 1ull, __ATOMIC_RELAXED,
