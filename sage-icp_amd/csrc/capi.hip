@@ -1326,7 +1326,7 @@ static bool plan_loop(const sageicp_map *m, uint64_t n, double sem_th, LoopPlan 
     int lw = icp_lw(n, sparse_voxels(m));
     bool filter = wants_filter(m, n, sem_th);
     if (lw < 1) return false;                          // (k_loop is built for 2..16 lanes per query)
-    const uint64_t cap_waves = 2ull * static_cast<uint64_t>(sc.num_cus) * kLoopMaxWavesHost - kLoopMaxWavesHost;
+    const uint64_t cap_waves = (2ull * static_cast<uint64_t>(sc.num_cus) - 1) / 32 * 32 * kLoopMaxWavesHost;
     uint64_t waves = (n + (64u >> lw) - 1) / (64u >> lw);
     if (mode == 2 && env_int("SAGEICP_LW", -1) < 0) {
         // fewer lanes per query than the launch-per-iteration loop would take, if that is what makes the frame fit
@@ -1336,11 +1336,12 @@ static bool plan_loop(const sageicp_map *m, uint64_t n, double sem_th, LoopPlan 
         }
     }
     if (waves > cap_waves) return false;
-    const uint64_t max_wgs = 2ull * static_cast<uint64_t>(sc.num_cus) - 8;
+    // (query workgroups come in XCD stripes: 8 x kLoopStripe = 32 of them, kernels.hip)
+    const uint64_t max_wgs = (2ull * static_cast<uint64_t>(sc.num_cus) - 1) / 32 * 32;
     int nw = static_cast<int>((waves + max_wgs - 1) / max_wgs);
     nw = std::max(nw, std::min(kLoopMaxWavesHost, std::max(1, env_int("SAGEICP_LOOP_WAVES", 4))));
     if (nw > kLoopMaxWavesHost) return false;
-    const uint64_t wgs = ((waves + nw - 1) / nw + 7) / 8 * 8;
+    const uint64_t wgs = ((waves + nw - 1) / nw + 31) / 32 * 32;
     // (cached per shape: the occupancy query costs microseconds)
     static std::mutex mu;
     static std::map<int, int> cache;

@@ -382,6 +382,7 @@ struct LoopLane {
     unsigned occ;
 };
 constexpr int kLoopMaxWaves = kLoopMaxWavesHost;   // waves per workgroup of k_loop (<= 512 threads)
+constexpr unsigned kLoopStripe = 4;          // workgroups of k_loop per XCD stripe (its grid: 32 k + 1 workgroups)
 constexpr int kNoVoxel = 0x7FFFFFFF;        // a home voxel no point has (|index| < 2^20): row not built yet
 // LDS header of a k_loop workgroup (words): ws[8][16] fp64 sums | accepted pairs [8] | arrival
 // counter | the pose of this iteration (R[9], t[3]) | done | loop state of the solving workgroup
@@ -466,11 +467,12 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
     // Workgroup b is dispatched to XCD b % 8 (observed; speed only): XCD x serves the stripes
     // x, x+8, x+16, ... of kStripe consecutive workgroups' worth of the spatially sorted frame,
     // so each private L2 sees a few compact regions of the map and every XCD gets the same mix
-    // of dense and sparse regions.  (k_loop: XCD x serves one contiguous eighth of the frame for
-    // the whole call — its L2 keeps that region of the map warm across the iterations.)
+    // of dense and sparse regions.  (k_loop: stripes of kLoopStripe workgroups; one contiguous eighth
+    // of the frame per XCD left the XCDs with 57k to 97k points to look at per iteration on a c2 shard,
+    // and the iteration ends with the slowest, profiles/r04/loop_times.txt.)
     constexpr unsigned kStripe = SAGE_ICP_STRIPE;
     const unsigned xcd = blockIdx.x & 7u, jb = blockIdx.x >> 3;
-    const unsigned wg = PERSIST ? xcd * ((gridDim.x - 1u) >> 3) + jb
+    const unsigned wg = PERSIST ? ((jb / kLoopStripe) * 8u + xcd) * kLoopStripe + (jb % kLoopStripe)
                                 : ((jb / kStripe) * 8u + xcd) * kStripe + (jb % kStripe);
     const unsigned wave_id = wg * static_cast<unsigned>(PERSIST ? nw : kIcpWavesPerBlock) +
                              static_cast<unsigned>(wv);                            // wave-uniform
@@ -553,13 +555,25 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
         if (NP > 6) stage(6, pc6);
     }
     if (__ballot(stale)) {
-        // Rare (a query crossed a voxel face since its row was built, a few % of the queries per
-        // iteration at the start of a cold registration, almost none near convergence): the lanes
-        // of a stale query share its 27 voxels, up to three probes in flight per lane, and write
-        // the row to LDS and back to the cache.
+        // A query crossed a voxel face since its row was built (a few % of the queries per iteration
+        // at the start of a cold registration, almost none near convergence; every query in the first
+        // pass of k_loop): its lanes rebuild the row in LDS (and in the cache).  With eight or more
+        // lanes per query (k_loop: four) a step into a NEIGHBOURING voxel keeps what the two neighbourhoods share —
+        // 18 of the 27 voxels after a step through a face, 12 through an edge, 8 through a corner: the
+        // words move inside the row, only the new layer is probed (one batch of loads instead of two or
+        // three), and the previous answer, if it lies in the shared part, stays the seed under its new
+        // enumeration key.  Otherwise all 27 voxels are probed, up to three / four in flight per lane.
         if (stale) {
             unsigned o = 0u, cq = 0u;
             constexpr int NV = (27 + W - 1) / W;          // voxels per lane
+            constexpr bool kShift = NV <= (PERSIST ? 7 : 4);     // (k_icp with four lanes per query sits on its register edge)
+            auto tally = [&](int v, uint32_t w) {
+                const unsigned c = (w == kEmptySlot) ? 0u : (w & 255u);
+                lrow[v] = w;
+                if constexpr (!PERSIST) P.rows[static_cast<size_t>(q) * kRowWords + static_cast<unsigned>(v)] = w;
+                o |= (c != 0u ? 1u : 0u) << v;
+                cq += c;
+            };
             // one probe: first slot load issued by `start`, resolved (and the row word stored) by `finish`
             auto start = [&](int v, uint32_t &sl, int4 &e) {
                 const int vc = v < 27 ? v : 26;
@@ -568,26 +582,69 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
             };
             auto finish = [&](int v, uint32_t sl, const int4 &e) {
                 if (v >= 27) return;
-                const uint32_t w = probe_resolve(P.table, P.mask, sl, e, s.kx + v / 9 - 1, s.ky + (v / 3) % 3 - 1,
-                                                 s.kz + v % 3 - 1);
-                const unsigned c = (w == kEmptySlot) ? 0u : (w & 255u);
-                lrow[v] = w;
-                if constexpr (!PERSIST) P.rows[static_cast<size_t>(q) * kRowWords + static_cast<unsigned>(v)] = w;
-                o |= (c != 0u ? 1u : 0u) << v;
-                cq += c;
+                tally(v, probe_resolve(P.table, P.mask, sl, e, s.kx + v / 9 - 1, s.ky + (v / 3) % 3 - 1,
+                                       s.kz + v % 3 - 1));
             };
+            if constexpr (kShift) {
+                const int dx = s.kx - static_cast<int>(rk.x), dy = s.ky - static_cast<int>(rk.y),
+                          dz = s.kz - static_cast<int>(rk.z);
+                const bool nearv = static_cast<unsigned>(dx + 1) <= 2u && static_cast<unsigned>(dy + 1) <= 2u &&
+                                   static_cast<unsigned>(dz + 1) <= 2u;
+                // the old words of this lane's voxels (LDS is in order within a wave: every read here
+                // precedes the writes below, also those of the query's other lanes)
+                uint32_t ow[NV];
+                bool reuse[NV];
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    const int v = static_cast<int>(ci) + W * j;
+                    const int a = v / 9 + dx, b = (v / 3) % 3 + dy, c = v % 3 + dz;
+                    reuse[j] = nearv && v < 27 && static_cast<unsigned>(a) <= 2u && static_cast<unsigned>(b) <= 2u &&
+                               static_cast<unsigned>(c) <= 2u;
+                    ow[j] = lrow[reuse[j] ? a * 9 + b * 3 + c : 0];
+                }
+                uint32_t sl[NV];
+                int4 e[NV];
+                constexpr int NB = PERSIST ? 4 : 3;       // probes in flight per lane (k_icp: its register budget)
+#pragma unroll
+                for (int j0 = 0; j0 < NV; j0 += NB) {
+#pragma unroll
+                    for (int j = j0; j < j0 + NB && j < NV; ++j) {
+                        sl[j] = 0u;
+                        e[j] = make_int4(0, 0, 0, 0);
+                        if (!reuse[j]) start(static_cast<int>(ci) + W * j, sl[j], e[j]);
+                    }
+#pragma unroll
+                    for (int j = j0; j < j0 + NB && j < NV; ++j) {
+                        const int v = static_cast<int>(ci) + W * j;
+                        if (reuse[j]) tally(v, ow[j]);
+                        else finish(v, sl[j], e[j]);
+                    }
+                }
+                // the previous answer under the new enumeration, if its voxel is still one of the 27
+                if (nearv && prev.x != 0xFFFFFFFFu) {
+                    const int vo = static_cast<int>(prev.x >> 8);
+                    const int a = vo / 9 - dx, b = (vo / 3) % 3 - dy, c = vo % 3 - dz;
+                    const bool in = static_cast<unsigned>(a) <= 2u && static_cast<unsigned>(b) <= 2u &&
+                                    static_cast<unsigned>(c) <= 2u;
+                    prev.x = in ? (static_cast<unsigned>(a * 9 + b * 3 + c) << 8) | (prev.x & 255u) : 0xFFFFFFFFu;
+                } else {
+                    prev.x = 0xFFFFFFFFu;
+                }
+            } else {
+                prev.x = 0xFFFFFFFFu;          // (the key's meaning went with the old row)
 #pragma unroll 1
-            for (int k0 = 0; k0 < NV; k0 += 3) {
-                const int v0 = static_cast<int>(ci) + W * k0;
-                const int v1 = k0 + 1 < NV ? v0 + W : 27, v2 = k0 + 2 < NV ? v0 + 2 * W : 27;
-                uint32_t s0, s1, s2;
-                int4 e0, e1, e2;
-                start(v0, s0, e0);
-                start(v1, s1, e1);
-                start(v2, s2, e2);
-                finish(v0, s0, e0);
-                finish(v1, s1, e1);
-                finish(v2, s2, e2);
+                for (int k0 = 0; k0 < NV; k0 += 3) {
+                    const int v0 = static_cast<int>(ci) + W * k0;
+                    const int v1 = k0 + 1 < NV ? v0 + W : 27, v2 = k0 + 2 < NV ? v0 + 2 * W : 27;
+                    uint32_t s0, s1, s2;
+                    int4 e0, e1, e2;
+                    start(v0, s0, e0);
+                    start(v1, s1, e1);
+                    start(v2, s2, e2);
+                    finish(v0, s0, e0);
+                    finish(v1, s1, e1);
+                    finish(v2, s2, e2);
+                }
             }
             o = seg_or_u32<W>(o);              // the lanes of a query are stale together
             cq = seg_add_u32<W>(cq);
@@ -865,14 +922,14 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
         // first iterations the seed IS the answer for most queries and the bound is the final
         // one).  Only queries without a seed (the first pass of a call, a rebuilt row) scan their
         // home voxel first; a wave without such a query skips that pass altogether.
-        const bool seeded = valid && !stale && prev.x != 0xFFFFFFFFu;
+        const bool seeded = valid && prev.x != 0xFFFFFFFFu;          // (a rebuilt row re-keyed or dropped it)
         const Point4 pp = LL->pp;
         evaluate(pp, seeded, prev.x);
         merged = seeded;
         const unsigned first = seeded ? 0u : (occ & (1u << kHome));
         if (__ballot(first != 0u)) scan(first, nullptr, false, 0u);
     } else if (FUSED) {
-        const bool seeded = valid && !stale && prev.x != 0xFFFFFFFFu;
+        const bool seeded = valid && prev.x != 0xFFFFFFFFu;          // (a rebuilt row re-keyed or dropped it)
         const Point4 pp = load_point(pts, seeded ? prev.y : 0u);      // the full record
         scan(occ & (1u << kHome), &pp, seeded, prev.x);
     } else {
@@ -961,10 +1018,10 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
         Point4 g;
         if constexpr (PERSIST) {
             // The answer of most queries is the previous iteration's (and then so is its record: the
-            // map is constant during a call, and an unchanged row gives a key the same meaning): only
-            // a query whose answer changed — or whose row was rebuilt — fetches a record, on all of
-            // its lanes (one request: the same address), since every lane evaluates the seed.
-            const bool changed = found && (stale || mkey != prev.x);
+            // map is constant during a call, and the key was carried over if the row was rebuilt):
+            // only a query whose answer changed fetches a record, on all of its lanes (one request:
+            // the same address), since every lane evaluates the seed.
+            const bool changed = found && mkey != prev.x;
             g = LL->pp;
             if (__ballot(changed)) {
                 const Point4 t = load_point(pts, changed ? woff : 0u);
@@ -1665,7 +1722,7 @@ void k_loop(IcpParams P, LoopParams L) {
     LoopLane LL;
     {
         const unsigned xcd = blockIdx.x & 7u, jb = blockIdx.x >> 3;
-        const unsigned wg = xcd * ((gridDim.x - 1u) >> 3) + jb;        // as icp_body<PERSIST>
+        const unsigned wg = ((jb / kLoopStripe) * 8u + xcd) * kLoopStripe + (jb % kLoopStripe);   // as icp_body<PERSIST>
         const unsigned q = (wg * static_cast<unsigned>(nw) + static_cast<unsigned>(wv)) * QW +
                            static_cast<unsigned>(lane >> LW);
         LL.f = P.frame[q < static_cast<unsigned>(P.n) ? q : 0u];
