@@ -15,10 +15,16 @@ already resident in HBM when the timed region starts.
           not started under a launcher.
 
 Prints ONE JSON line on rank 0 (see the task contract), including
-  roofline      the search + accumulation kernel (k_icp): algorithmic bytes (SURVEY.md §8d fused
-                form: 456 B/query + 16 B/candidate + 32 B/correspondence - 8 B/query, candidates
-                counted exactly by the kernel) / HIP-event launch duration, plus what actually
-                bounds it: hbm_frac (counter bytes), valu_frac, useful_inst_frac (profiles/)
+  roofline      the search + accumulation kernel (k_icp).  `achieved` / `frac` are what rocprofv3 shows
+                for it — FETCH_SIZE x 2 per launch / kernel-trace duration / 8 TB/s (`frac_basis` says
+                so) — whenever profiles/icp_counters.json holds counters taken on exactly the device
+                code that runs; `traffic_floor_us` (that traffic at the achievable 6.3 TB/s) and
+                `x_over_traffic_floor` put the kernel's distance from its own traffic in one number.
+                Beside them, named for what they are: `executed_bytes_frac` (SURVEY.md 8d's compact
+                records for the pairs the kernel actually evaluates / HIP-event duration: mostly cache
+                traffic, not an HBM fraction) and `effective_gather_gbs` (8d's contractual figure with
+                every candidate of the 27 voxels charged: what the reference scans).  Without fresh
+                counters `frac` falls back to the executed-bytes figure and `frac_basis` says that.
   cpu_baseline  the CPU oracle (a structure-faithful port of the reference path, OpenMP) timed on a
                 bounded sample of the same frame: warm-up, thread sweep, median of 5 at the fastest
                 count, and the 1-thread time; rank 0 at N = 1 only.
@@ -36,6 +42,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6300.0   # same guide: what a streaming kernel reaches
 
 
 def parse():
@@ -404,6 +411,27 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # Where an iteration of the sharded loop goes (not in the timed region: bracketing every kernel
+    # costs stream time): one more frame on every rank with HIP events around each launch — the
+    # search of this rank's shard, and the finish (reduction, exchange with the peers, solve).
+    breakdown = None
+    if use_dist and not args.independent:
+        sage.set_profiling(2)
+        try:
+            fence()
+            _, sb = step()
+            fence()
+            if sb.nn_launches:
+                breakdown = {"shard_compute_us_per_iteration": round(sb.us_nn / sb.nn_launches, 2),
+                             "exchange_us_per_iteration": round(sb.us_fin / sb.nn_launches, 2),
+                             "note": "rank 0, one frame after the timed region, HIP events around every launch: "
+                                     "k_icp on this rank's shard | k_fin incl. the wait for the peers' sums (direct "
+                                     "exchange) or k_fin + ncclAllReduce + k_fin (RCCL); on one GPU k_fin takes ~6 us"}
+        except sage.SageIcpError as e:
+            sys.stderr.write("rank %d: breakdown frame failed: %s\n" % (rank, e))
+        finally:
+            sage.set_profiling(0)
+
     if rank != 0:
         if use_dist:
             dist.barrier()
@@ -446,7 +474,12 @@ def main():
         compulsory = 16 * (vmap.size() + n_local + 4 * vmap.num_voxels())
         roofline = {"bound": "hbm", "kernel": "k_icp (correspondence search + Gauss-Newton sums)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "frac_basis": "executed-bytes model / HIP-event duration (NO fresh rocprofv3 counters for this "
+                                  "build: mostly cache traffic, not an HBM fraction)",
+                    "traffic": None,
+                    "executed_bytes_gbs": round(achieved, 1),
+                    "executed_bytes_frac": round(achieved / HBM_PEAK_GBS, 4),
                     "algorithmic_bytes_per_launch": round(executed_bytes),
                     "algorithmic_bytes_model": "448 B x queries + 16 B x (query, map point) pairs evaluated "
                                                "(counted by the kernel) + 32 B x correspondences",
@@ -467,6 +500,8 @@ def main():
                     "lanes_per_query": last.lanes_per_query,
                     "scan_form": "compact 16-B records behind an exact fp32 filter" if last.compact_scan
                                  else "full 32-B fp64 records",
+                    "loop_form": "one launch for the whole loop (k_loop): avg_launch_us is the launch / iterations"
+                                 if last.single_launch else "k_icp + k_fin per iteration",
                     "candidates_per_query": round(cand_per_launch / max(n_local, 1), 1),
                     "pairs_evaluated_frac": round(pairs / max(cands, 1), 4),
                     "timing": "mean k_icp duration from HIP events on the launch stream around 1 launch in 8 "
@@ -486,8 +521,17 @@ def main():
                     roofline["counters"] = c.get("counters_source")
                     roofline["traffic"] = c.get("hbm_bytes_per_launch")
                     if roofline["traffic"]:
-                        # both from the profiled runs (bytes and duration of the same launches)
+                        # both from the profiled runs (bytes and duration of the same launches):
+                        # THE roofline figure — what rocprofv3 shows, north_star's wording
+                        kt_us = c.get("avg_launch_us_kernel_trace") or avg_us
                         roofline["hbm_frac"] = c.get("hbm_frac")
+                        roofline["achieved"] = round(roofline["traffic"] / (kt_us * 1e-6) / 1e9, 1)
+                        roofline["frac"] = round(roofline["achieved"] / HBM_PEAK_GBS, 4)
+                        roofline["frac_basis"] = ("rocprofv3 FETCH_SIZE x 2 per executed launch / kernel-trace mean "
+                                                  "duration / 8 TB/s (" + str(c.get("counters_source", "")).split(" (")[0] + ")")
+                        floor_us = roofline["traffic"] / (HBM_ACHIEVABLE_GBS * 1e9) * 1e6
+                        roofline["traffic_floor_us"] = round(floor_us, 2)
+                        roofline["x_over_traffic_floor"] = round(kt_us / floor_us, 2)
                         roofline["traffic_over_algorithmic"] = round(roofline["traffic"] / executed_bytes, 3)
                     for key in ("avg_launch_us_kernel_trace", "valu_frac", "useful_inst_frac",
                                 "lane_utilization", "l2_hit_rate"):
@@ -543,6 +587,7 @@ def main():
                    "rccl_ranks": None if comm is None else comm.describe()["rccl_ranks"],
                    "comm": None if comm is None else comm.describe(),
                    "exchange_cross_check": cross_check,
+                   "iteration_breakdown": breakdown,
                    "scan_points": len(scan), "map_points": vmap.size(),
                    "map_voxels": vmap.num_voxels(), "iterations_per_frame": iters,
                    "correspondences_first_last": [last.n_corr_first, last.n_corr_last],

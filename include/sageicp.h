@@ -17,6 +17,15 @@
  *            ros/ros2/OdometryServer.cpp:356).  Different handles may be used concurrently.
  *   device   the HIP path is the only path: without a gfx950 device every compute entry
  *            returns SAGEICP_ERR_NO_DEVICE.  There is no CPU fallback in this library.
+ *   NaN/Inf  the reference turns coordinates into voxel indices and labels into classes with
+ *            static_cast<int> (VoxelHashMap.cpp:52-54,87-88,165; Preprocessing.cpp:58-64): undefined
+ *            for values that are not finite, so there is no behaviour to reproduce.  Every entry that
+ *            would cast one — AddPoints / Update (host and device), GetCorrespondences, RegisterFrame
+ *            (host buffer or resident frame), VoxelDownsample, the pipeline — refuses the WHOLE call
+ *            with SAGEICP_ERR_INVALID and changes nothing.  Where the reference IS defined it is
+ *            followed: Preprocess() drops a point whose norm is not finite (both range tests fail,
+ *            Preprocessing.cpp:176-177) — so the pipeline drops such points like the reference and only
+ *            refuses non-finite LABELS —, TransformPoints and AlignClouds propagate NaN.
  */
 #ifndef SAGEICP_H_
 #define SAGEICP_H_
@@ -281,9 +290,14 @@ int sageicp_pipeline_register_frame(sageicp_pipeline *p, const double *frame_xyz
  * sageicp_pipeline_register_frame() call on; it has finished when the register call after that one,
  * sageicp_pipeline_prefetch_cancel() or sageicp_pipeline_destroy() returns — until then the buffer
  * must stay valid and unchanged, also when the announced frame ends up not being registered.
- * A frame is recognised by pointer, size AND a fingerprint of its content taken here: a buffer
- * refilled with other data after the announcement is registered as the new frame it is. */
+ * A frame is recognised by pointer, size AND a fingerprint of its content taken here (64 rows spread
+ * over the frame and the last one: best effort — it tells a buffer refilled with another scan from
+ * the scan that was announced, not a buffer edited in a few places; do not edit announced buffers). */
 int sageicp_pipeline_prefetch(sageicp_pipeline *p, const double *next_frame_xyzl, uint64_t n);
+/* Wait for the helper thread without dropping what it prepared: afterwards nothing reads the
+ * announced buffer any more (it may be released or refilled), and the prepared clouds are still
+ * used if the announced frame — same pointer, size and content — is registered next. */
+int sageicp_pipeline_prefetch_wait(sageicp_pipeline *p);
 /* Drop an announcement / a prepared frame and wait for the helper thread: afterwards nothing
  * reads any announced buffer. */
 int sageicp_pipeline_prefetch_cancel(sageicp_pipeline *p);

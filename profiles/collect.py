@@ -84,6 +84,8 @@ entry = {
     "hbm_bytes_per_launch": hbm_bytes,
     "hbm_frac": round(hbm_bytes / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if hbm_bytes else None,
     "hbm_frac_definition": "FETCH_SIZE x 2 / kernel-trace duration of the executed launches / %.0f GB/s" % HBM_PEAK_GBS,
+    "traffic_floor_us": round(hbm_bytes / 6.3e12 * 1e6, 2) if hbm_bytes else None,
+    "x_over_traffic_floor": round(avg_us / (hbm_bytes / 6.3e12 * 1e6), 2) if hbm_bytes else None,
     "hbm_correction": "x2: on gfx950 FETCH_SIZE reports half the bytes of 16-B/lane reads (MI355X_MICROARCH.md, HBM); "
                       "Infinity-Cache hits are counted in it, so DRAM traffic is lower still",
     "valu_insts_per_launch": valu,

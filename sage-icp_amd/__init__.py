@@ -179,6 +179,7 @@ _SIGNATURES = [
      [C.c_void_p, _dp, C.c_uint64, _dp, _dp, _dp, _u64p, C.POINTER(Stats)]),
     ("sageicp_pipeline_prefetch", C.c_int, [C.c_void_p, _dp, C.c_uint64]),
     ("sageicp_pipeline_prefetch_cancel", C.c_int, [C.c_void_p]),
+    ("sageicp_pipeline_prefetch_wait", C.c_int, [C.c_void_p]),
     ("sageicp_pipeline_reinitialize", C.c_int, [C.c_void_p]),
     ("sageicp_pipeline_num_poses", C.c_uint64, [C.c_void_p]),
     ("sageicp_pipeline_pose", C.c_int, [C.c_void_p, C.c_uint64, _dp]),
@@ -495,6 +496,10 @@ class SageICP:
         self._announced = (getattr(self, "_announced", ()) + ((pts, pp),))[-2:]
         _check(lib().sageicp_pipeline_prefetch(self._h, pp, pts.reshape(-1, 4).shape[0]))
         return pts
+
+    def prefetch_wait(self):
+        """wait for the helper thread; what it prepared is kept"""
+        _check(lib().sageicp_pipeline_prefetch_wait(self._h))
 
     def prefetch_cancel(self):
         """drop an announced / prepared frame and wait for the helper thread"""

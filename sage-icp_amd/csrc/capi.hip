@@ -581,6 +581,7 @@ struct Prep {
         }
         int ovf = 0;
         HIPCHK(hipMemcpy(&ovf, d_overflow, sizeof(int), hipMemcpyDeviceToHost));
+        if (ovf & 2) return fail(SAGEICP_ERR_INVALID, "a label (or, without the range crop, a coordinate) is not finite (NaN / Inf)");
         if (ovf) return fail(SAGEICP_ERR_CAPACITY, "voxel index beyond +-2^19 in VoxelDownsample");
         return SAGEICP_OK;
     }
@@ -1186,8 +1187,12 @@ int device_update(sageicp_map *m, const double *xyzl, uint64_t n, const double p
     HIPCHK(map_update_device(dm, pol, us, static_cast<int>(n), pose, bound, s));
     HIPCHK(hipMemcpyAsync(m->h_ctr, m->d_ctr, sizeof(MapCounters), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (m->h_ctr->overflow) {
+    if (m->h_ctr->overflow & 2u) {
         // nothing was inserted or evicted (every kernel checks the flag first)
+        return fail(SAGEICP_ERR_INVALID, "Update: a coordinate or label is not finite (NaN / Inf); the map is unchanged");
+    }
+    if (m->h_ctr->overflow) {
+        // nothing was inserted or evicted either
         return fail(SAGEICP_ERR_CAPACITY, "voxel index beyond +-2^20 in the device map update");
     }
     if (m->h_ctr->unit_overflow) {
@@ -1213,6 +1218,21 @@ int device_update(sageicp_map *m, const double *xyzl, uint64_t n, const double p
     const_cast<HostMap &>(h).clear_dirty();
     m->mirror_stale_all = false;
     return SAGEICP_OK;
+}
+
+// Non-finite input (NaN / Inf coordinates or labels).  The reference turns such values into voxel
+// indices and label classes with static_cast<int> — undefined behaviour (INT_MIN on x86, 0 or a
+// saturated value on gfx950) — so there is nothing to be faithful to: every entry that would cast one
+// refuses the whole call with SAGEICP_ERR_INVALID before anything is changed (host buffers are checked
+// here, device-resident frames by the first kernel that reads them: sort.hip, map_update.hip,
+// preprocess.hip).  Where the reference's behaviour IS defined it is kept: Preprocess() drops a point
+// whose norm is not finite (both range comparisons fail, Preprocessing.cpp:176-177), TransformPoints
+// and AlignClouds propagate.
+static bool all_finite(const double *xyzl, uint64_t n) {
+    // (x - x is 0 for every finite x and NaN otherwise: four of them summed stay 0 exactly)
+    double acc = 0.0;
+    for (uint64_t i = 0; i < 4 * n; ++i) acc += xyzl[i] - xyzl[i];
+    return acc == 0.0;
 }
 
 void identity_pose(double T[7]) {
@@ -1415,7 +1435,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     // lane per query that no longer pays for its ~90 us: 45.3 against 47.2 us per iteration on the
     // c2 cold start, profiles/README.md.)
     if (n > 0)
-        HIPCHK(sort_frame(d_frame, sc.d_sorted, static_cast<int>(n), sc.d_state, true,
+        HIPCHK(sort_frame(d_frame, sc.d_sorted, static_cast<int>(n), sc.d_state, true, comm == nullptr,
                           m->host.voxel_size, sc.d_keys, sc.d_vals, sc.d_sort_temp,
                           sc.sort_temp_bytes_, s));
 
@@ -1446,7 +1466,9 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(sc.h_state, sc.d_state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        if (sc.h_state->loop_aborted || !sc.h_state->done) {
+        if (sc.h_state->bad_input) {
+            looped = true;                     // (reported below)
+        } else if (sc.h_state->loop_aborted || !sc.h_state->done) {
             // a wait inside the launch timed out (the grid was not resident as a whole: another stream
             // or process held CUs): the launch-per-iteration loop below registers the frame instead
             fill_state(sc.h_state, init);
@@ -1494,10 +1516,11 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         fp.p2p.rank = comm->rank;
         for (int r = 0; r < comm->nranks; ++r) fp.p2p.block[r] = comm->blocks[r];
         fp.p2p.exchanges = comm->d_exchanges;
-        // a peer's sums normally arrive within microseconds; one second of in-kernel waiting is
-        // already a failure (SAGEICP_P2P_TIMEOUT_S overrides, e.g. under a debugger)
+        // a peer's sums normally arrive within microseconds, but its FIRST launches of a process (code
+        // object loading) or a GPU shared with other work can take a second: five seconds of in-kernel
+        // waiting is a failure (SAGEICP_P2P_TIMEOUT_S overrides, e.g. under a debugger)
         fp.p2p.timeout_ticks = 100000000ull * static_cast<unsigned long long>(
-                                   std::max(1, env_int("SAGEICP_P2P_TIMEOUT_S", 1)));
+                                   std::max(1, env_int("SAGEICP_P2P_TIMEOUT_S", 5)));
         if (const int ticks = env_int("SAGEICP_P2P_TIMEOUT_TICKS", 0))      // tests: provoke a timeout
             fp.p2p.timeout_ticks = static_cast<unsigned long long>(ticks);
     }
@@ -1591,9 +1614,11 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         }
     }
     const IcpState &st = *sc.h_state;
+    if (st.bad_input)
+        return fail(SAGEICP_ERR_INVALID, "the frame holds a coordinate or label that is not finite (NaN / Inf)");
     if (st.acc_overflow)
         return fail(SAGEICP_ERR_CAPACITY, "a Gauss-Newton sum left the range of the fixed-point accumulators "
-                                          "(coordinates beyond ~10^6 m?)");
+                                          "(|sum over a wave| >= 2^50: coordinates beyond ~10^6 m, or a pose guess that is not finite)");
     if (st.exchange_failed) {
         // the ranks' exchange counters may now differ by one: a later exchange could pass its wait
         // on a stale tag and add rows of another iteration.  The blocks are dead until every rank
@@ -2024,6 +2049,8 @@ int sageicp_map_add_points(sageicp_map *m, const double *xyzl, uint64_t n) {
     if (!m || (n && !xyzl)) return fail(SAGEICP_ERR_INVALID, "null argument");
     if (m->replicas_diverged)
         return fail(SAGEICP_ERR_INVALID, "the copies of this multi-device map diverged in an earlier failed update: Clear() it");
+    if (!all_finite(xyzl, n))
+        return fail(SAGEICP_ERR_INVALID, "AddPoints: a coordinate or label is not finite (NaN / Inf); nothing was inserted");
     if (int rc = ensure_host(m)) return rc;
     uint64_t at = 0;
     const int why = m->host.add_points(xyzl, n, &at);     // limits are checked before a point is taken
@@ -2179,6 +2206,8 @@ int sageicp_get_correspondences(const sageicp_map *m, const double *q, uint64_t 
         return fail(SAGEICP_ERR_INVALID, "null argument");
     if (n > kMaxQueries) return fail(SAGEICP_ERR_INVALID, "too many queries (2^26 max)");
     *n_out = 0;
+    if (!all_finite(q, n))
+        return fail(SAGEICP_ERR_INVALID, "GetCorrespondences: a coordinate or label of a query is not finite (NaN / Inf)");
     int rc = ensure_host(m);      // the returned target points are read from the host copy
     if (rc) return rc;
     if ((rc = sync_mirror(m))) return rc;
@@ -2195,7 +2224,7 @@ int sageicp_get_correspondences(const sageicp_map *m, const double *q, uint64_t 
     HIPCHK(hipMemcpyAsync(sc.d_state, sc.h_state, sizeof(IcpState), hipMemcpyHostToDevice, s));
     // same pipeline as the ICP loop, pose = identity: sort, rows, search; results are mapped
     // back to the caller's query order through the sort permutation
-    HIPCHK(sort_frame(sc.d_frame, sc.d_sorted, static_cast<int>(n), sc.d_state, false,
+    HIPCHK(sort_frame(sc.d_frame, sc.d_sorted, static_cast<int>(n), sc.d_state, false, false,
                       m->host.voxel_size, sc.d_keys, sc.d_vals, sc.d_sort_temp, sc.sort_temp_bytes_,
                       s));
     const int lw = icp_lw(n, sparse_voxels(m));
@@ -2700,6 +2729,11 @@ int sageicp_pipeline_prefetch(sageicp_pipeline *p, const double *frame, uint64_t
     p->an_frame = frame;
     p->an_n = n;
     p->an_print = sageicp_pipeline::fingerprint(frame, n);
+    return SAGEICP_OK;
+}
+int sageicp_pipeline_prefetch_wait(sageicp_pipeline *p) {
+    if (!p) return fail(SAGEICP_ERR_INVALID, "null pipeline");
+    if (p->worker.joinable()) p->worker.join();     // what it prepared stays (`ready`)
     return SAGEICP_OK;
 }
 int sageicp_pipeline_prefetch_cancel(sageicp_pipeline *p) {

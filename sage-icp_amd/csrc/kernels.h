@@ -205,7 +205,11 @@ hipError_t voxel_downsample_device(const VdsParams &P, void *sort_temp, size_t s
 
 // sort.hip: re-ordering of a frame along the Morton curve of its map-frame voxels
 size_t sort_temp_bytes(int n);
-hipError_t sort_frame(const Point4 *d_in, Point4 *d_out, int n, const IcpState *st, bool apply_pose,
+// A frame point with a coordinate or label that is not finite raises st->bad_input (the reference
+// casts such values to int: undefined behaviour); with `stop_on_bad` it also ends the loop before its
+// first iteration (st->done, the progress word) — not under a communicator, where every rank has to
+// enqueue the same collectives.
+hipError_t sort_frame(const Point4 *d_in, Point4 *d_out, int n, IcpState *st, bool apply_pose, bool stop_on_bad,
                       double voxel_size, uint32_t *keys, uint32_t *vals, void *temp,
                       size_t temp_bytes, hipStream_t s);
 

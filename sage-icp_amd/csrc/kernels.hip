@@ -1697,6 +1697,7 @@ void k_loop(IcpParams P, LoopParams L) {
     LoopShared *sh = L.sh;
     double *s_pose = reinterpret_cast<double *>(smem + kLpPose);
 
+    if (P.st->bad_input) return;               // (sort.hip found a non-finite point: the host reports it)
     // ---- the solving workgroup: the last one of the grid, one wave, no queries --------------------------
     // (its own path through the kernel: the solve needs ~120 registers, the search ~95 with the state
     // it keeps, and neither is live in the other)

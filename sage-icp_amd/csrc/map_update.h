@@ -25,7 +25,7 @@ struct MapCounters {
     uint64_t total_points;
     uint32_t n_new;          // voxels created by the last update
     uint32_t n_far;          // voxels evicted by the last update
-    uint32_t overflow;       // a voxel index beyond +-2^20 was seen (update rejected)
+    uint32_t overflow;       // bit 0: a voxel index beyond +-2^20 was seen, bit 1: a non-finite coordinate or label (update rejected)
     uint32_t unit_overflow;  // the pass asks for more units than the point array holds (update rejected before a write)
     // size-classed regions (host_map.hpp): the unit allocator's state
     uint32_t units_hi;       // high-water mark

@@ -65,7 +65,12 @@ __global__ __launch_bounds__(256) void k_up_keys(const Point4 *raw, int n, Pose3
     const int vy = static_cast<int>(o.y / voxel_size);
     const int vz = static_cast<int>(o.z / voxel_size);
     const int lim = kKeyBias - 1;
-    if (vx < -lim || vx > lim || vy < -lim || vy > lim || vz < -lim || vz > lim) ctr->overflow = 1u;
+    // bit 1: a coordinate or label that is not finite (refused: the reference casts it to int, undefined
+    // behaviour); bit 0: a voxel index beyond the key's range.  Either rejects the whole update.
+    if (!(fabs(o.x) <= 1.7976931348623157e308 && fabs(o.y) <= 1.7976931348623157e308 &&
+          fabs(o.z) <= 1.7976931348623157e308 && fabs(o.l) <= 1.7976931348623157e308))
+        atomicOr(&ctr->overflow, 2u);
+    else if (vx < -lim || vx > lim || vy < -lim || vy > lim || vz < -lim || vz > lim) atomicOr(&ctr->overflow, 1u);
     keys[i] = pack_key(vx, vy, vz);
     idx[i] = static_cast<uint32_t>(i);
     flag[i] = UpdateEvents{};

@@ -43,6 +43,14 @@ __global__ __launch_bounds__(256) void k_vds_insert(VdsParams P) {
         valid = norm < P.max_range && norm > P.min_range;
         if (norm > P.label_max_range) p.l = 0.0;
     }
+    // (a point the crop keeps has finite coordinates; its label, and without the crop its coordinates,
+    // still have to be: the reference casts them to int next — undefined for NaN / Inf — so such a frame
+    // is refused as a whole, flag bit 1)
+    if (valid && !(fabs(p.x) <= 1.7976931348623157e308 && fabs(p.y) <= 1.7976931348623157e308 &&
+                   fabs(p.z) <= 1.7976931348623157e308 && fabs(p.l) <= 1.7976931348623157e308)) {
+        atomicOr(P.overflow, 2);
+        valid = false;
+    }
     int group = -1;
     if (valid && P.n_groups >= 0) {
         const int label = static_cast<int>(p.l);
@@ -61,7 +69,7 @@ __global__ __launch_bounds__(256) void k_vds_insert(VdsParams P) {
                         vz = static_cast<int>(p.z / vs);
         const long long B = 1ll << 19;
         if (vx < -B || vx >= B || vy < -B || vy >= B || vz < -B || vz >= B) {
-            *P.overflow = 1;       // voxel index does not fit the 20-bit key fields
+            atomicOr(P.overflow, 1);       // voxel index does not fit the 20-bit key fields
             valid = false;
         } else {
             const unsigned long long key = (static_cast<unsigned long long>(group) << 60) |

@@ -161,7 +161,7 @@ struct IcpState {
     int32_t exchange_failed;        // a peer's sums did not arrive in time (multi-GPU direct exchange)
     int32_t acc_overflow;           // a workgroup's sum did not fit the fixed-point accumulators (|value| >= 2^50)
     int32_t loop_aborted;           // k_loop: a wait inside the launch timed out (the host falls back to the launch-per-iteration loop)
-    int32_t pad1_;
+    int32_t bad_input;              // a coordinate or label of the frame is not finite (sort.hip): the call fails with SAGEICP_ERR_INVALID
 };
 
 // Index into the 16 closed-form sums of AlignClouds (Registration.cpp:59-94):

@@ -29,12 +29,23 @@ __device__ __forceinline__ uint32_t spread10(uint32_t v) {
 }
 
 template <bool APPLY_POSE>
-__global__ __launch_bounds__(256) void k_morton_keys(const Point4 *pts, int n, const IcpState *st,
+__global__ __launch_bounds__(256) void k_morton_keys(const Point4 *pts, int n, IcpState *st, int stop_on_bad,
                                                      double voxel_size, uint32_t *keys,
                                                      uint32_t *vals) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const Point4 f = pts[i];
+    // the one pass every frame goes through before it is searched: non-finite input is refused here
+    // (fabs(v) <= DBL_MAX is false for NaN and for the infinities)
+    if (!(fabs(f.x) <= 1.7976931348623157e308 && fabs(f.y) <= 1.7976931348623157e308 &&
+          fabs(f.z) <= 1.7976931348623157e308 && fabs(f.l) <= 1.7976931348623157e308)) {
+        st->bad_input = 1;
+        if (stop_on_bad) {
+            st->done = 1;
+            if (IcpProgress *pg = st->progress)
+                __hip_atomic_store(&pg->word, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     double x = f.x, y = f.y, z = f.z;
     if (APPLY_POSE) {
         const double *R = st->R;
@@ -68,16 +79,16 @@ size_t sort_temp_bytes(int n) {
 }
 
 // keys/vals: 2*n uint32 each (in | out halves).  perm_out = vals + n afterwards.
-hipError_t sort_frame(const Point4 *d_in, Point4 *d_out, int n, const IcpState *st, bool apply_pose,
+hipError_t sort_frame(const Point4 *d_in, Point4 *d_out, int n, IcpState *st, bool apply_pose, bool stop_on_bad,
                       double voxel_size, uint32_t *keys, uint32_t *vals, void *temp,
                       size_t temp_bytes, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     const int grid = (n + 255) / 256;
     if (apply_pose)
-        hipLaunchKernelGGL(k_morton_keys<true>, dim3(grid), dim3(256), 0, s, d_in, n, st, voxel_size,
-                           keys, vals);
+        hipLaunchKernelGGL(k_morton_keys<true>, dim3(grid), dim3(256), 0, s, d_in, n, st, stop_on_bad ? 1 : 0,
+                           voxel_size, keys, vals);
     else
-        hipLaunchKernelGGL(k_morton_keys<false>, dim3(grid), dim3(256), 0, s, d_in, n, st,
+        hipLaunchKernelGGL(k_morton_keys<false>, dim3(grid), dim3(256), 0, s, d_in, n, st, stop_on_bad ? 1 : 0,
                            voxel_size, keys, vals);
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys + n, vals,
                                                       vals + n, n, 0, 30, s);

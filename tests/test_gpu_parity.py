@@ -618,11 +618,16 @@ def test_rccl_refuses_two_ranks_on_one_device():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SAGEICP_BENCH_DEVICE="0", SAGEICP_NO_P2P="1", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, SAGEICP_BENCH_DEVICE="0", SAGEICP_NO_P2P="1", MASTER_ADDR="127.0.0.1", NCCL_DEBUG="WARN")
     run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1",
                           "--warmup", "0", "--scale", "0.05", "--no-cpu-baseline"],
                          capture_output=True, text=True, env=env, timeout=300)
     assert run.returncode != 0      # bench.py --gpus 2 launched its own ranks; RCCL refused the pair
+    # ... and it failed for THAT reason, where the communicator is created — not an import error, a
+    # typo or an out-of-memory somewhere else
+    text = (run.stdout + run.stderr).lower()
+    assert "ncclcomminitrank" in text or "sageicp_comm_create" in text, text[-3000:]
+    assert "duplicate gpu" in text or "invalid usage" in text or "invalid argument" in text, text[-3000:]
 
 
 def test_register_frame_through_rccl_comm_world1(gpu_sage, oracle):
@@ -728,18 +733,21 @@ def test_single_process_multi_device_mode(gpu_sage, oracle):
         assert dt < 1e-9 and dr < 1e-9
 
 
-def test_direct_exchange_between_two_processes(gpu_sage, tmp_path):
+@pytest.mark.parametrize("chunked", [0, 1])
+def test_direct_exchange_between_two_processes(gpu_sage, tmp_path, chunked):
     """bench.py with two ranks on the one GPU of the box (gloo rendezvous, no RCCL): each rank
     registers half of the frame and the sums travel through the HIP-IPC mapped blocks"""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # chunked: the loop form every RCCL run uses (fixed chunks of iterations, one synchronisation per
+    # chunk) around the product's own exchange — two processes, the HIP path on each shard
     env = dict(os.environ, SAGEICP_BENCH_DEVICE="0", SAGEICP_BENCH_BACKEND="gloo",
-               SAGEICP_P2P_TIMEOUT_S="3", MASTER_ADDR="127.0.0.1")
+               SAGEICP_P2P_TIMEOUT_S="5", MASTER_ADDR="127.0.0.1", SAGEICP_CHUNKED=str(chunked))
     common = ["--steps", "2", "--warmup", "1", "--scale", "0.1", "--no-cpu-baseline"]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-                          "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+                          "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(29533 + 2 * chunked),
                           os.path.join(root, "bench.py"), "--gpus", "2"] + common,
                          capture_output=True, text=True, env=env, timeout=600)
     assert two.returncode == 0, two.stderr[-2000:]
@@ -751,6 +759,8 @@ def test_direct_exchange_between_two_processes(gpu_sage, tmp_path):
     assert d2["n_gpus"] == 2 and "direct exchange" in d2["config"]["parallelism"]
     assert d2["config"]["iterations_per_frame"] == d1["config"]["iterations_per_frame"]
     assert d2["config"]["converged"] and d2["config"]["pose_error_vs_planted"] == d1["config"]["pose_error_vs_planted"]
+    br = d2["config"]["iteration_breakdown"]        # the first real SCALE line explains itself
+    assert br and br["shard_compute_us_per_iteration"] > 1.0 and br["exchange_us_per_iteration"] > 1.0
 
 
 def test_bench_independent_frames_mode(gpu_sage):

@@ -120,7 +120,6 @@ def test_prefetch_recognises_a_refilled_buffer_and_can_be_cancelled(gpu_sage, re
     """the announced frame is matched by pointer, size AND content: a buffer refilled with another
     scan after its clouds were prepared is registered as what it now holds (the stale prepared
     clouds are dropped); a cancelled announcement leaves nothing prepared and nothing reading"""
-    import time
     from sage_icp_amd import synthetic as syn
     frames, _ = syn.make_stream(6, 6, points_per_frame=20000)
     n = min(len(f) for f in frames)
@@ -132,7 +131,7 @@ def test_prefetch_recognises_a_refilled_buffer_and_can_be_cancelled(gpu_sage, re
     buf = frames[1].copy()
     b.prefetch(buf)                                   # announces the scan `buf` holds now (frame 1)
     assert np.array_equal(b.RegisterFrame(frames[0])[0], ref[0])
-    time.sleep(0.5)                                   # the helper has prepared frame 1's clouds by now
+    b.prefetch_wait()                                 # the helper has prepared frame 1's clouds and reads `buf` no more
     buf[:] = frames[2]                                # same pointer, same size, another scan
     assert np.array_equal(b.RegisterFrame(buf)[0], ref[1]), "stale prepared clouds were used"
     b.prefetch(frames[4])
@@ -148,7 +147,7 @@ def test_prefetch_recognises_a_refilled_buffer_and_can_be_cancelled(gpu_sage, re
 def _py_preprocess(frame, max_range, min_range, label_max_range):
     out = []
     for p in frame:
-        norm = float(np.sqrt(p[0] * p[0] + (p[1] * p[1] + p[2] * p[2])))     # Eigen's reduction order
+        norm = float(np.sqrt((p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]))     # point.head<3>().norm(): packet reduction
         if norm < max_range and norm > min_range:
             out.append([p[0], p[1], p[2], 0.0 if norm > label_max_range else p[3]])
     return np.array(out).reshape(-1, 4)
