@@ -32,7 +32,7 @@ inline Best2 search2(const Map &m, const Vec4 &point, double th) {
                 if (it == m.map.end()) continue;
                 for (const auto &nb : it->second.points) {
                     const double dx = nb[0] - point[0], dy = nb[1] - point[1], dz = nb[2] - point[2];
-                    double d = SAGE_SQNORM3(dx * dx, dy * dy, dz * dz);
+                    double d = SAGE_SQNORM3_NN(dx * dx, dy * dy, dz * dz);
                     if (static_cast<int>(nb[3]) == static_cast<int>(point[3]) ||
                         static_cast<int>(nb[3] * point[3]) == 0)
                         d = d * th;
@@ -65,6 +65,7 @@ extern "C" int probe_skip(const void *h, const double *frame, uint64_t n, const 
     std::vector<int> home(3 * n, INT32_MIN);
     std::vector<double> spos(3 * n, 0.0), marg(n, -1.0);
     const bool exact_disp = std::getenv("SKIP_EXACT") && std::atoi(std::getenv("SKIP_EXACT"));
+    const double cap = std::getenv("SKIP_CAP") ? std::atof(std::getenv("SKIP_CAP")) : 1e300;    // margin cap M (metres)
     const double cm = std::sqrt(std::max(1.0, sem_th));
     double a_k = 0, b_k = 0;           // movement bound of the last estimate: a |s|_1 + b
     *mismatches = 0;
@@ -95,7 +96,7 @@ extern "C" int probe_skip(const void *h, const double *frame, uint64_t n, const 
                     const double sb = std::sqrt(r.best), ss = r.second == std::numeric_limits<double>::max()
                                                                     ? std::numeric_limits<double>::max()
                                                                     : std::sqrt(r.second);
-                    bud = (ss - sb) / (2.0 * cm) * (1.0 - 1e-6);
+                    bud = std::min(cap, (ss - sb) / (2.0 * cm)) * (1.0 - 1e-6);
                     marg[i] = bud;
                     spos[3 * i] = p[0]; spos[3 * i + 1] = p[1]; spos[3 * i + 2] = p[2];
                 } else {
@@ -116,7 +117,7 @@ extern "C" int probe_skip(const void *h, const double *frame, uint64_t n, const 
             if (!has[i]) continue;
             const double dx = win[i][0] - source[4 * i], dy = win[i][1] - source[4 * i + 1],
                          dz = win[i][2] - source[4 * i + 2];
-            if (std::sqrt(SAGE_SQNORM3(dx * dx, dy * dy, dz * dz)) < max_dist) {
+            if (std::sqrt(SAGE_SQNORM3_ACCEPT(dx * dx, dy * dy, dz * dz)) < max_dist) {
                 std::memcpy(&src[4 * nc], &source[4 * i], 32);
                 std::memcpy(&tgt[4 * nc], win[i].data(), 32);
                 ++nc;

@@ -31,7 +31,7 @@ _u64p = C.POINTER(C.c_uint64)
 _i64p = C.POINTER(C.c_int64)
 _u8p = C.POINTER(C.c_uint8)
 
-ABI_VERSION = 2          # SAGEICP_ABI_VERSION of include/sageicp.h
+ABI_VERSION = 3          # SAGEICP_ABI_VERSION of include/sageicp.h
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_RCCL, ERR_CAPACITY = -1, -2, -3, -4, -5
 UNIQUE_ID_BYTES = 128
 P2P_HANDLE_BYTES = 64
@@ -64,6 +64,9 @@ class Stats(C.Structure):
         ("pairs_evaluated", C.c_uint64),
         ("lanes_per_query", C.c_uint32),
         ("compact_scan", C.c_uint32),
+        ("skip_search", C.c_uint32),
+        ("reserved1", C.c_uint32),
+        ("queries_searched", C.c_uint64),
     ]
 
 

