@@ -16,9 +16,10 @@ for wl, prm in cases:
     f = sage.Frame(w["map"], w["scan"])
     print("%s %s, %d queries" % (wl, prm, len(w["scan"])), flush=True)
     ref = None
-    settings = [dict(SAGEICP_SKIP=0), dict(SAGEICP_SKIP=1), dict(SAGEICP_SKIP=1, SAGEICP_SKIP_MARGIN_MM=20),
-                dict(SAGEICP_SKIP=1, SAGEICP_SKIP_MARGIN_MM=100), dict(SAGEICP_SKIP=1, SAGEICP_FILTER=0),
-                dict(SAGEICP_SKIP=1, SAGEICP_LW=1), dict(SAGEICP_SKIP=1, SAGEICP_LW=3)]
+    settings = [dict(SAGEICP_SKIP=0), dict(SAGEICP_SKIP=1), dict(SAGEICP_SKIP=1, SAGEICP_SKIP_MARGIN_MM=10),
+                dict(SAGEICP_SKIP=1, SAGEICP_SKIP_MARGIN_MM=20), dict(SAGEICP_SKIP=1, SAGEICP_SKIP_MARGIN_MM=30),
+                dict(SAGEICP_SKIP=1, SAGEICP_SKIP_MARGIN_MM=20, SAGEICP_FILTER=0),
+                dict(SAGEICP_SKIP=1, SAGEICP_SKIP_MARGIN_MM=20, SAGEICP_LW=1), dict(SAGEICP_SKIP=1, SAGEICP_SKIP_MARGIN_MM=20, SAGEICP_LW=3)]
     for env in settings:
         for k in ("SAGEICP_SKIP", "SAGEICP_SKIP_MARGIN_MM", "SAGEICP_FILTER", "SAGEICP_LW"):
             os.environ.pop(k, None)

@@ -1242,8 +1242,10 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
 // queries by millimetres, and a query whose answer beat the runner-up by more than that cannot
 // change its answer.  Exact, like the pruning: a search (icp_body<MODE 2>) leaves behind how far the
 // query may move before its answer could change (QState::margin, a lower bound — see the body), and
-// the answer's coordinates.  Per workgroup of 256 queries:
-//   phase A   one lane per query: pose apply, home voxel, distance moved since the last search.  A
+// the answer's coordinates.  Per workgroup of 64 queries (as many waves in flight as k_icp has: the
+// first build gave a workgroup 256 queries and the chip a quarter of the waves — 75 us per iteration on
+// c2 against k_icp's 41, profiles/r04/skip_ab_256.txt):
+//   phase A   (the first wave) one lane per query: pose apply, home voxel, distance moved since the last search.  A
 //             query still in its home voxel that moved less than its margin KEEPS its answer: its
 //             pair's acceptance test, weight and 16 Gauss-Newton terms are evaluated right here from
 //             80 bytes of state — no row, no map point, no search.  The others are compacted, in query
@@ -1294,7 +1296,7 @@ __device__ __forceinline__ void wave_sums_to_digits(const double *ws, const uint
 template <int LW, bool FILT>
 __global__ __launch_bounds__(64 * kIcpWavesPerBlock) __attribute__((amdgpu_waves_per_eu(SAGE_SKIP_OCC, 8)))
 void k_skip(IcpParams P) {
-    static_assert(kIcpWavesPerBlock * 64 == kSkipQueries, "one lane per query in phase A");
+    static_assert(kSkipQueries == 64, "phase A: one wave, one lane per query");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     if (P.check_done && P.st->done) return;
     constexpr int QW = 64 >> LW;
@@ -1311,7 +1313,9 @@ void k_skip(IcpParams P) {
     constexpr unsigned kStripe = SAGE_ICP_STRIPE;
     const unsigned xcd = blockIdx.x & 7u, jb = blockIdx.x >> 3;
     const unsigned wg = ((jb / kStripe) * 8u + xcd) * kStripe + (jb % kStripe);       // as icp_body
-    const unsigned q = wg * kSkipQueries + threadIdx.x;
+    unsigned listed = 0u;
+    if (wv == 0) {
+    const unsigned q = wg * kSkipQueries + static_cast<unsigned>(lane);
     const bool valid = q < static_cast<unsigned>(P.n);
     const Point4 f = P.frame[valid ? q : 0u];
     const QState S = P.qs[valid ? q : 0u];
@@ -1372,7 +1376,7 @@ void k_skip(IcpParams P) {
             unsigned a = 0u;
 #pragma unroll
             for (int r = 0; r < 4; ++r) a += static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(c), 16 * r));
-            const unsigned wave_id = wg * kIcpWavesPerBlock + static_cast<unsigned>(wv);
+            const unsigned wave_id = wg * kIcpWavesPerBlock;          // (any slot of this workgroup's)
             if (lane == 0 && wave_id < P.nwaves)
                 (void)__hip_atomic_fetch_add(&P.counters[2u * wave_id], static_cast<unsigned long long>(a),
                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1380,19 +1384,14 @@ void k_skip(IcpParams P) {
     }
     // the others, in query order
     const unsigned long long ab = __ballot(act);
-    if (lane == 0) cnt[wv] = static_cast<unsigned>(__popcll(ab));
-    __syncthreads();
-    unsigned before = 0u, listed = 0u;
-#pragma unroll
-    for (int k = 0; k < kIcpWavesPerBlock; ++k) {
-        before += k < wv ? cnt[k] : 0u;
-        listed += cnt[k];
+    if (act) list[static_cast<unsigned>(__popcll(ab & ((1ull << lane) - 1ull)))] = q;
+    if (lane == 0) cnt[0] = static_cast<unsigned>(__popcll(ab));
+    if (P.counters && lane == 0 && ab)         // searches run (64 slots behind the per-wave counters)
+        (void)__hip_atomic_fetch_add(&P.counters[2u * P.nwaves + (blockIdx.x & 63u)],
+                                     static_cast<unsigned long long>(__popcll(ab)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (act) list[before + static_cast<unsigned>(__popcll(ab & ((1ull << lane) - 1ull)))] = q;
-    if (P.counters && threadIdx.x == 0 && listed)      // searches run (64 slots behind the per-wave counters)
-        (void)__hip_atomic_fetch_add(&P.counters[2u * P.nwaves + (blockIdx.x & 63u)], static_cast<unsigned long long>(listed),
-                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
+    listed = cnt[0];
 
     // ---- phase B: the listed queries are searched -----------------------------------------------------------
     for (unsigned base = static_cast<unsigned>(wv) * QW; base < listed; base += kIcpWavesPerBlock * QW) {
