@@ -101,10 +101,9 @@ void launch_rows(const IcpParams &p, hipStream_t s);                     // (re)
 void launch_derive_cand(const Slot *table, uint32_t nslots, const Point4 *pts, uint4 *cand, uint64_t nslots_pts,
                         uint32_t *flags, hipStream_t s);
 void launch_icp(const IcpParams &p, int lw, bool fused, hipStream_t s);
-// k_skip (fused mode only): workgroups of 64 queries; queries that can keep their answer add their
-// pair's terms at once (first wave), the others are compacted and searched by the workgroup's waves
-constexpr int kSkipQueries = 64;
-int skip_blocks_for(int n);
+// k_skip (fused mode only): every wave owns 2 x (64 >> lw) queries; those that can keep their answer add
+// their pair's terms at once, the others are compacted and searched by the same wave in one or two rounds
+int skip_blocks_for(int n, int lw);
 size_t skip_lds_bytes(int lw);
 void launch_skip(const IcpParams &p, int lw, hipStream_t s);
 

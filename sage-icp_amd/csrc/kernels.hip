@@ -1242,28 +1242,31 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
 // queries by millimetres, and a query whose answer beat the runner-up by more than that cannot
 // change its answer.  Exact, like the pruning: a search (icp_body<MODE 2>) leaves behind how far the
 // query may move before its answer could change (QState::margin, a lower bound — see the body), and
-// the answer's coordinates.  Per workgroup of 64 queries (as many waves in flight as k_icp has: the
-// first build gave a workgroup 256 queries and the chip a quarter of the waves — 75 us per iteration on
-// c2 against k_icp's 41, profiles/r04/skip_ab_256.txt):
-//   phase A   (the first wave) one lane per query: pose apply, home voxel, distance moved since the last search.  A
+// the answer's coordinates.  Every WAVE is on its own (no workgroup barrier, no idle wave holding a
+// slot: two builds that classified per workgroup — 256 and 64 queries, the workgroup's waves
+// searching after a barrier — ran at 75 and 48-64 us per iteration on c2 against k_icp's 40,
+// profiles/r04/skip_ab_256.txt, skip_ab_64_barrier.txt): it owns 2 x (64 >> LW) queries and
+//   phase A   one lane per query: pose apply, home voxel, distance moved since the last search.  A
 //             query still in its home voxel that moved less than its margin KEEPS its answer: its
 //             pair's acceptance test, weight and 16 Gauss-Newton terms are evaluated right here from
 //             80 bytes of state — no row, no map point, no search.  The others are compacted, in query
-//             order (deterministic), into a list in LDS.
-//   phase B   the workgroup's waves search the listed queries, 64 >> LW per wave and round, with the
+//             order (deterministic), into the wave's list in LDS;
+//   phase B   searches the listed queries, 64 >> LW at a time (one round, or two), with the
 //             lanes-per-query machinery of k_icp.
 // The sums of both phases meet as fixed-point digits in LDS (integer adds: order-free) and leave the
-// workgroup as one set of 51 atomics.  On the c2 frame 31 % of the (query, iteration) pairs of a cold
+// wave as one set of 51 atomics.  On the c2 frame 31 % of the (query, iteration) pairs of a cold
 // or a steady registration still need a search (profiles/skip_probe.py replays the rule on the CPU and
 // checks every kept answer against a full search: none differs).
-__host__ __device__ constexpr unsigned skip_list_word(int lw) {
+__host__ __device__ constexpr int skip_queries_per_wave(int lw) { return (128 >> lw) > 64 ? 64 : (128 >> lw); }
+__host__ __device__ constexpr unsigned skip_wave_word(int lw) {       // per-wave areas behind the rows
     return kWgHeaderWords + static_cast<unsigned>(kIcpWavesPerBlock) * icp_wave_words(lw);
 }
-constexpr unsigned kSkDigits = kSkipQueries;                 // words after the list: 64 int64 digits
-constexpr unsigned kSkCount = kSkDigits + 2u * kAccWords;    // [4] listed per wave | [4] overflow flag
-constexpr unsigned kSkWords = kSkCount + 8u;
+constexpr unsigned kSkList = 0u;                             // [64] the wave's listed queries
+constexpr unsigned kSkDigits = 64u;                          // 64 int64 digits
+constexpr unsigned kSkFlag = kSkDigits + 2u * kAccWords;     // overflow flag
+constexpr unsigned kSkWaveWords = kSkFlag + 4u;
 
-// one wave's 16 sums + pair count (LDS, written by this wave) -> the workgroup's digits
+// one wave's 16 sums + pair count (LDS, written by this wave) -> the wave's digits
 __device__ __forceinline__ void wave_sums_to_digits(const double *ws, const uint32_t *pairs, long long *digits,
                                                     uint32_t *overflow) {
     const int lane = static_cast<int>(threadIdx.x & 63u);
@@ -1284,7 +1287,7 @@ __device__ __forceinline__ void wave_sums_to_digits(const double *ws, const uint
         } else {
             x = digit == 0 ? static_cast<long long>(pairs[0]) : 0ll;
         }
-        if (ok) (void)__hip_atomic_fetch_add(&digits[lane], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (ok) digits[lane] += x;             // (this wave's own words)
         else *overflow = 1u;
     }
     __builtin_amdgcn_wave_barrier();
@@ -1296,27 +1299,26 @@ __device__ __forceinline__ void wave_sums_to_digits(const double *ws, const uint
 template <int LW, bool FILT>
 __global__ __launch_bounds__(64 * kIcpWavesPerBlock) __attribute__((amdgpu_waves_per_eu(SAGE_SKIP_OCC, 8)))
 void k_skip(IcpParams P) {
-    static_assert(kSkipQueries == 64, "phase A: one wave, one lane per query");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     if (P.check_done && P.st->done) return;
     constexpr int QW = 64 >> LW;
+    constexpr int NQ = skip_queries_per_wave(LW);
     const int lane = static_cast<int>(threadIdx.x & 63u);
     const int wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-    uint32_t *list = smem + skip_list_word(LW);
-    long long *digits = reinterpret_cast<long long *>(list + kSkDigits);
-    uint32_t *cnt = list + kSkCount;
-    if (threadIdx.x < kAccWords) digits[threadIdx.x] = 0;
-    if (threadIdx.x < 8u) cnt[threadIdx.x] = 0u;
-    __syncthreads();
+    uint32_t *mine = smem + skip_wave_word(LW) + static_cast<unsigned>(wv) * kSkWaveWords;
+    uint32_t *list = mine + kSkList;
+    long long *digits = reinterpret_cast<long long *>(mine + kSkDigits);
+    uint32_t *flag = mine + kSkFlag;
+    digits[lane] = 0;
+    if (lane == 0) *flag = 0u;
 
     // ---- phase A: who keeps its answer -----------------------------------------------------------------
     constexpr unsigned kStripe = SAGE_ICP_STRIPE;
     const unsigned xcd = blockIdx.x & 7u, jb = blockIdx.x >> 3;
     const unsigned wg = ((jb / kStripe) * 8u + xcd) * kStripe + (jb % kStripe);       // as icp_body
-    unsigned listed = 0u;
-    if (wv == 0) {
-    const unsigned q = wg * kSkipQueries + static_cast<unsigned>(lane);
-    const bool valid = q < static_cast<unsigned>(P.n);
+    const unsigned wave_id = wg * kIcpWavesPerBlock + static_cast<unsigned>(wv);
+    const unsigned q = wave_id * NQ + static_cast<unsigned>(lane);
+    const bool valid = lane < NQ && q < static_cast<unsigned>(P.n);
     const Point4 f = P.frame[valid ? q : 0u];
     const QState S = P.qs[valid ? q : 0u];
     const Query s = make_query<false>(f, P.st->R, P.st->T + 4, 1, P.voxel_size);
@@ -1366,7 +1368,7 @@ void k_skip(IcpParams P) {
             if (lane == 0) ws[c] = tot;
         }
         if (lane == 0) smem[kWgPairs + wv] = pairs;
-        wave_sums_to_digits(ws, smem + kWgPairs + wv, digits, cnt + 4);
+        wave_sums_to_digits(ws, smem + kWgPairs + wv, digits, flag);
         if (P.counters) {                      // C_q of the kept queries (the candidates a search would have met)
             unsigned c = keep ? S.cq : 0u;
             c += dpp_u32<kDppXor1>(c);
@@ -1376,7 +1378,6 @@ void k_skip(IcpParams P) {
             unsigned a = 0u;
 #pragma unroll
             for (int r = 0; r < 4; ++r) a += static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(c), 16 * r));
-            const unsigned wave_id = wg * kIcpWavesPerBlock;          // (any slot of this workgroup's)
             if (lane == 0 && wave_id < P.nwaves)
                 (void)__hip_atomic_fetch_add(&P.counters[2u * wave_id], static_cast<unsigned long long>(a),
                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1384,27 +1385,24 @@ void k_skip(IcpParams P) {
     }
     // the others, in query order
     const unsigned long long ab = __ballot(act);
+    const unsigned listed = static_cast<unsigned>(__popcll(ab));
     if (act) list[static_cast<unsigned>(__popcll(ab & ((1ull << lane) - 1ull)))] = q;
-    if (lane == 0) cnt[0] = static_cast<unsigned>(__popcll(ab));
-    if (P.counters && lane == 0 && ab)         // searches run (64 slots behind the per-wave counters)
-        (void)__hip_atomic_fetch_add(&P.counters[2u * P.nwaves + (blockIdx.x & 63u)],
-                                     static_cast<unsigned long long>(__popcll(ab)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    listed = cnt[0];
+    if (P.counters && lane == 0 && listed)     // searches run (64 slots behind the per-wave counters)
+        (void)__hip_atomic_fetch_add(&P.counters[2u * P.nwaves + (wave_id & 63u)], static_cast<unsigned long long>(listed),
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_wave_barrier();
 
     // ---- phase B: the listed queries are searched -----------------------------------------------------------
-    for (unsigned base = static_cast<unsigned>(wv) * QW; base < listed; base += kIcpWavesPerBlock * QW) {
+    for (unsigned base = 0u; base < listed; base += QW) {
         const SkipCtx sk{list, base, listed};
         (void)icp_body<LW, true, FILT, 2>(P, smem, nullptr, nullptr, kIcpWavesPerBlock, &sk);
         wave_sums_to_digits(reinterpret_cast<const double *>(smem + kWgSums) + wv * kCount, smem + kWgPairs + wv,
-                            digits, cnt + 4);
+                            digits, flag);
     }
-    __syncthreads();
-    if (wv == 0 && lane < 3 * kAccValues && P.acc) {
-        long long *dst = P.acc + static_cast<size_t>(blockIdx.x & (kAccReplicas - 1)) * kAccWords;
+    if (lane < 3 * kAccValues && P.acc) {
+        long long *dst = P.acc + static_cast<size_t>(wave_id & (kAccReplicas - 1)) * kAccWords;
         const long long x = digits[lane];
-        if (cnt[4]) (void)__hip_atomic_fetch_or(P.acc + kAccWords - 1, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (*flag) (void)__hip_atomic_fetch_or(P.acc + kAccWords - 1, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else if (x) (void)__hip_atomic_fetch_add(dst + lane, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -2308,16 +2306,17 @@ void launch_loop(const IcpParams &p, const LoopParams &l, int lw, int grid, hipS
     }
 }
 
-int skip_blocks_for(int n) {
-    const long blocks = (static_cast<long>(n) + kSkipQueries - 1) / kSkipQueries;
+int skip_blocks_for(int n, int lw) {
+    const long per_wg = static_cast<long>(skip_queries_per_wave(lw)) * kIcpWavesPerBlock;
+    const long blocks = (static_cast<long>(n) + per_wg - 1) / per_wg;
     const long per_round = 8L * SAGE_ICP_STRIPE;
     const long r = ((blocks + per_round - 1) / per_round) * per_round;
     return static_cast<int>(r < per_round ? per_round : r);
 }
-size_t skip_lds_bytes(int lw) { return sizeof(uint32_t) * (skip_list_word(lw) + kSkWords); }
+size_t skip_lds_bytes(int lw) { return sizeof(uint32_t) * (skip_wave_word(lw) + kIcpWavesPerBlock * kSkWaveWords); }
 template <int LW>
 static void launch_skip_lw(const IcpParams &p, hipStream_t s) {
-    const dim3 g(skip_blocks_for(p.n)), b(64 * kIcpWavesPerBlock);
+    const dim3 g(skip_blocks_for(p.n, LW)), b(64 * kIcpWavesPerBlock);
     const size_t lds = skip_lds_bytes(LW);
     if (p.filter) hipLaunchKernelGGL((k_skip<LW, true>), g, b, lds, s, p);
     else hipLaunchKernelGGL((k_skip<LW, false>), g, b, lds, s, p);
