@@ -56,8 +56,8 @@ typedef struct sageicp_comm sageicp_comm;     /* opaque: RCCL communicator for q
  * capacity limits 2^24 voxels / 2^26 point slots (sageicp_map_point_slots) / |voxel index| < 2^20 (SAGEICP_ERR_CAPACITY);
  * sageicp_comm_describe, sageicp_map_pointcloud served from the HBM copy, sageicp_map_point_slots
  * (size-classed voxel storage).   3: sageicp_stats names its loop form (single_launch in the slot of
- * reserved0; skip_search and queries_searched appended), sageicp_pipeline_prefetch_wait, non-finite input
- * refused (SAGEICP_ERR_INVALID) at every entry that would cast it. */
+ * reserved0), sageicp_pipeline_prefetch_wait, non-finite input refused (SAGEICP_ERR_INVALID) at every entry
+ * that would cast it. */
 #define SAGEICP_ABI_VERSION 3
 
 /* Filled by sageicp_register_frame*.  Times are microseconds. */
@@ -84,10 +84,6 @@ typedef struct sageicp_stats {
     uint32_t lanes_per_query;   /* lanes that shared one query in the search kernel (1..16) */
     uint32_t compact_scan;      /* 1: the search scanned the 16-B compact copy of the map behind its fp32
                                  * filter (big frames, dense voxels); 0: the full fp64 records */
-    uint32_t skip_search;       /* 1: k_skip ran instead of k_icp: a query that provably keeps its previous answer
-                                 * (it moved less than the margin its last search established) is not searched */
-    uint32_t reserved1;
-    uint64_t queries_searched;  /* with skip_search: searches actually run, all iterations (else iterations x n) */
 } sageicp_stats;
 
 /* ---- library ------------------------------------------------------------------------ */

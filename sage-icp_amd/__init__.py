@@ -64,9 +64,6 @@ class Stats(C.Structure):
         ("pairs_evaluated", C.c_uint64),
         ("lanes_per_query", C.c_uint32),
         ("compact_scan", C.c_uint32),
-        ("skip_search", C.c_uint32),
-        ("reserved1", C.c_uint32),
-        ("queries_searched", C.c_uint64),
     ]
 
 

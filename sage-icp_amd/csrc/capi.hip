@@ -113,7 +113,6 @@ struct Scratch {
     // per-call work buffers: the queries' cached neighbourhood rows, the workgroup partials
     uint32_t *d_rows = nullptr;
     uint2 *d_prev = nullptr;       // every query's record of the previous iteration (kernels.h)
-    QState *d_qs = nullptr;        // k_skip: every query's keep-state (kernels.h)
     uint32_t *d_work = nullptr;    // instrumented builds: points handed to each query
     double *d_partials = nullptr; size_t partials_cap = 0;
     double *d_partials2 = nullptr; size_t partials2_cap = 0;   // second stage of the reduction (k_red, big frames)
@@ -184,14 +183,12 @@ struct Scratch {
         if (d_sort_temp) HIPCHK(hipFree(d_sort_temp));
         if (d_rows) HIPCHK(hipFree(d_rows));
         if (d_prev) HIPCHK(hipFree(d_prev));
-        if (d_qs) HIPCHK(hipFree(d_qs));
-        d_rows = nullptr; d_prev = nullptr; d_qs = nullptr;
+        d_rows = nullptr; d_prev = nullptr;
         d_sorted = nullptr; d_keys = d_vals = nullptr; d_sort_temp = nullptr; sort_cap = 0;
         const size_t cap = n + n / 4 + 1024;
         HIPCHK(hipMalloc(&d_sorted, cap * sizeof(Point4)));
         HIPCHK(hipMalloc(&d_rows, cap * kRowWords * sizeof(uint32_t)));
         HIPCHK(hipMalloc(&d_prev, cap * sizeof(uint2)));
-        HIPCHK(hipMalloc(&d_qs, cap * sizeof(QState)));
 #ifdef SAGE_NN_TIMING
         if (d_work) HIPCHK(hipFree(d_work));
         d_work = nullptr;
@@ -248,7 +245,6 @@ struct Scratch {
         if (d_sort_temp) (void)hipFree(d_sort_temp);
         if (d_rows) (void)hipFree(d_rows);
         if (d_prev) (void)hipFree(d_prev);
-        if (d_qs) (void)hipFree(d_qs);
         if (d_work) (void)hipFree(d_work);
         if (d_partials) (void)hipFree(d_partials);
         if (d_partials2) (void)hipFree(d_partials2);
@@ -1265,11 +1261,6 @@ double accept_threshold(double max_dist) {
     return std::sqrt(x) < max_dist ? x : -1.0;
 }
 
-// does sem_th give the search a usable lower bound (kernels.hip "Exact pruning")?
-static bool prune_on(double sem_th) { return sem_th >= 0.0 && env_int("SAGEICP_NO_PRUNE", 0) == 0; }
-// frames from this size on go through k_skip (SAGEICP_SKIP=0/1 overrides)
-constexpr uint64_t kSkipMinQueries = 1ull << 62;      // (off by default until measured)
-
 // fewer than six points per voxel on average
 static bool sparse_voxels(const sageicp_map *m) {
     const uint64_t mp = m->on_device ? m->ctr.total_points : m->host.total_points;
@@ -1328,16 +1319,6 @@ IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, 
     ip.kernel = 0.0;
     ip.accept_r2 = -1.0;
     ip.nn_prev = sc.d_prev;
-    ip.qs = sc.d_qs;
-    {
-        // k_skip (kernels.hip): a kept answer is good for at most `cap` metres of movement; a search looks
-        // that much further than its answer needs (in square roots of scaled distances: x 2 sqrt(max(1, th)))
-        const double cap = 1e-3 * std::max(1, env_int("SAGEICP_SKIP_MARGIN_MM", 50));
-        const double cm = std::sqrt(std::max(1.0, sem_th >= 0.0 ? sem_th : 1.0));
-        ip.skip_cap = cap;
-        ip.skip_reach = 2.0 * cap * cm;
-        ip.skip_inv2cm = 1.0 / (2.0 * cm);
-    }
     ip.work = sc.d_work;
     ip.partials = sc.d_partials;
     ip.counters = nullptr;
@@ -1444,7 +1425,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     ip.kernel = kernel;
     ip.accept_r2 = accept_threshold(max_dist);
     ip.counters = stats ? sc.d_cand : nullptr;
-    if (stats) HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * (2 * ip.nwaves + 66), s));
+    if (stats) HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * 2 * (ip.nwaves + 1), s));
 
     // Spatial ordering of the frame: the loop runs on a copy sorted by map-frame voxel under the
     // initial guess, so that the queries of a wave share home voxels and neighbouring waves touch
@@ -1496,7 +1477,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
                 sc.h_state->progress = sc.d_prog;
             }
             HIPCHK(hipMemcpyAsync(sc.d_state, sc.h_state, sizeof(IcpState), hipMemcpyHostToDevice, s));
-            if (stats) HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * (2 * ip.nwaves + 66), s));
+            if (stats) HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * 2 * (ip.nwaves + 1), s));
             use_loop = false;
         } else {
             looped = true;
@@ -1508,14 +1489,9 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
             }
         }
     }
-    // k_skip instead of k_icp: queries that provably keep their answer are not searched (kernels.hip).
-    // Needs the exact pruning to be on (a usable sem_th) and the fixed-point accumulators.
-    const bool use_skip = !looped && n > 0 && prune_on(sem_th) && env_int("SAGEICP_PARTIALS", 0) == 0 &&
-                          env_int("SAGEICP_SKIP", n >= kSkipMinQueries ? 1 : 0) != 0;
     if (n > 0 && !looped) {
         launch_rows(ip, s);
         HIPCHK(hipMemsetAsync(sc.d_prev, 0xFF, n * sizeof(uint2), s));     // no previous answers yet
-        if (use_skip) HIPCHK(hipMemsetAsync(sc.d_qs, 0, n * sizeof(QState), s));      // nothing to keep yet
     }
 
     // The workgroups of k_icp add their sums into fixed-point accumulators (kernels.h) that k_fin
@@ -1557,8 +1533,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     auto enqueue_iteration = [&](int slot, int iteration) -> int {
         const bool ev = sampled(iteration);
         if (ev) HIPCHK(hipEventRecord(sc.events[5 * slot + 1], s));
-        if (use_skip) launch_skip(ip, lw, s);
-        else launch_icp(ip, lw, true, s);
+        launch_icp(ip, lw, true, s);
         if (ev) HIPCHK(hipEventRecord(sc.events[5 * slot + 2], s));
         if (red_rows) launch_red(rp, s);
         launch_fin(fp, s);
@@ -1671,8 +1646,6 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         stats->lanes_per_query = 1u << lw;
         stats->compact_scan = (looped ? plan.filter && ip.filter : ip.filter != 0) ? 1u : 0u;
         stats->single_launch = looped ? 1u : 0u;
-        stats->skip_search = use_skip ? 1u : 0u;
-        stats->queries_searched = use_skip ? st.sum_searched : static_cast<uint64_t>(st.iter) * n;
         for (int i = 0; i < 64 && i < st.iter; ++i) stats->n_corr_hist[i] = st.n_corr[i];
         stats->us_wall = now_us() - t_begin;
     }

@@ -21,20 +21,6 @@ constexpr int kRowWords = 32;
 constexpr int kRowCq = 27, kRowKey = 28, kRowOcc = 31;
 constexpr int kRowLdsStride = 36;          // words; 16-B pieces of 8 consecutive rows hit distinct banks
 
-// k_skip: what a query keeps from its last search so that later iterations can do without one.  The
-// answer (winner) stands while the query stays in its home voxel (same 27 voxels, and the map is
-// constant during a call) and has moved less than `margin` from where it was searched: the pair's
-// Gauss-Newton terms then need this record and the frame point only.
-struct alignas(16) QState {
-    double wx, wy, wz;        // the answer's coordinates
-    double sx, sy, sz;        // where the query was when it was searched
-    float margin;             // movement the answer survives (0: search again)
-    uint32_t cq;              // C_q of the query's neighbourhood (the candidate accounting of a kept answer)
-    int32_t kx, ky, kz;       // its home voxel then
-    uint32_t pad;
-};
-static_assert(sizeof(QState) == 80, "five 16-byte pieces");
-
 struct IcpParams {
     const Point4 *frame;      // pristine (sorted) frame, or ready-made queries (apply_pose == 0)
     int n;
@@ -75,11 +61,6 @@ struct IcpParams {
     double *partials;         // out: [gridDim.x][kNumSums] one partial per workgroup (acc == nullptr)
     long long *acc;           // out: the Gauss-Newton sums as fixed-point accumulators (see kAcc* below):
                               // every workgroup ADDS its 16 sums and its pair count with integer atomics
-    QState *qs;               // k_skip: [n] keep-states (zeroed at the start of a call)
-    double skip_reach;        // k_skip: 2 x margin cap x sqrt(max(1, sem_th)): how far beyond the answer, in square
-                              // roots of scaled distances, a search looks (see kernels.hip `widened`)
-    double skip_cap;          // k_skip: the margin cap (metres)
-    double skip_inv2cm;       // k_skip: 1 / (2 sqrt(max(1, sem_th)))
     unsigned long long *counters;  // optional: [2 x waves] running sums of {C_q, pairs evaluated}
     unsigned nwaves;          // waves that own queries: ceil(n / (64 >> lw))
 #ifdef SAGE_ICP_DELAY_PROBE
@@ -101,11 +82,6 @@ void launch_rows(const IcpParams &p, hipStream_t s);                     // (re)
 void launch_derive_cand(const Slot *table, uint32_t nslots, const Point4 *pts, uint4 *cand, uint64_t nslots_pts,
                         uint32_t *flags, hipStream_t s);
 void launch_icp(const IcpParams &p, int lw, bool fused, hipStream_t s);
-// k_skip (fused mode only): every wave owns 2 x (64 >> lw) queries; those that can keep their answer add
-// their pair's terms at once, the others are compacted and searched by the same wave in one or two rounds
-int skip_blocks_for(int n, int lw);
-size_t skip_lds_bytes(int lw);
-void launch_skip(const IcpParams &p, int lw, hipStream_t s);
 
 struct GnParams {             // stand-alone AlignClouds on explicit pairs
     const Point4 *src;

@@ -109,11 +109,6 @@ __device__ __forceinline__ double min_f64(double a, double b) {
     asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-__device__ __forceinline__ double max_f64(double a, double b) {      // (neither operand is ever a NaN where it is used)
-    double r;
-    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
 // min(v, v of the partner lane) in one VOP2-DPP instruction.  The s_nop covers the two wait
 // states a DPP read needs after a VALU write of the same register (the compiler's hazard
 // recogniser does not look into inline assembly).
@@ -412,17 +407,9 @@ __host__ __device__ constexpr unsigned loop_wave_words(int lw) {
 // `pose` (LDS: R[9], t[3]); nothing is read from or written to the global rows / nn_prev arrays;
 // the body ends with the wave's sums parked in the workgroup's LDS header and returns true on the
 // last wave of the workgroup to arrive (`nw` waves), which the caller lets finish the iteration.
-// MODE 2 (k_skip): the wave searches the queries a list names (those that could not keep their
-// previous answer, see k_skip), tracks the runner-up of every search, leaves each query's keep-state
-// (QState) behind, and ends with the wave's sums in the workgroup's LDS header.
-struct SkipCtx {
-    const uint32_t *list;      // LDS: the workgroup's queries that need a search, in query order
-    unsigned base, count;      // this wave's first entry; entries in the list
-};
-template <int LW, bool FUSED, bool FILT, int MODE = 0>
+template <int LW, bool FUSED, bool FILT, bool PERSIST = false>
 __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, LoopLane *LL = nullptr,
-                                         const double *pose = nullptr, int nw = kIcpWavesPerBlock,
-                                         const SkipCtx *SK = nullptr);
+                                         const double *pose = nullptr, int nw = kIcpWavesPerBlock);
 
 // a pair of scanned points in flight: compact records (FILT) or full ones
 struct PairCompact {
@@ -452,12 +439,10 @@ void k_icp(IcpParams P) {
 #endif
 }
 
-template <int LW, bool FUSED, bool FILT, int MODE>
+template <int LW, bool FUSED, bool FILT, bool PERSIST>
 __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, LoopLane *LL, const double *pose,
-                                         int nw, const SkipCtx *SK) {
-    constexpr bool PERSIST = MODE == 1;        // k_loop
-    constexpr bool SKIPM = MODE == 2;          // k_skip
-    static_assert(MODE == 0 || FUSED, "k_loop and k_skip always accumulate");
+                                         int nw) {
+    static_assert(!PERSIST || FUSED, "the persistent loop always accumulates");
     constexpr int W = 1 << LW;                 // lanes per query
     constexpr int QW = 64 >> LW;               // queries per wave
     constexpr int SH = 5;                      // points are addressed by byte offset
@@ -472,7 +457,7 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
 #endif
     const int lane = static_cast<int>(threadIdx.x & 63u);
     const int wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-    if (FUSED && MODE == 0) {
+    if (FUSED && !PERSIST) {
         if (threadIdx.x == 0) smem[kWgArrive] = 0u;
         __syncthreads();
     }
@@ -494,13 +479,8 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
 
     const int qw = lane >> LW;                 // this lane's query within the wave
     const unsigned ci = static_cast<unsigned>(lane) & (W - 1u);
-    unsigned q = wave_id * QW + static_cast<unsigned>(qw);
-    bool valid = q < static_cast<unsigned>(P.n);
-    if constexpr (SKIPM) {                     // the wave's queries come from the workgroup's list
-        const unsigned e = SK->base + static_cast<unsigned>(qw);
-        valid = e < SK->count;
-        q = SK->list[valid ? e : 0u];
-    }
+    const unsigned q = wave_id * QW + static_cast<unsigned>(qw);
+    const bool valid = q < static_cast<unsigned>(P.n);
     const unsigned qc = valid ? q : 0u;        // keeps the loads of idle lanes legal
     uint32_t *lrow = wl + qw * kRowLdsStride;
     const uint32_t *grow = P.rows + static_cast<size_t>(qc) * kRowWords;
@@ -728,7 +708,6 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
     unsigned k = ci, kend = 0u, off = 0u;
     // The reference's comparison, fp64, on a full record.  Branch-free: a lane that holds no
     // candidate here (`on` false) turns its distance into a NaN, which loses every comparison.
-    double second = __longlong_as_double(0x7FF0000000000000ll);     // k_skip: the runner-up's scaled distance (+inf: none yet)
     auto evaluate = [&](const Point4 &nb, bool on, unsigned key) {
         const double dx = nb.x - s.x, dy = nb.y - s.y, dz = nb.z - s.z;
         double d = SAGE_SQNORM3_NN(dx * dx, dy * dy, dz * dz);
@@ -737,13 +716,6 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
         const bool same = static_cast<int>(nb.l) == pli || fabs(nb.l * s.l) < 1.0;
         const double ds = d * th;
         d = same ? ds : d;
-        if constexpr (SKIPM) {
-            // the loser of (what is held, this candidate) is a runner-up — unless this IS the
-            // candidate held (the seed met again in its voxel) or the lane has none here
-            const bool counts = on & (key != bkey);
-            const double dd = __hiloint2double(counts ? __double2hiint(d) : 0x7FF00000, counts ? __double2loint(d) : 0);
-            second = min_f64(second, max_f64(best, dd));
-        }
         d = __hiloint2double(on ? __double2hiint(d) : 0x7FF80000, __double2loint(d));
         // lexicographic (d, key): the home voxel is visited first, out of enumeration order;
         // a NaN distance never wins
@@ -789,19 +761,9 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
     auto round_up = [](double x) {             // the next fp32 above x (an infinity becomes a NaN:
         return __uint_as_float(__float_as_uint(static_cast<float>(x)) + 1u);   // `D32 > NaN` is false, nothing is dropped)
     };
-    // k_skip: everything the search does NOT look at must lie beyond the answer by a known margin (the
-    // answer is then kept, without a search, while the query moves less than that): bounds are widened
-    // from b to (sqrt(b) + skip_reach)^2 — skip_reach = 2 x margin cap x sqrt(max(1, sem_th)), in
-    // square roots of scaled distances — before a voxel is pruned or a compact candidate dropped.
-    // (the root in fp32, rounded up generously: a bound only has to be on the safe side)
-    auto widened = [&](double b) {
-        const double r = static_cast<double>(__builtin_sqrtf(static_cast<float>(b))) * (1.0 + 1e-6) + P.skip_reach;
-        return r * r;
-    };
     auto set_thresholds = [&]() {
         if constexpr (!FILT) return;
-        const double fbw = SKIPM ? widened(fb) : fb;
-        float a = round_up(fbw * P.filt_inv_same + slack), b = round_up(fbw * P.filt_inv_diff + slack);
+        float a = round_up(fb * P.filt_inv_same + slack), b = round_up(fb * P.filt_inv_diff + slack);
         if (unknown) {                         // the looser one; a NaN stands for an infinity
             float m = a > b ? a : b;
             if (a != a || b != b) m = __uint_as_float(0x7FC00000u);
@@ -975,9 +937,8 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
     }
     NN_T(2);
     // what the query holds after its home voxel (or its seed) bounds the rest of its search
-    const double bound0 = seg_min_f64<W>(best);
-    fb = bound0;                               // (set_thresholds runs at the start of the scan)
-    const double bound = SKIPM ? widened(bound0) : bound0;     // k_skip: see `widened`
+    const double bound = seg_min_f64<W>(best);
+    fb = bound;                                // (set_thresholds runs at the start of the scan)
     unsigned need = P.keep_all;
     if constexpr (W >= 4) {
         // The 26 bound tests are the same for every lane of the query: lane a < 3 takes the x-layer
@@ -1021,22 +982,6 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
     const unsigned woff = (lrow[found ? mkey >> 8 : 0u] >> 8) * (kUnitPoints * 32u) +
                           ((mkey & 255u) << SH);
     NN_T(3);
-    // k_skip: how far this query may move before its answer has to be looked for again.  The runner-up
-    // among the candidates the search evaluated: every lane's own, and a lane's best that is not the
-    // winner; whatever the search did not evaluate lies beyond the answer by the widened bounds'
-    // reach.  Moving the query by e changes sqrt(scaled distance) of any candidate by at most
-    // sqrt(max(1, sem_th)) e, so the answer stands while e < (sqrt(runner-up) - sqrt(answer)) /
-    // (2 sqrt(max(1, sem_th))), capped at the reach; rounded down, and 0 (never kept) on a tie.
-    float keep_margin = 0.0f;
-    if constexpr (SKIPM) {
-        double sec = (bkey != mkey) ? min_f64(second, best) : second;
-        sec = seg_min_f64<W>(sec);
-        const double gap = (sqrt(sec) - sqrt(m)) * P.skip_inv2cm;          // (+inf - finite = +inf: capped below)
-        double mg = fmin(gap, P.skip_cap) * (1.0 - 1e-6) - 1e-12 * (1.0 + (fabs(s.x) + (fabs(s.y) + fabs(s.z))));
-        mg = (found && mg > 0.0) ? mg : 0.0;
-        keep_margin = __uint_as_float(__float_as_uint(static_cast<float>(mg)) - (mg > 0.0 ? 1u : 0u));   // a float at or below it
-        if (!(static_cast<double>(keep_margin) <= mg)) keep_margin = 0.0f;
-    }
 
     if (P.counters) {                          // C_q and pairs handed out, summed over the wave
         // (both fit 16 bits per query: one packed value goes through the four DPP exchanges inside
@@ -1092,26 +1037,8 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
 #pragma unroll
         for (int c = 0; c < kCount; ++c) t[c] = 0.0;
         bool use = false;
-        if constexpr (SKIPM) {
-            if (valid && ci == 0u && !found) {
-                QState z{};
-                z.kx = s.kx; z.ky = s.ky; z.kz = s.kz;
-                z.cq = lrow[kRowCq];
-                P.qs[q] = z;                   // nothing to keep: searched again next time
-            }
-        }
         if (found && ci == 0u) {
             if constexpr (!PERSIST) g = load_point(pts, woff);
-            if constexpr (SKIPM) {
-                QState z;
-                z.wx = g.x; z.wy = g.y; z.wz = g.z;
-                z.sx = s.x; z.sy = s.y; z.sz = s.z;
-                z.margin = keep_margin;
-                z.cq = lrow[kRowCq];
-                z.kx = s.kx; z.ky = s.ky; z.kz = s.kz;
-                z.pad = 0u;
-                P.qs[q] = z;
-            }
             const double rx = s.x - g.x, ry = s.y - g.y, rz = s.z - g.z;
             // (closest_neighboor - point).head<3>().norm() < max_correspondance_distance (VoxelHashMap.cpp:111)
             use = SAGE_SQNORM3_ACCEPT(rx * rx, ry * ry, rz * rz) <= P.accept_r2;
@@ -1174,7 +1101,6 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
             }
         }
 #endif
-        if constexpr (SKIPM) return false;     // (k_skip adds the wave's sums into the workgroup's digits itself)
         if constexpr (PERSIST) {
             // k_loop finishes the iteration itself (wg_sums_to_acc, arrival, solve)
             const bool last = prior == static_cast<unsigned>(nw) - 1u;
@@ -1235,176 +1161,6 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
     }
 #endif
     return false;
-}
-
-// ------------------------------------------------------------------------------------ k_skip
-// The search kernel of big frames once the loop creeps: most of an ICP run's iterations move the
-// queries by millimetres, and a query whose answer beat the runner-up by more than that cannot
-// change its answer.  Exact, like the pruning: a search (icp_body<MODE 2>) leaves behind how far the
-// query may move before its answer could change (QState::margin, a lower bound — see the body), and
-// the answer's coordinates.  Every WAVE is on its own (no workgroup barrier, no idle wave holding a
-// slot: two builds that classified per workgroup — 256 and 64 queries, the workgroup's waves
-// searching after a barrier — ran at 75 and 48-64 us per iteration on c2 against k_icp's 40,
-// profiles/r04/skip_ab_256.txt, skip_ab_64_barrier.txt): it owns 2 x (64 >> LW) queries and
-//   phase A   one lane per query: pose apply, home voxel, distance moved since the last search.  A
-//             query still in its home voxel that moved less than its margin KEEPS its answer: its
-//             pair's acceptance test, weight and 16 Gauss-Newton terms are evaluated right here from
-//             80 bytes of state — no row, no map point, no search.  The others are compacted, in query
-//             order (deterministic), into the wave's list in LDS;
-//   phase B   searches the listed queries, 64 >> LW at a time (one round, or two), with the
-//             lanes-per-query machinery of k_icp.
-// The sums of both phases meet as fixed-point digits in LDS (integer adds: order-free) and leave the
-// wave as one set of 51 atomics.  On the c2 frame 31 % of the (query, iteration) pairs of a cold
-// or a steady registration still need a search (profiles/skip_probe.py replays the rule on the CPU and
-// checks every kept answer against a full search: none differs).
-__host__ __device__ constexpr int skip_queries_per_wave(int lw) { return (128 >> lw) > 64 ? 64 : (128 >> lw); }
-__host__ __device__ constexpr unsigned skip_wave_word(int lw) {       // per-wave areas behind the rows
-    return kWgHeaderWords + static_cast<unsigned>(kIcpWavesPerBlock) * icp_wave_words(lw);
-}
-constexpr unsigned kSkList = 0u;                             // [64] the wave's listed queries
-constexpr unsigned kSkDigits = 64u;                          // 64 int64 digits
-constexpr unsigned kSkFlag = kSkDigits + 2u * kAccWords;     // overflow flag
-constexpr unsigned kSkWaveWords = kSkFlag + 4u;
-
-// one wave's 16 sums + pair count (LDS, written by this wave) -> the wave's digits
-__device__ __forceinline__ void wave_sums_to_digits(const double *ws, const uint32_t *pairs, long long *digits,
-                                                    uint32_t *overflow) {
-    const int lane = static_cast<int>(threadIdx.x & 63u);
-    __builtin_amdgcn_wave_barrier();
-    if (lane < 3 * kAccValues) {
-        const int c = lane / 3, digit = lane % 3;
-        long long x;
-        bool ok = true;
-        if (c < kCount) {
-            const double v = ws[c];
-            const double a = __builtin_rint(v);                          // as wg_sums_to_acc
-            const double r1 = (v - a) * 1099511627776.0;
-            const double b = __builtin_rint(r1);
-            const double c2 = __builtin_rint((r1 - b) * 1099511627776.0);
-            const double d = digit == 0 ? a : (digit == 1 ? b : c2);
-            ok = fabs(a) < 1125899906842624.0;
-            x = __double_as_longlong(d + 6755399441055744.0) - 0x4338000000000000ll;
-        } else {
-            x = digit == 0 ? static_cast<long long>(pairs[0]) : 0ll;
-        }
-        if (ok) digits[lane] += x;             // (this wave's own words)
-        else *overflow = 1u;
-    }
-    __builtin_amdgcn_wave_barrier();
-}
-
-#ifndef SAGE_SKIP_OCC
-#define SAGE_SKIP_OCC 5        // waves per SIMD k_skip's register allocation is held to (96 registers)
-#endif
-template <int LW, bool FILT>
-__global__ __launch_bounds__(64 * kIcpWavesPerBlock) __attribute__((amdgpu_waves_per_eu(SAGE_SKIP_OCC, 8)))
-void k_skip(IcpParams P) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    if (P.check_done && P.st->done) return;
-    constexpr int QW = 64 >> LW;
-    constexpr int NQ = skip_queries_per_wave(LW);
-    const int lane = static_cast<int>(threadIdx.x & 63u);
-    const int wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-    uint32_t *mine = smem + skip_wave_word(LW) + static_cast<unsigned>(wv) * kSkWaveWords;
-    uint32_t *list = mine + kSkList;
-    long long *digits = reinterpret_cast<long long *>(mine + kSkDigits);
-    uint32_t *flag = mine + kSkFlag;
-    digits[lane] = 0;
-    if (lane == 0) *flag = 0u;
-
-    // ---- phase A: who keeps its answer -----------------------------------------------------------------
-    constexpr unsigned kStripe = SAGE_ICP_STRIPE;
-    const unsigned xcd = blockIdx.x & 7u, jb = blockIdx.x >> 3;
-    const unsigned wg = ((jb / kStripe) * 8u + xcd) * kStripe + (jb % kStripe);       // as icp_body
-    const unsigned wave_id = wg * kIcpWavesPerBlock + static_cast<unsigned>(wv);
-    const unsigned q = wave_id * NQ + static_cast<unsigned>(lane);
-    const bool valid = lane < NQ && q < static_cast<unsigned>(P.n);
-    const Point4 f = P.frame[valid ? q : 0u];
-    const QState S = P.qs[valid ? q : 0u];
-    const Query s = make_query<false>(f, P.st->R, P.st->T + 4, 1, P.voxel_size);
-    const double ex = s.x - S.sx, ey = s.y - S.sy, ez = s.z - S.sz;
-    const double e2 = ex * ex + (ey * ey + ez * ez);
-    const double mg = static_cast<double>(S.margin);
-    // (the margin is a lower bound rounded down; the distance moved is rounded up)
-    const bool keep = valid && mg > 0.0 && s.kx == S.kx && s.ky == S.ky && s.kz == S.kz &&
-                      e2 * (1.0 + 1e-9) < (mg * mg) * (1.0 - 1e-9);
-    const bool act = valid && !keep;
-    if (__ballot(keep)) {
-        double t[kCount];
-#pragma unroll
-        for (int c = 0; c < kCount; ++c) t[c] = 0.0;
-        bool use = false;
-        if (keep) {
-            // exactly the epilogue of a searched query (icp_body), on the kept answer
-            const double rx = s.x - S.wx, ry = s.y - S.wy, rz = s.z - S.wz;
-            use = SAGE_SQNORM3_ACCEPT(rx * rx, ry * ry, rz * rz) <= P.accept_r2;
-            const double r2 = SAGE_SQNORM3_RESID(rx * rx, ry * ry, rz * rz);
-            if (use) {
-                const double k = P.kernel;
-                const double den = k + r2;
-                const double w = (k * k) / (den * den);
-                const double wsx = w * s.x, wsy = w * s.y, wsz = w * s.z;
-                t[kW] = w;
-                t[kWsx] = wsx; t[kWsy] = wsy; t[kWsz] = wsz;
-                t[kWxx] = wsx * s.x; t[kWxy] = wsx * s.y; t[kWxz] = wsx * s.z;
-                t[kWyy] = wsy * s.y; t[kWyz] = wsy * s.z; t[kWzz] = wsz * s.z;
-                t[kWrx] = w * rx; t[kWry] = w * ry; t[kWrz] = w * rz;
-                t[kWcx] = w * (s.y * rz - s.z * ry);
-                t[kWcy] = w * (s.z * rx - s.x * rz);
-                t[kWcz] = w * (s.x * ry - s.y * rx);
-            }
-        }
-        const unsigned pairs = static_cast<unsigned>(__popcll(__ballot(use)));
-        // the wave's sums in a fixed order: four DPP exchanges inside the rows of 16 lanes, the four rows
-        double *ws = reinterpret_cast<double *>(smem + kWgSums) + wv * kCount;
-#pragma unroll
-        for (int c = 0; c < kCount; ++c) {
-            double v = t[c];
-            v += dpp_f64<kDppXor1>(v);
-            v += dpp_f64<kDppXor2>(v);
-            v += dpp_f64<kDppHalfMirror>(v);
-            v += dpp_f64<kDppMirror>(v);
-            const double tot = (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
-            if (lane == 0) ws[c] = tot;
-        }
-        if (lane == 0) smem[kWgPairs + wv] = pairs;
-        wave_sums_to_digits(ws, smem + kWgPairs + wv, digits, flag);
-        if (P.counters) {                      // C_q of the kept queries (the candidates a search would have met)
-            unsigned c = keep ? S.cq : 0u;
-            c += dpp_u32<kDppXor1>(c);
-            c += dpp_u32<kDppXor2>(c);
-            c += dpp_u32<kDppHalfMirror>(c);
-            c += dpp_u32<kDppMirror>(c);
-            unsigned a = 0u;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a += static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(c), 16 * r));
-            if (lane == 0 && wave_id < P.nwaves)
-                (void)__hip_atomic_fetch_add(&P.counters[2u * wave_id], static_cast<unsigned long long>(a),
-                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    // the others, in query order
-    const unsigned long long ab = __ballot(act);
-    const unsigned listed = static_cast<unsigned>(__popcll(ab));
-    if (act) list[static_cast<unsigned>(__popcll(ab & ((1ull << lane) - 1ull)))] = q;
-    if (P.counters && lane == 0 && listed)     // searches run (64 slots behind the per-wave counters)
-        (void)__hip_atomic_fetch_add(&P.counters[2u * P.nwaves + (wave_id & 63u)], static_cast<unsigned long long>(listed),
-                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_wave_barrier();
-
-    // ---- phase B: the listed queries are searched -----------------------------------------------------------
-    for (unsigned base = 0u; base < listed; base += QW) {
-        const SkipCtx sk{list, base, listed};
-        (void)icp_body<LW, true, FILT, 2>(P, smem, nullptr, nullptr, kIcpWavesPerBlock, &sk);
-        wave_sums_to_digits(reinterpret_cast<const double *>(smem + kWgSums) + wv * kCount, smem + kWgPairs + wv,
-                            digits, flag);
-    }
-    if (lane < 3 * kAccValues && P.acc) {
-        long long *dst = P.acc + static_cast<size_t>(wave_id & (kAccReplicas - 1)) * kAccWords;
-        const long long x = digits[lane];
-        if (*flag) (void)__hip_atomic_fetch_or(P.acc + kAccWords - 1, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else if (x) (void)__hip_atomic_fetch_add(dst + lane, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
 }
 
 // ------------------------------------------------------------------------------------ WaveLanes
@@ -2193,9 +1949,6 @@ __global__ __launch_bounds__(1024) void k_sum_counters(const unsigned long long 
         }
         st->sum_candidates = t;
         st->sum_pairs = u;
-        unsigned long long sr = 0;
-        for (int i = 0; i < 64; ++i) sr += c[2 * n + i];       // k_skip's searches
-        st->sum_searched = sr;
     }
 }
 
@@ -2303,32 +2056,6 @@ void launch_loop(const IcpParams &p, const LoopParams &l, int lw, int grid, hipS
             if (p.filter) hipLaunchKernelGGL((k_loop<4, true>), g, b, lds, s, p, l);
             else hipLaunchKernelGGL((k_loop<4, false>), g, b, lds, s, p, l);
             break;
-    }
-}
-
-int skip_blocks_for(int n, int lw) {
-    const long per_wg = static_cast<long>(skip_queries_per_wave(lw)) * kIcpWavesPerBlock;
-    const long blocks = (static_cast<long>(n) + per_wg - 1) / per_wg;
-    const long per_round = 8L * SAGE_ICP_STRIPE;
-    const long r = ((blocks + per_round - 1) / per_round) * per_round;
-    return static_cast<int>(r < per_round ? per_round : r);
-}
-size_t skip_lds_bytes(int lw) { return sizeof(uint32_t) * (skip_wave_word(lw) + kIcpWavesPerBlock * kSkWaveWords); }
-template <int LW>
-static void launch_skip_lw(const IcpParams &p, hipStream_t s) {
-    const dim3 g(skip_blocks_for(p.n, LW)), b(64 * kIcpWavesPerBlock);
-    const size_t lds = skip_lds_bytes(LW);
-    if (p.filter) hipLaunchKernelGGL((k_skip<LW, true>), g, b, lds, s, p);
-    else hipLaunchKernelGGL((k_skip<LW, false>), g, b, lds, s, p);
-}
-void launch_skip(const IcpParams &p, int lw, hipStream_t s) {
-    if (p.n <= 0) return;
-    switch (lw) {
-        case 0: launch_skip_lw<0>(p, s); break;
-        case 1: launch_skip_lw<1>(p, s); break;
-        case 2: launch_skip_lw<2>(p, s); break;
-        case 3: launch_skip_lw<3>(p, s); break;
-        default: launch_skip_lw<4>(p, s); break;
     }
 }
 

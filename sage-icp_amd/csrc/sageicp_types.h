@@ -156,7 +156,6 @@ struct IcpState {
     double sums[kNumSums];          // last reduced GN sums (diagnostics / multi-GPU exchange)
     unsigned long long sum_candidates;  // sum over launches and queries of C_q (roofline bytes)
     unsigned long long sum_pairs;       // (query, candidate) pairs k_icp actually scanned
-    unsigned long long sum_searched;    // k_skip: queries searched (the others kept their answer), all iterations
     uint32_t n_corr[kHistory];      // accepted correspondences per iteration (all ranks)
     IcpProgress *progress;          // host-mapped progress block (nullptr: not published)
     int32_t exchange_failed;        // a peer's sums did not arrive in time (multi-GPU direct exchange)
