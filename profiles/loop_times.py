@@ -74,3 +74,20 @@ if hasattr(sage.lib(), "sageicp_debug_loop_info"):
         q = np.quantile(sm, [0.2, 0.4, 0.6, 0.8])
         b = np.digitize(sm, q)
         print("   search time by quintile of the workgroup's points: " + " ".join("%.2f" % dur[b == k].mean() for k in range(5)))
+
+# ---- where a wave's iteration goes (cycles per phase, mean over all waves and iterations)
+if hasattr(sage.lib(), "sageicp_debug_loop_phases"):
+    ph = np.zeros(16, dtype=np.uint64)
+    sage.lib().sageicp_debug_loop_phases(ph.ctypes.data_as(C.c_void_p), 1)
+    pose, st = sage.register_frame(f, w["map"], sage.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"], return_stats=True)
+    sage.lib().sageicp_debug_loop_phases(ph.ctypes.data_as(C.c_void_p), 1)
+    k = float(ph[10]) or 1.0
+    names = ["pose, query, home voxel", "row rebuild (stale), face gaps", "seed, home-only scan (unseeded)", "bounds -> need mask",
+             "scan", "argmin", "answer's record (if changed)", "pair terms, wave reduction, ticket"]
+    ghz = 2.1
+    print("mean over %d wave-iterations, us at %.1f GHz (s_memtime cycles):" % (int(k), ghz))
+    for i, nm in enumerate(names):
+        print("   %-38s %6.2f" % (nm, ph[i] / k / ghz / 1e3))
+    print("   %-38s %6.2f   (sum of the above)" % ("body", ph[:8].sum() / k / ghz / 1e3))
+    print("   %-38s %6.2f   (last wave of a workgroup only: sums -> accumulators, atomics acknowledged, count)" % ("closing the workgroup", ph[9] / k / ghz / 1e3 * (st.lanes_per_query and 1)))
+    print("   %-38s %6.2f   (barrier: the workgroup's poller has the next pose)" % ("waiting", ph[8] / k / ghz / 1e3))

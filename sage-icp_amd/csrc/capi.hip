@@ -1384,6 +1384,10 @@ static bool plan_loop(const sageicp_map *m, uint64_t n, double sem_th, LoopPlan 
 // The ICP loop of Registration.cpp:127-138 as a stream of launches: k_icp (search + accumulation)
 // and k_fin (reduce, solve, compose, test) per iteration — or, for a frame that fits the machine
 // and is not sharded over GPUs, as ONE launch (k_loop).
+// (set while a frame whose sums left the range of the fixed-point accumulators is registered again
+// with one fp64 partial per workgroup — see the end of run_icp)
+static thread_local bool g_fp64_partials = false;
+
 int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const double init[7],
             double max_dist, double kernel, double sem_th, sageicp_comm *comm, double out[7],
             sageicp_stats *stats, double us_upload, double t_begin) {
@@ -1413,7 +1417,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
 
     int lw = icp_lw(n, sparse_voxels(m));
     LoopPlan plan{};
-    bool use_loop = !comm && plan_loop(m, n, sem_th, &plan);
+    bool use_loop = !comm && !g_fp64_partials && plan_loop(m, n, sem_th, &plan);
     if (use_loop) lw = plan.lw;
     const int blocks = n ? icp_blocks_for(static_cast<int>(n), lw) : 1;
     if ((rc = ensure_cand(m, wants_filter(m, n, sem_th)))) return rc;
@@ -1498,7 +1502,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     // reads in one round trip; SAGEICP_PARTIALS=1 keeps the older form — one fp64 partial per
     // workgroup, reduced by k_fin (big frames: k_red folds them into a few rows first) — for
     // comparisons.
-    const bool use_acc = env_int("SAGEICP_PARTIALS", 0) == 0;
+    const bool use_acc = env_int("SAGEICP_PARTIALS", 0) == 0 && !g_fp64_partials;
     if (use_acc) HIPCHK(hipMemsetAsync(sc.d_acc, 0, sizeof(long long) * kAccReplicas * kAccWords, s));
     ip.acc = use_acc ? sc.d_acc : nullptr;
     const int red_rows = (n && !use_acc) ? red_rows_for(blocks) : 0;
@@ -1616,6 +1620,15 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     const IcpState &st = *sc.h_state;
     if (st.bad_input)
         return fail(SAGEICP_ERR_INVALID, "the frame holds a coordinate or label that is not finite (NaN / Inf)");
+    if (st.acc_overflow && !comm && !g_fp64_partials) {
+        // |sum over a wave| >= 2^50: georeferenced coordinates (UTM: ~3e6 m, s^2 x 64 queries) do that.
+        // The reference has no such limit: the frame is registered again with the fp64 partials of
+        // round 2 (one per workgroup, reduced by k_fin in a fixed order) — slower, not wrong.
+        g_fp64_partials = true;
+        const int rc2 = run_icp(m, d_frame, n, init, max_dist, kernel, sem_th, comm, out, stats, us_upload, t_begin);
+        g_fp64_partials = false;
+        return rc2;
+    }
     if (st.acc_overflow)
         return fail(SAGEICP_ERR_CAPACITY, "a Gauss-Newton sum left the range of the fixed-point accumulators "
                                           "(|sum over a wave| >= 2^50: coordinates beyond ~10^6 m, or a pose guess that is not finite)");

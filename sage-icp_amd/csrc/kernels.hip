@@ -380,7 +380,15 @@ struct LoopLane {
     uint2 prev;
     int kx, ky, kz;
     unsigned occ;
+#ifdef SAGE_LOOP_TIMING
+    unsigned long long ph[8], tprev;           // probe builds: cycles per phase of the body, summed over the iterations
+#endif
 };
+#ifdef SAGE_LOOP_TIMING
+#define LP_T(i) do { if constexpr (PERSIST) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); LL->ph[i] += _t - LL->tprev; LL->tprev = _t; } } while (0)
+#else
+#define LP_T(i) do { } while (0)
+#endif
 constexpr int kLoopMaxWaves = kLoopMaxWavesHost;   // waves per workgroup of k_loop (<= 512 threads)
 constexpr unsigned kLoopStripe = 4;          // workgroups of k_loop per XCD stripe (its grid: 32 k + 1 workgroups)
 constexpr int kNoVoxel = 0x7FFFFFFF;        // a home voxel no point has (|index| < 2^20): row not built yet
@@ -540,6 +548,7 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
                                  static_cast<uint32_t>(s.kz) != rk.z);
     unsigned occ = rk.w;
     NN_T(0);
+    LP_T(0);
     if constexpr (!PERSIST) {
         // stage the row in LDS (a stale one is overwritten below)
         auto stage = [&](int k, const uint4 &v) {
@@ -691,6 +700,7 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
         gaps(s.z, s.kz, gz);
     }
     NN_T(1);
+    LP_T(1);
 
     // ---- search -----------------------------------------------------------------------------------
     // closest_distance2 starts at numeric_limits<double>::max() (VoxelHashMap.cpp:80); the value
@@ -936,6 +946,7 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
         scan(occ & (1u << kHome), nullptr, false, 0u);
     }
     NN_T(2);
+    LP_T(2);
     // what the query holds after its home voxel (or its seed) bounds the rest of its search
     const double bound = seg_min_f64<W>(best);
     fb = bound;                                // (set_thresholds runs at the start of the scan)
@@ -970,7 +981,9 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
             need |= (lb <= bound) ? (1u << v) : 0u;
         }
     }
+    LP_T(3);
     scan((merged ? (need | (1u << kHome)) : (need & ~(1u << kHome))) & occ, nullptr, false, 0u);
+    LP_T(4);
 
     // argmin over the W lanes of the query: first the minimum distance (never NaN: a NaN distance
     // fails every comparison), then the smallest key among the lanes that hold it; the winner's
@@ -982,6 +995,7 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
     const unsigned woff = (lrow[found ? mkey >> 8 : 0u] >> 8) * (kUnitPoints * 32u) +
                           ((mkey & 255u) << SH);
     NN_T(3);
+    LP_T(5);
 
     if (P.counters) {                          // C_q and pairs handed out, summed over the wave
         // (both fit 16 bits per query: one packed value goes through the four DPP exchanges inside
@@ -1029,6 +1043,7 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
             }
             LL->pp = g;
             LL->prev = make_uint2(found ? mkey : 0xFFFFFFFFu, woff);
+            LP_T(6);
         }
 #ifdef SAGE_NN_TIMING
         if (valid && ci == 0u && P.work) P.work[q] = npairs;
@@ -1101,6 +1116,7 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
             }
         }
 #endif
+        LP_T(7);
         if constexpr (PERSIST) {
             // k_loop finishes the iteration itself (wg_sums_to_acc, arrival, solve)
             const bool last = prior == static_cast<unsigned>(nw) - 1u;
@@ -1532,8 +1548,16 @@ constexpr int kLoopTimedIters = 64, kLoopTimedWgs = 512;
 __device__ unsigned long long g_loop_wg[kLoopTimedIters][kLoopTimedWgs][2];
 __device__ unsigned g_loop_wginfo[kLoopTimedIters][kLoopTimedWgs][4];     // HW_ID | max points of a query | stale queries | points
 __device__ unsigned long long g_loop_solver[kLoopTimedIters][4];
+__device__ unsigned long long g_loop_phase[16];     // [0..7] cycles per body phase, [8] wait for the pose, [9] closing a workgroup, [10] wave-iterations
 #define LOOP_STAMP_SOLVER(it, k) do { if ((it) < kLoopTimedIters && (threadIdx.x & 63u) == 0u) g_loop_solver[it][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define LOOP_STAMP_WG(it, k) do { if ((it) < kLoopTimedIters && blockIdx.x < kLoopTimedWgs && (threadIdx.x & 63u) == 0u) g_loop_wg[it][blockIdx.x][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" void sageicp_debug_loop_phases(unsigned long long *out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_loop_phase), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_loop_phase), z, sizeof(z));
+    }
+}
 extern "C" void sageicp_debug_loop_info(unsigned *info) {
     (void)hipMemcpyFromSymbol(info, HIP_SYMBOL(g_loop_wginfo), sizeof(unsigned) * kLoopTimedIters * kLoopTimedWgs * 4);
 }
@@ -1733,9 +1757,20 @@ void k_loop(IcpParams P, LoopParams L) {
         LL.occ = 0u;
     }
     __syncthreads();
+#ifdef SAGE_LOOP_TIMING
+    for (int i = 0; i < 8; ++i) LL.ph[i] = 0;
+    unsigned long long t_wait = 0, t_close = 0, n_it = 0;
+#endif
 
     for (int it = 0;; ++it) {
+#ifdef SAGE_LOOP_TIMING
+        LL.tprev = __builtin_amdgcn_s_memtime();
+        ++n_it;
+#endif
         const bool last = icp_body<LW, true, FILT, true>(P, smem, &LL, s_pose, nw);
+#ifdef SAGE_LOOP_TIMING
+        const unsigned long long t_a = __builtin_amdgcn_s_memtime();
+#endif
         if (last) {
             // this wave closes the workgroup's iteration
             wg_sums_to_acc(reinterpret_cast<const double *>(smem + kLpSums), smem + kLpPairs, nw,
@@ -1790,9 +1825,24 @@ void k_loop(IcpParams P, LoopParams L) {
             }
             LOOP_STAMP_WG(it, 1);
         }
+#ifdef SAGE_LOOP_TIMING
+        const unsigned long long t_b = __builtin_amdgcn_s_memtime();
+        if (last) t_close += t_b - t_a;
+#endif
         __syncthreads();
+#ifdef SAGE_LOOP_TIMING
+        t_wait += __builtin_amdgcn_s_memtime() - t_b;
+#endif
         if (smem[kLpDone]) break;
     }
+#ifdef SAGE_LOOP_TIMING
+    if (lane == 0) {
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_loop_phase[i], LL.ph[i]);
+        atomicAdd(&g_loop_phase[8], t_wait);
+        atomicAdd(&g_loop_phase[9], t_close);
+        atomicAdd(&g_loop_phase[10], n_it);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------ k_gn

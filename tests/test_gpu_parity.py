@@ -904,3 +904,25 @@ def test_c5_full_size_properties(gpu_sage, oracle, params):
     assert dt < 1e-7 and dr < 1e-7 and st.iterations == ost.iterations
     assert st.n_corr_first == ost.n_corr_first and st.n_corr_last == ost.n_corr_last
     assert st.sum_candidates == ost.sum_candidates_total
+
+
+def test_sums_beyond_the_fixed_point_range_fall_back_to_fp64_partials(gpu_sage, oracle, monkeypatch):
+    """|sum over a wave| >= 2^50 (coordinates of millions of metres: georeferenced clouds) does not fit
+    the fixed-point accumulators; the reference has no such limit, so the frame is registered again
+    through the fp64 partials of round 2 instead of failing — the same answer as asking for them"""
+    monkeypatch.setenv("SAGEICP_LW", "1")                    # 32 queries per wave
+    rng = np.random.default_rng(3)
+    off = np.array([8.0e6, -3.0e6, 0.0, 0.0])
+    mp = rng.uniform(-60, 60, size=(30000, 4))
+    mp[:, 2] = rng.uniform(-2, 2, 30000)
+    mp[:, 3] = rng.choice([0, 40, 50], 30000)
+    q = mp[rng.choice(30000, 4000, replace=False)] + [0.3, -0.2, 0.05, 0]
+    m = gpu_sage.VoxelHashMap(8.0, 1e9)
+    m.AddPoints(mp + off)
+    frame = np.ascontiguousarray(q + off)
+    pose, st = gpu_sage.register_frame(frame, m, gpu_sage.IDENTITY, 6.0, 0.5, 0.4, return_stats=True)
+    assert st.iterations >= 1 and np.all(np.isfinite(pose))
+    monkeypatch.setenv("SAGEICP_PARTIALS", "1")
+    monkeypatch.setenv("SAGEICP_LOOP", "0")
+    ref, sr = gpu_sage.register_frame(frame, m, gpu_sage.IDENTITY, 6.0, 0.5, 0.4, return_stats=True)
+    assert np.array_equal(pose, ref) and st.iterations == sr.iterations
