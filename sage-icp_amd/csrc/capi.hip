@@ -1362,6 +1362,7 @@ static bool plan_loop(const sageicp_map *m, uint64_t n, double sem_th, LoopPlan 
     nw = std::max(nw, std::min(kLoopMaxWavesHost, std::max(1, env_int("SAGEICP_LOOP_WAVES", 4))));
     if (nw > kLoopMaxWavesHost) return false;
     const uint64_t wgs = ((waves + nw - 1) / nw + 31) / 32 * 32;
+    if (wgs / 8 > 255) return false;                   // (a word of the accumulators counts its workgroups in 8 bits)
     // (cached per shape: the occupancy query costs microseconds)
     static std::mutex mu;
     static std::map<int, int> cache;

@@ -138,16 +138,16 @@ void launch_red(const RedParams &p, hipStream_t s);
 // ---- k_loop: the whole ICP loop of a frame that fits the machine in ONE launch -----------------
 // Every wave keeps its queries (frame point, previous answer and its record in registers, the
 // neighbourhood row in LDS) for the whole call; an iteration ends with the workgroups adding their
-// sums into the fixed-point accumulators and counting themselves in, the last wave of workgroup 0
-// solving and publishing the next pose, and one wave per workgroup waiting for it — no kernel
-// boundary, no k_fin, L2s that stay warm.  Everything the workgroups share inside the launch is
+// sums into fixed-point accumulators whose words count their contributors, a one-wave solving workgroup
+// reading them when they are complete, solving and publishing the next pose, and one wave per
+// workgroup waiting for it — no kernel boundary, no k_fin, L2s that stay warm.  Everything the workgroups share inside the launch is
 // accessed with agent-scope atomics only (per-XCD L2s are not coherent with each other); the block
 // is zeroed before every launch.
 constexpr int kLoopReplicas = 8;           // accumulator copies (workgroup b adds into copy b & 7)
 constexpr int kLoopPoseGranules = 25;      // R[9], t[3] as 24 x {tag, 32 bits} + {tag, done}
 struct LoopShared {
-    long long acc[2][kLoopReplicas][kAccWords];         // as FinParams::acc, one set per iteration parity; word 63 of copy 0: overflow flag
-    unsigned long long arrive[kLoopReplicas][16];       // [r][0]: workgroups counted in, all iterations (one per 128-B line)
+    long long acc[2][kLoopReplicas][kAccWords];         // as FinParams::acc, one set per iteration parity, every word
+                                                        // (digit << 8) | workgroups in it; word 63 of copy 0: overflow flag
     unsigned long long pose[32];                        // granules (tag << 32) | payload, tag = iteration + 1
     unsigned long long abort_word[16];                  // [0] != 0: a wait timed out somewhere — everybody leaves
 };

@@ -337,6 +337,14 @@ __host__ __device__ constexpr unsigned icp_wave_words(int lw) {
 // arrival, not on the waves per workgroup, not on which loop (k_icp + k_fin or k_loop) ran.
 // `ws` = [nw][16] fp64 sums of the workgroup's waves, `pairs` = [nw] accepted pairs (LDS); `dst` = the
 // replica this workgroup adds into.
+// COUNTED (k_loop): every word also counts its contributions — a workgroup adds (digit << 8) + 1, the low
+// byte of a word says how many workgroups are in it — so that whoever reads the accumulators inside the
+// launch knows, word by word, when they are complete, and the workgroup neither waits for its atomics to
+// be acknowledged nor keeps a separate arrival counter (that wait was 3.8 us at the tail of every
+// iteration, profiles/r04/loop_phases.txt).  The digits get 8 bits less room for it: a wave's sum has to
+// stay below 2^44 (coordinates of a few 10^5 m); beyond, the overflow flag sends the frame through the fp64
+// partials (capi.hip), as everywhere.
+template <bool COUNTED = false>
 __device__ __forceinline__ void wg_sums_to_acc(const double *ws, const uint32_t *pairs, int nw, long long *dst,
                                                long long *overflow) {
     const int lane = static_cast<int>(threadIdx.x & 63u);
@@ -353,7 +361,7 @@ __device__ __forceinline__ void wg_sums_to_acc(const double *ws, const uint32_t 
             const double b = __builtin_rint(r1);
             const double c2 = __builtin_rint((r1 - b) * 1099511627776.0);
             const double d = digit == 0 ? a : (digit == 1 ? b : c2);
-            ok &= fabs(a) < 1125899906842624.0;                       // 2^50 (coordinates of 10^6 m stay far below)
+            ok &= fabs(a) < (COUNTED ? 17592186044416.0 : 1125899906842624.0);    // 2^44 / 2^50 (coordinates of 10^6 m stay far below 2^50)
             // integer of magnitude < 2^51 held in a double -> int64 through the 2^52 + 2^51 trick
             // (both numbers lie in [2^52, 2^53): their bit patterns differ by exactly d)
             x += __double_as_longlong(d + 6755399441055744.0) - 0x4338000000000000ll;
@@ -364,8 +372,13 @@ __device__ __forceinline__ void wg_sums_to_acc(const double *ws, const uint32_t 
         x = static_cast<long long>(n);
     }
     if (lane < 3 * kAccValues) {
-        if (ok) (void)__hip_atomic_fetch_add(dst + lane, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else (void)__hip_atomic_fetch_or(overflow, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (COUNTED) {
+            (void)__hip_atomic_fetch_add(dst + lane, ok ? x * 256 + 1 : 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!ok) (void)__hip_atomic_fetch_or(overflow, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (ok) (void)__hip_atomic_fetch_add(dst + lane, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else (void)__hip_atomic_fetch_or(overflow, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -1096,10 +1109,16 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
             if (lane == 0) smem[(PERSIST ? kLpPairs : kWgPairs) + wv] = pairs;
         }
         // Workgroup partial: the last wave to arrive adds the four rows in wave order.
+        // (what the ticket orders — the waves' sums — lives in LDS, which serves a CU's waves in order: the
+        // ticket is a relaxed LDS atomic between compiler barriers.  An acquire-release one made every wave
+        // wait for its outstanding GLOBAL traffic first — the counters' fire-and-forget atomics, the nn_prev
+        // store —: 1.5 us at the tail of a wave of k_loop, profiles/r04/loop_phases.txt.)
         unsigned prior = 0u;
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
         if (lane == 0)
-            prior = __hip_atomic_fetch_add(&smem[PERSIST ? kLpArrive : kWgArrive], 1u, __ATOMIC_ACQ_REL,
+            prior = __hip_atomic_fetch_add(&smem[PERSIST ? kLpArrive : kWgArrive], 1u, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
         prior = __builtin_amdgcn_readfirstlane(prior);
 #ifdef SAGE_LOOP_TIMING
         if constexpr (PERSIST) {
@@ -1120,11 +1139,9 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
         if constexpr (PERSIST) {
             // k_loop finishes the iteration itself (wg_sums_to_acc, arrival, solve)
             const bool last = prior == static_cast<unsigned>(nw) - 1u;
-            if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             return last;
         }
         if (prior == kIcpWavesPerBlock - 1u && P.acc) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             wg_sums_to_acc(reinterpret_cast<const double *>(smem + kWgSums), smem + kWgPairs, kIcpWavesPerBlock,
                            P.acc + static_cast<size_t>(blockIdx.x & (kAccReplicas - 1)) * kAccWords,
                            P.acc + kAccWords - 1);
@@ -1526,12 +1543,12 @@ __global__ __launch_bounds__(kFinThreads) void k_fin(FinParams P) {
 // The whole loop of Registration.cpp:127-138 in one launch (kernels.h, LoopShared).  Per iteration:
 //   every wave        icp_body<PERSIST> on the queries it keeps — pose from LDS, state in registers,
 //                     rows in LDS — and parks its sums in the workgroup's LDS header;
-//   last wave of a    adds the workgroup's sums into the fixed-point accumulators, waits until its
-//   workgroup         atomics are performed (vmcnt) and counts the workgroup in;
-//   the solving       (one wave, the last workgroup of the grid, no queries) waits for every workgroup's
-//   workgroup         count, reads this iteration's set of accumulators (two sets alternate; the one just
-//                     read is cleared for the iteration after the next), solves, composes, tests, and
-//                     publishes the next pose as 25
+//   last wave of a    adds the workgroup's sums into the fixed-point accumulators: (digit << 8) + 1 per
+//   workgroup         word, fire and forget — the low byte of every word counts who is in it;
+//   the solving       (one wave, the last workgroup of the grid, no queries) reads this iteration's set of
+//   workgroup         accumulators until every word counts all its workgroups (two sets alternate; the one
+//                     just read is cleared for the iteration after the next), solves, composes, tests,
+//                     and publishes the next pose as 25
 //                     self-tagged 8-byte granules (tag = iteration + 1: the data is the flag, no fence
 //                     on either side);
 //   wave 0 of every   polls the granules (one relaxed agent-scope load per lane and pass), hands the
@@ -1589,18 +1606,29 @@ __device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, u
     long long *digits = reinterpret_cast<long long *>(smem + kLpDigits);
     const unsigned long long tag = static_cast<unsigned long long>(it) + 1ull;
 
-    // 1. every workgroup has counted itself in for this iteration (its sums are in the accumulators)
+    // 1. the sums of this iteration's set of accumulators: read (one round trip per pass) until every word
+    // says that all the workgroups adding into it are in (its low byte counts them, wg_sums_to_acc) —
+    // the read that finds them complete IS the read of the sums.  The set is then cleared for the
+    // iteration after the next (the clears are complete long before that pose is published: the waits
+    // of the next iteration's passes cover them).
     {
         // (the grid is 8 k query workgroups + this one: k of them add into each copy)
-        const unsigned long long per = (static_cast<unsigned long long>(gridDim.x) - 1ull) >> 3;
-        const unsigned long long target = tag * per;
+        const long long per = static_cast<long long>((gridDim.x - 1u) >> 3);
+        long long (*acc)[kAccWords] = sh->acc[it & 1];
+        long long v[kLoopReplicas];
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         for (;;) {
+#pragma unroll
+            for (int r = 0; r < kLoopReplicas; ++r)
+                v[r] = __hip_atomic_load(&acc[r][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             bool ok = true;
-            unsigned long long ab = 0ull;
-            if (lane < kLoopReplicas) ok = ld_agent(&sh->arrive[lane][0]) >= target;
-            else if (lane == kLoopReplicas) ab = ld_agent(&sh->abort_word[0]);
+            if (lane < 3 * kAccValues) {
+#pragma unroll
+                for (int r = 0; r < kLoopReplicas; ++r) ok &= (v[r] & 255ll) == per;
+            }
             if (__all(ok)) break;
+            unsigned long long ab = 0ull;
+            if (lane == 0) ab = ld_agent(&sh->abort_word[0]);
             const bool late = __builtin_amdgcn_s_memrealtime() - t0 > L.timeout_ticks;
             if (__any(ab != 0ull) || late) {
                 if (lane == 0) {
@@ -1612,20 +1640,15 @@ __device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, u
             }
             __builtin_amdgcn_s_sleep(1);
         }
-    }
-    LOOP_STAMP_SOLVER(it, 0);
-    // 2. the sums of this iteration's set of accumulators (one round trip), which is then cleared for
-    // the iteration after the next (the clears are complete long before that pose is published: the
-    // wait for the next iteration's loads covers them)
-    {
-        long long (*acc)[kAccWords] = sh->acc[it & 1];
-        long long v[kLoopReplicas];
-#pragma unroll
-        for (int r = 0; r < kLoopReplicas; ++r)
-            v[r] = __hip_atomic_load(&acc[r][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        LOOP_STAMP_SOLVER(it, 0);
         long long d = 0;
+        if (lane < 3 * kAccValues) {
 #pragma unroll
-        for (int r = 0; r < kLoopReplicas; ++r) d += v[r];
+            for (int r = 0; r < kLoopReplicas; ++r) d += (v[r] - per) >> 8;       // (exact: the low byte is the count)
+        } else {
+#pragma unroll
+            for (int r = 0; r < kLoopReplicas; ++r) d += v[r];                    // (word 63: the overflow flag)
+        }
 #pragma unroll
         for (int r = 0; r < kLoopReplicas; ++r)
             __hip_atomic_store(&acc[r][lane], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1773,8 +1796,8 @@ void k_loop(IcpParams P, LoopParams L) {
 #endif
         if (last) {
             // this wave closes the workgroup's iteration
-            wg_sums_to_acc(reinterpret_cast<const double *>(smem + kLpSums), smem + kLpPairs, nw,
-                           &sh->acc[it & 1][blockIdx.x & (kLoopReplicas - 1)][0], &sh->acc[it & 1][0][kAccWords - 1]);
+            wg_sums_to_acc<true>(reinterpret_cast<const double *>(smem + kLpSums), smem + kLpPairs, nw,
+                                 &sh->acc[it & 1][blockIdx.x & (kLoopReplicas - 1)][0], &sh->acc[it & 1][0][kAccWords - 1]);
             if (lane == 0) smem[kLpArrive] = 0u;          // everybody is in: ready for the next iteration
 #ifdef SAGE_LOOP_TIMING
             if (lane == 0 && it < kLoopTimedIters && blockIdx.x < kLoopTimedWgs) {
@@ -1788,10 +1811,6 @@ void k_loop(IcpParams P, LoopParams L) {
                 smem[kLpDbg] = 0u; smem[kLpDbg + 1] = 0u; smem[kLpDbg + 2] = 0u;
             }
 #endif
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the adds are performed before the count
-            if (lane == 0)
-                (void)__hip_atomic_fetch_add(&sh->arrive[blockIdx.x & (kLoopReplicas - 1)][0], 1ull, __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_AGENT);
             LOOP_STAMP_WG(it, 0);
         }
         if (wv == 0) {
