@@ -627,9 +627,9 @@ def test_rccl_refuses_two_ranks_on_one_device():
     # typo or an out-of-memory somewhere else
     text = (run.stdout + run.stderr).lower()
     print(text[-6000:])                                      # (shown by pytest when the assertions below fail)
-    assert "sageicp error -4" in text or "ncclcomminitrank" in text or "sageicp_comm_create" in text, \
-        "bench.py --gpus 2 failed, but not where the RCCL communicator is created"
-    assert "duplicate gpu" in text or "invalid usage" in text or "invalid argument" in text or "nccl" in text
+    # (the first RCCL communicator of a rank is torch.distributed's own; RCCL names the reason itself)
+    assert "duplicate gpu detected" in text and "invalid usage" in text, \
+        "bench.py --gpus 2 failed, but not because RCCL refused two ranks on one device"
 
 
 def test_register_frame_through_rccl_comm_world1(gpu_sage, oracle):
