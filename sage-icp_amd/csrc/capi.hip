@@ -2066,6 +2066,22 @@ int sageicp_map_add_points(sageicp_map *m, const double *xyzl, uint64_t n) {
     if (!all_finite(xyzl, n))
         return fail(SAGEICP_ERR_INVALID, "AddPoints: a coordinate or label is not finite (NaN / Inf); nothing was inserted");
     if (int rc = ensure_host(m)) return rc;
+    // A voxel index out of range is found by a dry pass: nothing is inserted then (like non-finite input
+    // above).  Only the storage limits (2^24 voxels / 2^24 units of 4 points: 67 M point slots, DESIGN.md
+    // section 1) can still stop a call part-way — before the point that does not fit, the points before it
+    // in, the map consistent: which point that is depends on the retention policy's decisions on every
+    // point before it.
+    {
+        const double vs = m->host.voxel_size;
+        constexpr int32_t kLim = 1 << 20;
+        for (uint64_t i = 0; i < n; ++i) {
+            const int32_t vx = static_cast<int32_t>(xyzl[4 * i] / vs), vy = static_cast<int32_t>(xyzl[4 * i + 1] / vs),
+                          vz = static_cast<int32_t>(xyzl[4 * i + 2] / vs);
+            if (vx <= -kLim || vx >= kLim || vy <= -kLim || vy >= kLim || vz <= -kLim || vz >= kLim)
+                return fail(SAGEICP_ERR_CAPACITY, "AddPoints: voxel index beyond +-2^20 at point " + std::to_string(i) +
+                                                      "; nothing was inserted");
+        }
+    }
     uint64_t at = 0;
     const int why = m->host.add_points(xyzl, n, &at);     // limits are checked before a point is taken
     // every copy of a multi-device map takes exactly the points rank 0 took: all of them, or the

@@ -68,7 +68,8 @@
 #define SAGE_ICP_STRIPE 8      // workgroups of the sorted frame per XCD stripe
 #endif
 #ifndef SAGE_ICP_OCC
-#define SAGE_ICP_OCC 6         // waves per SIMD the register allocation of k_icp is held to
+#define SAGE_ICP_OCC 6         // waves per SIMD k_icp's register allocation must allow at least (<= 80 registers); the
+                               // variants that matter sit at 72 and run 7 (tools/resource_usage.sh)
 #endif
 // pairs of candidates a lane of k_loop keeps in flight while it scans: of full records / of compact ones
 #ifndef SAGE_LOOP_DEPTH_FULL

@@ -101,3 +101,17 @@ def test_pipeline_drops_nonfinite_coordinates_like_the_reference_and_refuses_non
     with pytest.raises(gpu_sage.SageIcpError) as e:
         a.RegisterFrame(bad)
     assert e.value.code == gpu_sage.ERR_INVALID
+
+
+def test_add_points_with_a_voxel_index_out_of_range_inserts_nothing(sage):
+    """|voxel index| >= 2^20 (a coordinate beyond ~10^6 voxels): refused before anything is taken"""
+    mp, _ = _scene()
+    m = sage.VoxelHashMap(1.0, 100.0)
+    m.AddPoints(mp[:1000])
+    before = m.Pointcloud()
+    pts = mp[1000:2000].copy()
+    pts[900, 0] = 2.0e6
+    with pytest.raises(sage.SageIcpError) as e:
+        m.AddPoints(pts)
+    assert e.value.code == sage.ERR_CAPACITY and "nothing was inserted" in str(e.value)
+    assert np.array_equal(m.Pointcloud(), before)
