@@ -119,6 +119,7 @@ struct Scratch {
     long long *d_acc = nullptr;    // fixed-point accumulators of the Gauss-Newton sums (kernels.h, kAcc*)
     LoopShared *d_loop = nullptr;  // what the workgroups of k_loop share inside its launch (kernels.h)
     int num_cus = 0;
+    int loop_cooldown = 0;         // calls that stay away from k_loop after one of its launches timed out
     unsigned long long *d_cand = nullptr;      // per-wave counters of k_icp [2 x sort_cap]
     IcpState *d_state = nullptr;
     IcpState *h_state = nullptr;   // pinned
@@ -1343,6 +1344,12 @@ static bool plan_loop(const sageicp_map *m, uint64_t n, double sem_th, LoopPlan 
     const Scratch &sc = m->sc;
     const int mode = env_int("SAGEICP_LOOP", 1);       // 0: never, 1: where it fits and pays, 2: wherever it fits
     if (mode == 0 || n == 0 || sc.num_cus < 8) return false;
+    // a launch that timed out (its grid was not resident as a whole: the GPU is shared with other work)
+    // cost 50 ms before the frame went through the other loop: the next calls do not try again
+    if (m->sc.loop_cooldown > 0) {
+        --m->sc.loop_cooldown;
+        return false;
+    }
     int lw = icp_lw(n, sparse_voxels(m));
     bool filter = wants_filter(m, n, sem_th);
     if (lw < 1) return false;                          // (k_loop is built for 2..16 lanes per query)
@@ -1476,6 +1483,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         } else if (sc.h_state->loop_aborted || !sc.h_state->done) {
             // a wait inside the launch timed out (the grid was not resident as a whole: another stream
             // or process held CUs): the launch-per-iteration loop below registers the frame instead
+            sc.loop_cooldown = std::max(0, env_int("SAGEICP_LOOP_COOLDOWN", 256));
             fill_state(sc.h_state, init);
             if (polled) {
                 std::memset(sc.h_prog, 0, sizeof(IcpProgress));

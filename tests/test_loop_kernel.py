@@ -188,12 +188,21 @@ def test_timeout_inside_the_launch_falls_back(gpu_sage, oracle):
     p = syn.PARAMS["cold"]
     with Env(SAGEICP_LOOP=0):
         a = gpu_sage.register_frame(w["scan"], w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"])
-    with Env(SAGEICP_LOOP=2, SAGEICP_LOOP_TIMEOUT_TICKS=1):
+    with Env(SAGEICP_LOOP=2, SAGEICP_LOOP_TIMEOUT_TICKS=1, SAGEICP_LOOP_COOLDOWN=2):
         b, sb = gpu_sage.register_frame(w["scan"], w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"],
                                         p["sem_th"], return_stats=True)
     assert np.array_equal(a, b)
     # (a tick is 10 ns: a wait that long never succeeds on a grid of this size)
     assert sb.single_launch == 0
+    # a map whose launch timed out stays away from k_loop for a while (here: two calls), then tries again
+    with Env(SAGEICP_LOOP=2):
+        forms = []
+        for _ in range(3):
+            c, sc = gpu_sage.register_frame(w["scan"], w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"],
+                                            p["sem_th"], return_stats=True)
+            assert np.array_equal(a, c)
+            forms.append(sc.single_launch)
+    assert forms == [0, 0, 1]
 
 
 def test_streamed_frames_through_the_pipeline(gpu_sage, oracle):
