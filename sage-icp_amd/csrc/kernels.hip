@@ -341,8 +341,10 @@ __host__ __device__ constexpr unsigned icp_wave_words(int lw) {
 // COUNTED (k_loop): every word also counts its contributions — a workgroup adds (digit << 8) + 1, the low
 // byte of a word says how many workgroups are in it — so that whoever reads the accumulators inside the
 // launch knows, word by word, when they are complete, and the workgroup neither waits for its atomics to
-// be acknowledged nor keeps a separate arrival counter (that wait was 3.8 us at the tail of every
-// iteration, profiles/r04/loop_phases.txt).  The digits get 8 bits less room for it: a wave's sum has to
+// be acknowledged nor keeps a separate arrival counter.  (The form that did both — s_waitcnt vmcnt(0), then
+// one of eight counters — ran an iteration in the same time, profiles/r04/loop_times_counted_words.txt against
+// loop_times_xcd_stripes_rowshift.txt: this one is kept for having one protocol less and no ordering
+// assumption at all.)  The digits get 8 bits less room for it: a wave's sum has to
 // stay below 2^44 (coordinates of a few 10^5 m); beyond, the overflow flag sends the frame through the fp64
 // partials (capi.hip), as everywhere.
 template <bool COUNTED = false>
@@ -1111,9 +1113,9 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
         }
         // Workgroup partial: the last wave to arrive adds the four rows in wave order.
         // (what the ticket orders — the waves' sums — lives in LDS, which serves a CU's waves in order: the
-        // ticket is a relaxed LDS atomic between compiler barriers.  An acquire-release one made every wave
-        // wait for its outstanding GLOBAL traffic first — the counters' fire-and-forget atomics, the nn_prev
-        // store —: 1.5 us at the tail of a wave of k_loop, profiles/r04/loop_phases.txt.)
+        // ticket is a relaxed LDS atomic between compiler barriers.  An acquire-release one also waits for the
+        // wave's outstanding GLOBAL traffic — the counters' fire-and-forget atomics, the nn_prev store — which
+        // nothing here needs; measured, it made no difference to either loop.)
         unsigned prior = 0u;
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         if (lane == 0)
