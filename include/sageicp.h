@@ -108,6 +108,24 @@ void sageicp_map_destroy(sageicp_map *map);
  * environment variable SAGEICP_DEVICES=0,1,2,3 applies the same to every map the process creates. */
 int sageicp_map_set_devices(sageicp_map *map, const int *devices, int n);
 int sageicp_map_num_devices(const sageicp_map *map);
+/* Reference-order mode (off by default; the map must be empty when it is switched).  The search never
+ * depends on the iteration order of the reference's tsl::robin_map (core/VoxelHashMap.hpp:106), but two
+ * things a caller can observe do: RemovePointsFarFromLocation erases WHILE iterating the container
+ * (VoxelHashMap.cpp:176-184), so the voxel that the backward-shift deletion moves into the bucket just
+ * erased is skipped and survives until a later frame, and Pointcloud() lists the voxels in bucket order
+ * (:132-142).  By default this library removes every far voxel and lists block-pool order.  With the
+ * mode on, the map also keeps the bucket array the reference's container would have (robin_map v1.0.1:
+ * growth from zero buckets at load 0.5, robin-hood displacement, backward-shift deletion, clear() keeps
+ * the array, the reference's 20-bit VoxelHash) and both behaviours are the reference's.  Such a map is
+ * maintained on the host (sageicp_map_update_pose_device and the pipeline fall back to the host update:
+ * ~3 ms instead of ~0.3 ms per streamed frame).  SAGEICP_MAP_REFERENCE_ORDER=1 applies the mode to every
+ * map the process creates (for callers behind the header shim).
+ * sageicp_map_reference_order: 0 off; 1 on; -1 on, but an insertion met a probe distance the emulation
+ * does not model (>= 128: not before a map holds several 10^5 voxels, where the reference's own table
+ * degenerates with its 20-bit hash) — the map works, its order is no longer claimed to be the
+ * reference's. */
+int sageicp_map_set_reference_order(sageicp_map *map, int on);
+int sageicp_map_reference_order(const sageicp_map *map);
 /* copy construction / copy assignment (ros/ros2/OdometryServer.cpp:104 copy-assigns the pipeline) */
 sageicp_map *sageicp_map_clone(const sageicp_map *map);
 int sageicp_map_clear(sageicp_map *map);                    /* Clear(), VoxelHashMap.hpp:93 */
@@ -131,7 +149,7 @@ int sageicp_map_update_pose(sageicp_map *map, const double *xyzl, uint64_t n,
 int sageicp_map_update_pose_device(sageicp_map *map, const double *xyzl, uint64_t n,
                                    const double pose[7]);
 /* Pointcloud(), VoxelHashMap.cpp:132-142.  Returns the number of points the map holds; writes
- * at most `cap` of them (block-pool order; the reference's is its hash map's bucket order).  While
+ * at most `cap` of them (block-pool order; a map in reference-order mode: the reference's bucket order).  While
  * the HBM copy is the authority (after a device-side update) the points are packed on the device
  * and only they cross PCIe: the map stays resident, the next RegisterFrame uploads nothing.
  * `out_xyzl` is typically a fresh allocation (the reference's Pointcloud() returns a new vector):

@@ -151,6 +151,7 @@ struct VoxelHash {
 //   * erase: clear the bucket, then shift the following entries back by one while their
 //     distance from home is > 0 (wrapping around the end of the array)
 //   * iteration: bucket 0 .. bucket_count-1, skipping empty ones
+//   * clear(): empties the buckets and keeps the array (no shrink with min load factor 0)
 // Not modelled: the growth forced by a probe distance beyond DIST_FROM_IDEAL_BUCKET_LIMIT (never
 // reached with <= 10^5 voxels per table).  Only the ORDER is emulated here; the payload is an
 // index into the caller's storage.
@@ -237,7 +238,8 @@ struct RobinOrder {
             }
         }
     }
-    void clear() { b.clear(); n = 0; }
+    // tsl::robin_map::clear() (min load factor 0): the buckets are emptied, the array stays
+    void clear() { std::fill(b.begin(), b.end(), Bucket()); n = 0; }
 };
 
 int g_robin_order = 0;     // sgo_set_robin_order: bit 0 = VoxelDownsample emission and Pointcloud() in bucket

@@ -133,6 +133,8 @@ _SIGNATURES = [
     ("sageicp_map_destroy", None, [C.c_void_p]),
     ("sageicp_map_set_devices", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
     ("sageicp_map_num_devices", C.c_int, [C.c_void_p]),
+    ("sageicp_map_set_reference_order", C.c_int, [C.c_void_p, C.c_int]),
+    ("sageicp_map_reference_order", C.c_int, [C.c_void_p]),
     ("sageicp_map_clone", C.c_void_p, [C.c_void_p]),
     ("sageicp_map_clear", C.c_int, [C.c_void_p]),
     ("sageicp_map_empty", C.c_int, [C.c_void_p]),
@@ -340,6 +342,17 @@ class VoxelHashMap:
         return VoxelHashMap(self.voxel_size_, self.max_distance_, self.basic_points_per_voxel_,
                             self.critical_points_per_voxel_, self.basic_parts_labels_,
                             self.device, _handle=h)
+
+    def set_reference_order(self, on=True):
+        """Reference-order mode (include/sageicp.h): the far-voxel sweep erases while iterating the
+        reference's robin_map bucket array and Pointcloud() lists the voxels in bucket order.  The map
+        must be empty."""
+        _check(lib().sageicp_map_set_reference_order(self._h, 1 if on else 0))
+        return self
+
+    def reference_order(self):
+        """0 off, 1 on, -1 on but beyond what the emulation models"""
+        return int(lib().sageicp_map_reference_order(self._h))
 
     def set_devices(self, devices):
         """single-process multi-GPU mode: the map spans these devices, RegisterFrame shards over them"""

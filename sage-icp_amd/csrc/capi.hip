@@ -1681,6 +1681,18 @@ int device_update_all(sageicp_map *m, const double *xyzl, uint64_t n, const doub
                       const Point4 *d_points) {
     if (m->replicas_diverged)
         return fail(SAGEICP_ERR_INVALID, "the copies of this multi-device map diverged in an earlier failed update: Clear() it");
+    if (m->host.track_order) {
+        // a reference-order map is maintained on the host (host_map.hpp: the bucket array of the
+        // reference's robin_map is host state); the device mirror follows by dirty ranges
+        std::vector<double> pts_host;
+        if (d_points) {
+            pts_host.resize(4 * n);
+            HIPCHK(hipSetDevice(m->device));
+            if (n) HIPCHK(hipMemcpy(pts_host.data(), d_points, n * sizeof(Point4), hipMemcpyDeviceToHost));
+            xyzl = pts_host.data();
+        }
+        return sageicp_map_update_pose(m, xyzl, n, pose);
+    }
     int rc = device_update(m, xyzl, n, pose, d_points);
     if (rc || m->replicas.empty()) return rc;       // (a failed device update changes nothing on its device)
     std::vector<double> host;
@@ -1908,7 +1920,26 @@ sageicp_map *sageicp_map_create(double voxel_size, double max_distance, int basi
             return nullptr;
         }
     }
+    // SAGEICP_MAP_REFERENCE_ORDER=1: every map of this process is created in reference-order mode (the
+    // knob for callers behind the header shim; sageicp_map_set_reference_order for everyone else)
+    if (env_int("SAGEICP_MAP_REFERENCE_ORDER", 0)) (void)sageicp_map_set_reference_order(m, 1);
     return m;
+}
+
+int sageicp_map_set_reference_order(sageicp_map *m, int on) {
+    if (!m) return fail(SAGEICP_ERR_INVALID, "null map");
+    if (!map_is_empty(m) || m->on_device)
+        return fail(SAGEICP_ERR_INVALID, "sageicp_map_set_reference_order: the map must be empty (the bucket order "
+                                         "records every insertion since construction)");
+    m->host.track_order = on != 0;
+    m->host.order = sageicp::RobinTable();          // zero buckets, like a default-constructed robin_map
+    for (sageicp_map *r : m->replicas)
+        if (int rc = sageicp_map_set_reference_order(r, on)) return rc;
+    return SAGEICP_OK;
+}
+int sageicp_map_reference_order(const sageicp_map *m) {
+    if (!m || !m->host.track_order) return 0;
+    return m->host.order.valid() ? 1 : -1;
 }
 
 int sageicp_map_set_devices(sageicp_map *m, const int *devices, int n) {

@@ -24,6 +24,12 @@
 // bucket order; the far-voxel sweep removes EVERY voxel whose first point is out of range
 // (the reference erases while iterating its robin_map, which may skip some until a later
 // frame).  The search itself (kernels.hip) never depends on either.
+// A map in REFERENCE-ORDER mode (`track_order`, set while the map is empty) keeps, next to all of
+// the above, the bucket array the reference's tsl::robin_map would have (robin_order.hpp
+// RobinTable, fed with every new voxel in arrival order): its sweep erases while iterating that
+// array, as VoxelHashMap.cpp:176-184 does — the voxel shifted into a bucket just erased survives
+// until a later frame —, and Pointcloud() lists the voxels in bucket order (:132-142).  Such a map
+// is maintained on the host only (capi.hip routes its updates here).
 #pragma once
 
 #include <algorithm>
@@ -37,6 +43,7 @@
 
 #include <sys/mman.h>
 
+#include "robin_order.hpp"
 #include "sageicp_types.h"
 
 namespace sageicp {
@@ -147,6 +154,8 @@ public:
     std::vector<uint32_t> dirty_pts;
     std::vector<uint32_t> dirty_slots;
     uint64_t generation = 0;          // bumps on every mutation
+    bool track_order = false;         // reference-order mode (see the header of this file)
+    RobinTable order;                 // block indices in the reference's bucket order (track_order only)
 
     HostMap() { reset_table(1024); }
 
@@ -191,6 +200,7 @@ public:
         blocks_hi = 0;
         total_points = 0;
         table_all_dirty = true;
+        order.clear();                // (tsl::robin_map::clear() keeps its bucket array: so does this)
         ++generation;
     }
 
@@ -238,6 +248,21 @@ public:
     void remove_far(const double origin[3]) {
         const double max2 = max_distance * max_distance;
         bool any = false;
+        if (track_order) {
+            // VoxelHashMap.cpp:177-183 as written: erase while iterating the robin_map
+            order.sweep_erase(
+                [&](uint32_t b) {
+                    const Point4 &p = pts[first_point(b)];
+                    const double dx = p.x - origin[0], dy = p.y - origin[1], dz = p.z - origin[2];
+                    return SAGE_SQNORM3_FAR(dx * dx, dy * dy, dz * dz) > max2;
+                },
+                [&](uint32_t b) {
+                    erase_block(b);
+                    any = true;
+                });
+            if (any) ++generation;
+            return;
+        }
         for (uint32_t b = 0; b < blocks_hi; ++b) {
             if (cnt[b] == 0) continue;
             const Point4 &p = pts[first_point(b)];
@@ -252,12 +277,17 @@ public:
 
     uint64_t pointcloud(double *out, uint64_t capacity) const {
         uint64_t k = 0;
-        for (uint32_t b = 0; b < blocks_hi; ++b) {
-            if (!cnt[b]) continue;
+        auto emit = [&](uint32_t b) {
             const Point4 *p = &pts[first_point(b)];
             for (int j = 0; j < cnt[b]; ++j, ++k)
                 if (k < capacity) std::memcpy(out + 4 * k, &p[j], 32);
+        };
+        if (track_order) {
+            order.for_each(emit);     // VoxelHashMap.cpp:136-140: bucket order
+            return k;
         }
+        for (uint32_t b = 0; b < blocks_hi; ++b)
+            if (cnt[b]) emit(b);
         return k;
     }
 
@@ -468,6 +498,7 @@ private:
             ++total_points;
             mark_slot(s);
             mark_point(first_point(b));
+            if (track_order) order.insert(reference_voxel_hash(vx, vy, vz), b);
             return 0;
         }
         const uint32_t b = block_of[table[s].blk >> 8];

@@ -197,4 +197,109 @@ private:
     }
 };
 
+// The bucket array of a LIVING tsl::robin_map<Voxel, VoxelBlock, VoxelHash> (the reference's
+// VoxelHashMap::map_, core/VoxelHashMap.hpp:106): insertions of new voxels in arrival order
+// (VoxelHashMap.cpp:166-172), the far-voxel sweep that erases WHILE it iterates (:176-184), clear()
+// (VoxelHashMap.hpp:93), copies, and iteration in bucket order (Pointcloud(), :132-142).  The payload
+// is the caller's block index.  Used only by maps created in reference-order mode
+// (sageicp_map_set_reference_order / SAGEICP_MAP_REFERENCE_ORDER=1, host_map.hpp): what is observable
+// of the reference's container beyond the search — which far voxels survive a sweep for another frame,
+// and the order Pointcloud() lists the voxels in — is then the reference's.
+//   * erase(pos): the bucket is cleared and the entries behind it move one bucket back while their
+//     distance from home is > 0 (backward-shift deletion, wrapping around the end of the array)
+//   * `for (auto &[k, v] : map_) if (far) map_.erase(k);` — the iterator of the range-for then steps
+//     past the bucket that was just refilled by the shift: that entry is not looked at in this sweep
+//   * clear() empties the buckets and KEEPS the array (min load factor 0: no shrink), so a map that
+//     is cleared and filled again iterates in another order than a fresh one
+//   * a copy has the same array
+// Same rules, same limit as the replay above: valid() turns false when a probe distance the replay
+// does not model is met (kProbeLimit); the table keeps working as a container, its order is then no
+// longer claimed to be the reference's.
+class RobinTable {
+public:
+    static constexpr uint64_t kProbeLimit = RobinOrderReplay::kProbeLimit;
+    bool valid() const { return max_field_ <= kProbeLimit; }
+    size_t size() const { return size_; }
+    size_t buckets() const { return b_.size(); }
+    uint32_t max_probe() const { return static_cast<uint32_t>(max_field_ ? max_field_ - 1 : 0); }
+
+    void clear() {
+        std::fill(b_.begin(), b_.end(), 0ull);
+        size_ = 0;
+    }
+    // hash: reference_voxel_hash of a voxel that is not in the table; val < 2^28
+    void insert(uint32_t hash, uint32_t val) {
+        if (size_ >= static_cast<size_t>(static_cast<float>(b_.size()) * 0.5f)) grow();
+        put(pack(hash, val));
+        ++size_;
+    }
+    // f(val) for every entry, bucket 0 .. buckets-1
+    template <class F>
+    void for_each(F f) const {
+        for (const uint64_t e : b_)
+            if (e) f(static_cast<uint32_t>(e & kValMask));
+    }
+    // the reference's sweep: pred(val) decides, on_erase(val) is told before the entry goes
+    template <class P, class E>
+    void sweep_erase(P pred, E on_erase) {
+        for (size_t i = 0; i < b_.size(); ++i) {
+            const uint64_t e = b_[i];
+            if (!e) continue;
+            const uint32_t v = static_cast<uint32_t>(e & kValMask);
+            if (!pred(v)) continue;
+            on_erase(v);
+            erase_at(i);          // bucket i now holds what stood behind it; the loop moves on to i + 1
+        }
+    }
+
+private:
+    static constexpr uint64_t kValMask = (1ull << 28) - 1;
+    std::vector<uint64_t> b_;     // distance + 1 in bits 48..63 (0: empty), hash in 28..47, value in 0..27
+    size_t size_ = 0;
+    uint64_t max_field_ = 0;
+
+    static uint64_t pack(uint32_t h, uint32_t v) { return (1ull << 48) | (static_cast<uint64_t>(h) << 28) | v; }
+    void put(uint64_t e) {
+        const size_t mask = b_.size() - 1;
+        size_t i = (((e >> 28) & 0xFFFFFu) + ((e >> 48) - 1)) & mask;
+        for (;;) {
+            const uint64_t r = b_[i];
+            if ((e >> 48) > (r >> 48)) {          // strictly farther from home than the resident
+                b_[i] = e;
+                if ((e >> 48) > max_field_) max_field_ = e >> 48;
+                if (!r) return;
+                e = r;
+            }
+            if ((e >> 48) >= 0xFFFFu) {           // (the 16-bit field must not wrap; far beyond kProbeLimit)
+                max_field_ = 0xFFFFu;
+                // park it in the next empty bucket: the container stays whole, the order is void
+                while (b_[i]) i = (i + 1) & mask;
+                b_[i] = e;
+                return;
+            }
+            e += 1ull << 48;
+            i = (i + 1) & mask;
+        }
+    }
+    void grow() {
+        std::vector<uint64_t> old;
+        old.swap(b_);
+        b_.assign(old.empty() ? 2 : old.size() * 2, 0ull);
+        for (const uint64_t e : old)
+            if (e) put((e & ((1ull << 48) - 1)) | (1ull << 48));       // distance 0 again, old bucket order
+    }
+    void erase_at(size_t i) {
+        const size_t mask = b_.size() - 1;
+        b_[i] = 0;
+        --size_;
+        size_t prev = i, j = (i + 1) & mask;
+        while ((b_[j] >> 48) > 1) {
+            b_[prev] = b_[j] - (1ull << 48);
+            b_[j] = 0;
+            prev = j;
+            j = (j + 1) & mask;
+        }
+    }
+};
+
 }  // namespace sageicp

@@ -61,7 +61,8 @@ def gpu_sage(sage):
 def reference_emission_order(oracle):
     """The product's VoxelDownsample emits in the reference's tsl::robin_map bucket order (its
     default); the oracle does so in mode 1 (mode 3 adds the reference's erase-while-iterating
-    sweep, which the product does not reproduce — measured without effect on the poses)."""
+    sweep, which the product follows only for maps in reference-order mode,
+    tests/test_reference_order_map.py — measured without effect on the poses)."""
     oracle.set_robin_order(1)
     yield
     oracle.set_robin_order(0)
