@@ -10,6 +10,9 @@ import time
 sys.path.insert(0, os.getcwd())
 import numpy as np  # noqa: E402
 import sage_icp_amd as sage  # noqa: E402
+
+if os.environ.get("LOOP_LIB"):           # a variant build of the library (A/B runs)
+    sage.LIB_PATH = os.path.abspath(os.environ["LOOP_LIB"])
 from sage_icp_amd import synthetic as syn  # noqa: E402
 
 KNOBS = ("SAGEICP_LOOP", "SAGEICP_LW", "SAGEICP_LOOP_WAVES", "SAGEICP_FILTER")

@@ -3,6 +3,8 @@ import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np
 import sage_icp_amd as sage
+if os.environ.get("LOOP_LIB"):           # a variant build of the library (A/B runs)
+    sage.LIB_PATH = os.path.abspath(os.environ["LOOP_LIB"])
 from sage_icp_amd import synthetic as syn
 frames, truth = syn.make_stream(21, 40, points_per_frame=120000)
 dev_update = os.environ.get("STREAM_HOST_MAP_UPDATE", "0") != "1"

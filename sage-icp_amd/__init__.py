@@ -25,6 +25,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # libsageicp_hip.v0.so, built by build.py next to the default
 SQNORM3_ORDER = 0 if os.environ.get("SAGE_SQNORM3_ORDER", "2") == "0" else 2
 LIB_PATH = os.path.join(_HERE, "libsageicp_hip.v0.so" if SQNORM3_ORDER == 0 else "libsageicp_hip.so")
+if os.environ.get("SAGEICP_VARIANT_LIB"):      # measurement only: a variant build of the same library (profiles/)
+    LIB_PATH = os.path.abspath(os.environ["SAGEICP_VARIANT_LIB"])
 
 _dp = C.POINTER(C.c_double)
 _u64p = C.POINTER(C.c_uint64)

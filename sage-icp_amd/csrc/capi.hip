@@ -1279,6 +1279,17 @@ static bool wants_filter(const sageicp_map *m, uint64_t n, double sem_th) {
     return sem_th >= 0.0 && want != 0;
 }
 
+// With 2 or 4 lanes per query: do the lanes stride through a query's voxels as one sequence (kernels.hip,
+// "flat order")?  Where the voxels hold few points relative to the lanes — fewer than 2 W on average —,
+// restarting in every voxel leaves lanes idle and makes the heaviest query's chain the longer one (c5:
+// +4.6 %, c1 through the launch-per-iteration loop: +13 %); against c2's and c4's ~12 points per voxel the
+// restart is faster by 1.5 and 5 %.  (8 and 16 lanes always stride flat; SAGEICP_FLAT=0/1 overrides.)
+static bool wants_flat(const sageicp_map *m, int lw) {
+    const uint64_t mp = m->on_device ? m->ctr.total_points : m->host.total_points;
+    const uint64_t mv = m->on_device ? m->ctr.num_voxels : m->host.num_voxels;
+    return env_int("SAGEICP_FLAT", mp < (2ull << lw) * mv ? 1 : 0) != 0;
+}
+
 // k_icp's arguments for a search of `n` queries against the HBM copy of `m`
 IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, double sem_th, int lw) {
     const Scratch &sc = m->sc;
@@ -1305,6 +1316,7 @@ IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, 
         const double inf = std::numeric_limits<double>::infinity();
         const bool filt = wants_filter(m, n, sem_th) && env_int("SAGEICP_NO_FILTER", 0) == 0;
         ip.filter = wants_filter(m, n, sem_th) ? 1 : 0;
+        ip.flat = wants_flat(m, lw) ? 1 : 0;
         ip.filt_inv_diff = filt ? k1 : inf;
         ip.filt_inv_same = filt ? (sem_th > 0.0 ? k1 / sem_th : inf) : inf;
         ip.filt_slack = std::ldexp(1.0, -44) * 1025.0 * (1.0 + 1e-6);
@@ -1354,7 +1366,17 @@ static bool plan_loop(const sageicp_map *m, uint64_t n, double sem_th, LoopPlan 
     bool filter = wants_filter(m, n, sem_th);
     if (lw < 1) return false;                          // (k_loop is built for 2..16 lanes per query)
     const uint64_t cap_waves = (2ull * static_cast<uint64_t>(sc.num_cus) - 1) / 32 * 32 * kLoopMaxWavesHost;
-    uint64_t waves = (n + (64u >> lw) - 1) / (64u >> lw);
+    auto waves_at = [n](int l) { return (n + (64u >> l) - 1) / (64u >> l); };
+    if (env_int("SAGEICP_LW", -1) < 0) {
+        // An iteration of k_loop ends with its slowest wave, and with eight or more lanes per query the
+        // lanes stride through a query's voxels in flat order (kernels.hip): more lanes than the
+        // launch-per-iteration loop would take pay here as long as the waves fit the machine — 8 where it
+        // would take 4 (c1: 17.8 -> 13.4 us per iteration), 16 against dense voxels (15k queries: 16.3 ->
+        // 15.8; c1's sparse ones: 13.4 -> 14.4); profiles/r04/flat_where.txt
+        if (lw < 3 && waves_at(3) <= cap_waves) lw = 3;
+        if (lw == 3 && !sparse_voxels(m) && waves_at(4) <= cap_waves) lw = 4;
+    }
+    uint64_t waves = waves_at(lw);
     if (mode == 2 && env_int("SAGEICP_LW", -1) < 0) {
         // fewer lanes per query than the launch-per-iteration loop would take, if that is what makes the frame fit
         while (waves > cap_waves && lw > 1) {
@@ -1426,7 +1448,9 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     int lw = icp_lw(n, sparse_voxels(m));
     LoopPlan plan{};
     bool use_loop = !comm && !g_fp64_partials && plan_loop(m, n, sem_th, &plan);
-    if (use_loop) lw = plan.lw;
+    // (the one-launch loop chooses its own lanes per query, plan.lw; `lw` stays what the launch-per-iteration
+    // loop takes — also when it has to finish a frame the one-launch loop gave up on)
+    const unsigned loop_waves = use_loop ? static_cast<unsigned>((n + (64u >> plan.lw) - 1) / (64u >> plan.lw)) : 0u;
     const int blocks = n ? icp_blocks_for(static_cast<int>(n), lw) : 1;
     if ((rc = ensure_cand(m, wants_filter(m, n, sem_th)))) return rc;
     if ((rc = sc.reserve_sort(n))) return rc;
@@ -1437,7 +1461,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     ip.kernel = kernel;
     ip.accept_r2 = accept_threshold(max_dist);
     ip.counters = stats ? sc.d_cand : nullptr;
-    if (stats) HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * 2 * (ip.nwaves + 1), s));
+    if (stats) HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * 2 * (std::max(ip.nwaves, loop_waves) + 1), s));
 
     // Spatial ordering of the frame: the loop runs on a copy sorted by map-frame voxel under the
     // initial guess, so that the queries of a wave share home voxels and neighbouring waves touch
@@ -1459,7 +1483,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         if (prof && (rc = sc.reserve_events(1))) return rc;
         IcpParams lp = ip;
         lp.filter = plan.filter ? ip.filter : 0;
-        lp.nwaves = static_cast<unsigned>((n + (64u >> lw) - 1) / (64u >> lw));
+        lp.nwaves = loop_waves;
         LoopParams L{};
         L.sh = sc.d_loop;
         L.st = sc.d_state;
@@ -1472,7 +1496,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         L.max_iterations = kMaxIterations;
         HIPCHK(hipMemsetAsync(sc.d_loop, 0, sizeof(LoopShared), s));
         if (prof) HIPCHK(hipEventRecord(sc.events[1], s));
-        launch_loop(lp, L, lw, plan.grid, s);
+        launch_loop(lp, L, plan.lw, plan.grid, s);
         if (prof) HIPCHK(hipEventRecord(sc.events[2], s));
         if (stats) launch_sum_counters(sc.d_cand, static_cast<int>(lp.nwaves), sc.d_state, s);
         HIPCHK(hipGetLastError());
@@ -1665,7 +1689,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         stats->nn_launches = nn_launches;
         stats->sum_candidates = st.sum_candidates;
         stats->pairs_evaluated = st.sum_pairs;
-        stats->lanes_per_query = 1u << lw;
+        stats->lanes_per_query = 1u << (looped ? plan.lw : lw);
         stats->compact_scan = (looped ? plan.filter && ip.filter : ip.filter != 0) ? 1u : 0u;
         stats->single_launch = looped ? 1u : 0u;
         for (int i = 0; i < 64 && i < st.iter; ++i) stats->n_corr_hist[i] = st.n_corr[i];

@@ -36,6 +36,8 @@ struct IcpParams {
     uint32_t pts_bytes;       // size of the point array: under 4 GiB (2^24 units of 128 B), read with 32-bit
                               // byte offsets through a buffer resource
     int filter;               // 1: the scan reads the compact copy and filters in fp32 (big frames, dense voxels)
+    int flat;                 // 1: with 2 or 4 lanes per query the lanes stride through a query's voxels as one
+                              // sequence (sparse voxels; 8 and 16 lanes always do; kernels.hip "flat order")
     const uint4 *cand;        // compact copy of pts (fp32 x, y, z, label; k_derive_cand), same indexing
     uint32_t cand_bytes;      // its size
     const uint32_t *cand_flags;   // bit 0: some label of the map cannot be classified in fp32

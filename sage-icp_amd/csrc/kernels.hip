@@ -431,7 +431,10 @@ __host__ __device__ constexpr unsigned loop_wave_words(int lw) {
 // `pose` (LDS: R[9], t[3]); nothing is read from or written to the global rows / nn_prev arrays;
 // the body ends with the wave's sums parked in the workgroup's LDS header and returns true on the
 // last wave of the workgroup to arrive (`nw` waves), which the caller lets finish the iteration.
-template <int LW, bool FUSED, bool FILT, bool PERSIST = false>
+#ifndef SAGE_LOOP_FLAT_MINW
+#define SAGE_LOOP_FLAT_MINW 8      // k_loop: flat-order scan from this many lanes per query (icp_body)
+#endif
+template <int LW, bool FUSED, bool FILT, bool PERSIST = false, bool FLATQ = false>
 __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, LoopLane *LL = nullptr,
                                          const double *pose = nullptr, int nw = kIcpWavesPerBlock);
 
@@ -446,24 +449,35 @@ struct PairFull {
     unsigned ka;
     bool ha, hb;
 };
+// ... of a scan in flat order (below): b may lie in another voxel than a
+struct PairCompactFlat {
+    uint4 a, b;
+    unsigned ka, oa, kb, ob;
+    bool ha, hb;
+};
+struct PairFullFlat {
+    Point4 a, b;
+    unsigned ka, kb;
+    bool ha, hb;
+};
 
-template <int LW, bool FUSED, bool FILT>
+template <int LW, bool FUSED, bool FILT, bool FLATQ>
 __global__ __launch_bounds__(64 * kIcpWavesPerBlock) __attribute__((amdgpu_waves_per_eu(SAGE_ICP_OCC, 8)))
 void k_icp(IcpParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     if (P.check_done && P.st->done) return;
-    icp_body<LW, FUSED, FILT>(P, smem);
+    icp_body<LW, FUSED, FILT, false, FLATQ>(P, smem);
 #ifdef SAGE_ICP_DELAY_PROBE
     // probe: the same pass again inside the launch — what an iteration costs on L2s that were not
     // emptied by a kernel boundary (its sums are added a second time: the solve does not care)
     for (unsigned r = 0; r < P.dbg_repeat; ++r) {
         __syncthreads();
-        icp_body<LW, FUSED, FILT>(P, smem);
+        icp_body<LW, FUSED, FILT, false, FLATQ>(P, smem);
     }
 #endif
 }
 
-template <int LW, bool FUSED, bool FILT, bool PERSIST>
+template <int LW, bool FUSED, bool FILT, bool PERSIST, bool FLATQ>
 __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, LoopLane *LL, const double *pose,
                                          int nw) {
     static_assert(!PERSIST || FUSED, "the persistent loop always accumulates");
@@ -809,9 +823,59 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
     // two points of the open voxel (k and k + W); two register sets alternate, so while one pair
     // is filtered the loads of the next pair are in flight (no register copies across the loop
     // edge: the wait before a pair leaves the younger loads outstanding).
-    using Pair = std::conditional_t<FILT, PairCompact, PairFull>;
+    // FLAT: the lanes of a query stride through the points of its open voxels as ONE sequence — lane c
+    // takes points c, c + W, c + 2W, ... of the concatenation — instead of starting again at slot c in
+    // every voxel.  With 16 lanes and ~10 points per voxel the restart leaves lanes 10..15 idle in every
+    // voxel and gives lanes 0..9 one point per voxel: a query that must look at all 27 voxels is a chain
+    // of 27 points per lane; in flat order it is 270 / 16 = 17.  (Which lane looks at a point changes
+    // nothing: the answer is the lexicographic minimum over all of them, reduced across the lanes
+    // afterwards.)  A launch ends with its slowest wave — the one holding the heaviest query
+    // (profiles/r04/loop_times.txt) — and few points per voxel relative to the lanes per query make
+    // the restart's chain the longer one: always with 8 and 16 lanes (k_loop c1 17.8 -> 13.4 us per
+    // iteration, 15k-query shards 19.0 -> 15.8 with 16 lanes, the streamed sources' ICP 1.52 -> 1.44 ms),
+    // with 2 and 4 lanes where the host finds fewer than 2 W points per voxel on average (P.flat: c5
+    // 213 -> 223 frames/s; against c2's and c4's ~12 points per voxel the per-voxel restart is the faster
+    // one by 1.5 and 5 %, profiles/r04/flat_where.txt).
+    constexpr bool FLAT = PERSIST ? (W >= SAGE_LOOP_FLAT_MINW) : FLATQ;
+    using Pair = std::conditional_t<FLAT, std::conditional_t<FILT, PairCompactFlat, PairFullFlat>,
+                                    std::conditional_t<FILT, PairCompact, PairFull>>;
     auto scan = [&](unsigned need, const Point4 *seed, bool seeded, unsigned seed_key) {
+        // flat order: the next point of this lane — its key, where its record lives, whether there is one
+        auto next = [&](bool &h, unsigned &key, unsigned &o) {
+            while (k >= kend && need) {        // past the end of the open voxel by k - kend points: on into the next
+                const unsigned e = k - kend;
+                const unsigned v = static_cast<unsigned>(__builtin_ctz(need));
+                need &= need - 1u;
+                const uint32_t w = lrow[v];
+                kend = (v << 8) | (w & 255u);
+                k = (v << 8) + e;
+                off = (((w >> 8) * kUnitPoints) + e) << SHC;
+                npairs += w & 255u;
+            }
+            h = k < kend;
+            key = k;
+            o = off;
+            k += h ? static_cast<unsigned>(W) : 0u;
+            off += h ? static_cast<unsigned>(W) << SHC : 0u;
+        };
         auto issue = [&](Pair &n, bool &more) {
+            if constexpr (FLAT) {
+                unsigned oa, ob;
+                next(n.ha, n.ka, oa);
+                next(n.hb, n.kb, ob);
+                if constexpr (FILT) {
+                    n.oa = oa;
+                    n.ob = ob;
+                    n.a = load_cand(cands, n.ha ? oa : 0u);
+                    n.b = load_cand(cands, n.hb ? ob : 0u);
+                } else {
+                    n.a = load_point(pts, n.ha ? oa : 0u);
+                    n.b = load_point(pts, n.hb ? ob : 0u);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                more = (k < kend) | (need != 0u);
+                return;
+            } else {
             while (k >= kend && need) {        // open this lane's next voxel
                 const unsigned v = static_cast<unsigned>(__builtin_ctz(need));
                 need &= need - 1u;
@@ -841,14 +905,17 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
             k += n.ha ? 2u * W : 0u;
             off += n.ha ? (2u * W) << SHC : 0u;
             more = (k < kend) | (need != 0u);
+            }
         };
         auto consume = [&](const Pair &n) {
+            unsigned kb;                        // b's key: W points on in a's voxel, or its own (flat order)
+            if constexpr (FLAT) kb = n.kb; else kb = n.ka + W;
             if constexpr (!FILT) {
                 evaluate(n.a, n.ha, n.ka);
-                evaluate(n.b, n.hb, n.ka + W);
+                evaluate(n.b, n.hb, kb);
             } else {
             // (the candidate already held — the seed met again in its voxel — needs no second look)
-            const bool pa = passes(n.a, n.ha) & (n.ka != bkey), pb = passes(n.b, n.hb) & (n.ka + W != bkey);
+            const bool pa = passes(n.a, n.ha) & (n.ka != bkey), pb = passes(n.b, n.hb) & (kb != bkey);
 #ifdef SAGE_NN_TIMING
             ++n_consume;
 #endif
@@ -861,11 +928,12 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
                 ++n_exact;
                 n_exact_lanes += static_cast<unsigned>(__popcll(__ballot(pa)) + __popcll(__ballot(pb)));
 #endif
-                const unsigned ob = n.oa + (static_cast<unsigned>(W) << SHC);
+                unsigned ob;
+                if constexpr (FLAT) ob = n.ob; else ob = n.oa + (static_cast<unsigned>(W) << SHC);
                 const Point4 ea = load_point(pts, pa ? n.oa << 1 : 0u);
                 const Point4 eb = load_point(pts, pb ? ob << 1 : 0u);
                 evaluate(ea, pa, n.ka);
-                evaluate(eb, pb, n.ka + W);
+                evaluate(eb, pb, kb);
                 fb = min_f64(fb, best);
                 set_thresholds();
             }
@@ -2069,12 +2137,26 @@ static void launch_icp_lw(const IcpParams &p, bool fused, hipStream_t s) {
     const int grid = icp_blocks_for(p.n, LW);
     const size_t lds = icp_lds_bytes(LW);
     const dim3 g(grid), b(64 * kIcpWavesPerBlock);
-    if (p.filter) {
-        if (fused) hipLaunchKernelGGL((k_icp<LW, true, true>), g, b, lds, s, p);
-        else hipLaunchKernelGGL((k_icp<LW, false, true>), g, b, lds, s, p);
+    // flat order: always with 8 and 16 lanes per query, never with one (it is the same thing), on request between
+    constexpr bool kBoth = LW == 1 || LW == 2;
+    const bool flat = LW >= 3 || (kBoth && p.flat);
+    auto go = [&](auto flat_c) {
+        constexpr bool F = decltype(flat_c)::value;
+        if (p.filter) {
+            if (fused) hipLaunchKernelGGL((k_icp<LW, true, true, F>), g, b, lds, s, p);
+            else hipLaunchKernelGGL((k_icp<LW, false, true, F>), g, b, lds, s, p);
+        } else {
+            if (fused) hipLaunchKernelGGL((k_icp<LW, true, false, F>), g, b, lds, s, p);
+            else hipLaunchKernelGGL((k_icp<LW, false, false, F>), g, b, lds, s, p);
+        }
+    };
+    if constexpr (kBoth) {
+        if (flat) go(std::true_type{});
+        else go(std::false_type{});
+    } else if constexpr (LW >= 3) {
+        go(std::true_type{});
     } else {
-        if (fused) hipLaunchKernelGGL((k_icp<LW, true, false>), g, b, lds, s, p);
-        else hipLaunchKernelGGL((k_icp<LW, false, false>), g, b, lds, s, p);
+        go(std::false_type{});
     }
 }
 void launch_icp(const IcpParams &p, int lw, bool fused, hipStream_t s) {

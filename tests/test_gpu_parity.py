@@ -61,14 +61,16 @@ def test_correspondences_index_exact(gpu_sage, oracle, seed, vs, basic, critical
 @given(seed=st.integers(0, 2**31 - 1), vs=st.sampled_from([0.1, 0.3, 0.8, 1.0, 2.5]),
        th=st.sampled_from([0.05, 0.4, 1.0, 1.7]), md=st.sampled_from([0.2, 0.9, 2.0, 6.0]),
        basic=st.integers(0, 24), critical=st.integers(1, 24), span=st.sampled_from([1.5, 6.0, 20.0]),
-       lw=st.integers(0, 4), compact=st.booleans(), n_q=st.sampled_from([1, 63, 700, 5000]))
+       lw=st.integers(0, 4), compact=st.booleans(), n_q=st.sampled_from([1, 63, 700, 5000]), flat=st.booleans())
 def test_get_correspondences_property(gpu_sage, oracle, seed, vs, th, md, basic, critical, span, lw,
-                                      compact, n_q):
+                                      compact, n_q, flat):
     """random clouds, voxel sizes, capacities, thresholds, query counts, clustered queries and
     queries on voxel faces, in every kernel variant: the HIP search against the oracle, index for
-    index and bit for bit"""
-    old = {k: os.environ.get(k) for k in ("SAGEICP_LW", "SAGEICP_FILTER")}
+    index and bit for bit (flat: the lanes of a query stride through its voxels as one sequence — a choice
+    with 2 and 4 lanes per query, the rule with 8 and 16)"""
+    old = {k: os.environ.get(k) for k in ("SAGEICP_LW", "SAGEICP_FILTER", "SAGEICP_FLAT")}
     os.environ["SAGEICP_LW"], os.environ["SAGEICP_FILTER"] = str(lw), "1" if compact else "0"
+    os.environ["SAGEICP_FLAT"] = "1" if flat else "0"
     try:
         rng = np.random.default_rng(seed)
         labels = [0, 0, 10, 40, 44, 50, 70, 71, 80, 251]
@@ -389,14 +391,16 @@ def test_register_frame_pose_parity_c2_scaled(gpu_sage, oracle, params, scan_for
     assert np.array_equal(pose, pose2)
 
 
-@pytest.mark.parametrize("lw", [0, 1, 2, 3, 4])
-def test_every_lanes_per_query_variant(gpu_sage, oracle, scan_form, lw, monkeypatch):
+@pytest.mark.parametrize("lw,flat", [(0, 0), (1, 0), (1, 1), (2, 0), (2, 1), (3, 1), (4, 1)])
+def test_every_lanes_per_query_variant(gpu_sage, oracle, scan_form, lw, flat, monkeypatch):
     """k_icp is compiled for 1, 2, 4, 8 and 16 lanes per query and the library picks by frame size
     and voxel density (capi.hip::icp_lw), so a given workload only ever reaches one or two of the
-    variants: each is forced in turn (SAGEICP_LW) in both scan forms — index-exact search, the same
-    registration as the oracle's, the same exact candidate count."""
+    variants: each is forced in turn (SAGEICP_LW) in both scan forms and, with 2 and 4 lanes, in both orders
+    the lanes take a query's points in (SAGEICP_FLAT; 8 and 16 lanes: always flat) — index-exact search, the
+    same registration as the oracle's, the same exact candidate count."""
     from sage_icp_amd import synthetic as syn
     monkeypatch.setenv("SAGEICP_LW", str(lw))
+    monkeypatch.setenv("SAGEICP_FLAT", str(flat))
     mp, q = random_scene(31 + lw)
     a, b = both_maps(gpu_sage, oracle, mp)
     for th, md in ((0.4, 6.0), (1.0, 2.0), (0.05, 0.9)):
@@ -553,14 +557,15 @@ def test_register_frame_with_initial_guess_and_edge_inputs(gpu_sage, oracle, sca
 @given(seed=st.integers(0, 2**31 - 1), vs=st.sampled_from([0.3, 0.8, 1.0, 2.0]),
        sigma=st.sampled_from([0.3, 1.0, 2.0]), th=st.sampled_from([0.05, 0.4, 1.0]),
        lw=st.integers(0, 4), compact=st.booleans(), n_q=st.sampled_from([200, 3000, 12000]),
-       noise=st.sampled_from([0.0, 0.02]))
-def test_register_frame_property(gpu_sage, oracle, seed, vs, sigma, th, lw, compact, n_q, noise):
+       noise=st.sampled_from([0.0, 0.02]), flat=st.booleans())
+def test_register_frame_property(gpu_sage, oracle, seed, vs, sigma, th, lw, compact, n_q, noise, flat):
     """RegisterFrame on random scenes (voxel size, thresholds as the adaptive sigma gives them:
     max_corr 3 sigma, kernel sigma / 3; semantic threshold; frame size; a random planted motion and
     a random initial guess near it; with and without noise) in every kernel variant: the same
     iteration count, correspondence counts and pose as the oracle"""
-    old = {k: os.environ.get(k) for k in ("SAGEICP_LW", "SAGEICP_FILTER")}
+    old = {k: os.environ.get(k) for k in ("SAGEICP_LW", "SAGEICP_FILTER", "SAGEICP_FLAT")}
     os.environ["SAGEICP_LW"], os.environ["SAGEICP_FILTER"] = str(lw), "1" if compact else "0"
+    os.environ["SAGEICP_FLAT"] = "1" if flat else "0"
     try:
         rng = np.random.default_rng(seed)
         mp, _ = random_scene(seed % 1000, n_map=30000, n_q=10, span=15.0)
@@ -632,8 +637,11 @@ def test_rccl_refuses_two_ranks_on_one_device():
         "bench.py --gpus 2 failed, but not because RCCL refused two ranks on one device"
 
 
-def test_register_frame_through_rccl_comm_world1(gpu_sage, oracle):
-    """the RCCL exchange path (reduce -> ncclAllReduce -> solve) with a one-rank communicator"""
+def test_register_frame_through_rccl_comm_world1(gpu_sage, oracle, monkeypatch):
+    """the RCCL exchange path (reduce -> ncclAllReduce -> solve) with a one-rank communicator: bit for bit the
+    launch-per-iteration loop without a communicator (the one-launch loop may take another number of lanes per
+    query — other waves, other roundings of the per-wave sums — and is compared in tests/test_loop_kernel.py)"""
+    monkeypatch.setenv("SAGEICP_LOOP", "0")
     w, om = _workload(gpu_sage, oracle, "c2", 0.05)
     f = gpu_sage.Frame(w["map"], w["scan"])
     ref = gpu_sage.register_frame(f, w["map"], gpu_sage.IDENTITY, 6.0, 2 / 3, 0.4)
@@ -648,6 +656,7 @@ def test_chunked_rccl_loop_equals_polled_loop(gpu_sage, oracle, monkeypatch):
     host-polled loop of one GPU: same bits, same iteration count — through a one-rank RCCL
     communicator, and for the plain single-GPU call forced into chunks (SAGEICP_CHUNKED=1)"""
     from sage_icp_amd import synthetic as syn
+    monkeypatch.setenv("SAGEICP_LOOP", "0")     # (the launch-per-iteration loop on both sides: equal lanes per query)
     w, om = _workload(gpu_sage, oracle, "c2", 0.05)
     f = gpu_sage.Frame(w["map"], w["scan"])
     for prm in ("cold", "steady"):
@@ -674,10 +683,11 @@ def test_chunked_rccl_loop_equals_polled_loop(gpu_sage, oracle, monkeypatch):
         assert direct.describe()["rccl_ranks"] == -1 and direct.describe()["p2p_enabled"] == 1
 
 
-def test_register_frame_through_direct_exchange_world1(gpu_sage, oracle):
+def test_register_frame_through_direct_exchange_world1(gpu_sage, oracle, monkeypatch):
     """the direct exchange path (reduce -> stores into the mapped blocks -> tags -> solve, all inside k_fin)
     with a one-rank communicator that has no RCCL side; the RCCL communicator can switch to it
     and back"""
+    monkeypatch.setenv("SAGEICP_LOOP", "0")     # (the launch-per-iteration loop on both sides: equal lanes per query)
     w, om = _workload(gpu_sage, oracle, "c2", 0.05)
     f = gpu_sage.Frame(w["map"], w["scan"])
     ref, rst = gpu_sage.register_frame(f, w["map"], gpu_sage.IDENTITY, 6.0, 2 / 3, 0.4, return_stats=True)
