@@ -194,3 +194,33 @@ def test_streamed_pipeline_with_a_reference_order_map(gpu_sage, oracle_ref):
         assert np.array_equal(ma[:, 3], mb[:, 3]) and np.allclose(ma[:, :3], mb[:, :3], rtol=0, atol=1e-8), "frame %d" % k
         differs += int(len(md) != len(ma))
     assert differs > 0, "the default sweep was expected to evict voxels the reference's leaves for a later frame"
+
+
+def test_random_update_sequences_against_the_oracle(sage, oracle_ref):
+    """property test on the host: random voxel sizes, ranges, capacities, frame sizes and sensor paths (incl.
+    jumps back into evicted ground and Clear() in the middle) — after every Update the product's Pointcloud()
+    is the oracle's in mode 3, byte for byte and in order"""
+    from hypothesis import given, settings, HealthCheck, strategies as st
+
+    @settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(seed=st.integers(0, 2**31 - 1), vs=st.sampled_from([0.5, 1.0, 2.0]), rng_m=st.sampled_from([8.0, 20.0, 45.0]),
+           basic=st.integers(1, 6), critical=st.integers(0, 6), step=st.sampled_from([0.0, 3.0, 9.0, 25.0]),
+           n_pts=st.sampled_from([1, 40, 600, 3000]))
+    def run(seed, vs, rng_m, basic, critical, step, n_pts):
+        rng = np.random.default_rng(seed)
+        m = sage.VoxelHashMap(vs, rng_m, basic, critical, [40, 50]).set_reference_order(True)
+        om = oracle_ref.Map(vs, rng_m, basic, critical, [40, 50])
+        centre = np.zeros(3)
+        for f in range(10):
+            if f == 6 and seed % 3 == 0:
+                m.Clear(); om.clear()
+            centre = centre + [step, rng.normal() * 0.5, 0.0] if seed % 5 or f != 7 else np.zeros(3)
+            pts = _cloud(rng, n_pts, centre, spread=rng_m * 1.2)
+            m.Update(pts, centre)
+            om.add_points(pts)
+            om.remove_far(centre)
+            assert m.size() == om.size() and m.num_voxels() == om.num_voxels()
+            assert np.array_equal(m.Pointcloud(), om.pointcloud())
+        assert m.reference_order() == 1
+
+    run()
