@@ -72,7 +72,11 @@ static int icp_lw(uint64_t n, bool sparse_voxels) {
     // 80k queries on (c5, 200k: 188 -> 211 frames/s; 100k: 301 -> 321; 50k: 728 -> 707), against
     // dense ones only at c4's size (500k: 47.4 -> 47.8, cold 63.3 -> 64.6; c2, 120k: 132 -> 118)
     if (n >= (sparse_voxels ? 80000u : 400000u)) return 1;
-    if (n >= 50000) return 2;
+    // eight lanes stride through a query's voxels in flat order (kernels.hip) since late round 4 and hold
+    // against dense voxels up to ~110k queries (50k: 25.7 against 31.1 us per iteration with four; 60k: 28.0 /
+    // 31.5; 80k: 32.3 / 34.5; 100k: 36.2 / 37.1; 120k: 40.8 / 40.6 — profiles/r04/lanes_probe2.txt); the
+    // switch used to sit at 50k
+    if (n >= (sparse_voxels ? 50000u : 110000u)) return 2;
     // against voxels that hold a few points each a scan is two or three points per lane whatever
     // the split: four lanes per query then beat eight from 4k queries on (c1: 632 vs 616 frames/s)
     if (sparse_voxels && n >= 4096) return 2;
@@ -1377,11 +1381,14 @@ static bool plan_loop(const sageicp_map *m, uint64_t n, double sem_th, LoopPlan 
         if (lw == 3 && !sparse_voxels(m) && waves_at(4) <= cap_waves) lw = 4;
     }
     uint64_t waves = waves_at(lw);
-    if (mode == 2 && env_int("SAGEICP_LW", -1) < 0) {
-        // fewer lanes per query than the launch-per-iteration loop would take, if that is what makes the frame fit
-        while (waves > cap_waves && lw > 1) {
+    if (env_int("SAGEICP_LW", -1) < 0) {
+        // fewer lanes per query than the launch-per-iteration loop would take, if that is what makes the frame
+        // fit: four instead of eight pay (32k .. 61k queries: 22.8 against 23.3 us per iteration at 40k, 23.7 /
+        // 25.7 at 50k, 23.8 / 28.0 at 60k — profiles/r04/loop_mid2.txt, lanes_probe2.txt), two do not (70k: 35.4
+        // against 29.9) and are taken only where the loop is forced (SAGEICP_LOOP=2)
+        while (waves > cap_waves && lw > (mode == 2 ? 1 : 2)) {
             --lw;
-            waves = (n + (64u >> lw) - 1) / (64u >> lw);
+            waves = waves_at(lw);
         }
     }
     if (waves > cap_waves) return false;
