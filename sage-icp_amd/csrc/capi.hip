@@ -66,21 +66,21 @@ static int env_int(const char *name, int dflt) {
 static int icp_lw(uint64_t n, bool sparse_voxels) {
     const int e = env_int("SAGEICP_LW", -1);
     if (e >= 0) return e > 4 ? 4 : e;
+    // (all of this re-measured after the flat-order scan, profiles/r04/lanes_probe2.txt (dense voxels) and
+    // lanes_probe3.txt (sparse ones); us per iteration)
     // the biggest frames are bound by instruction issue, not by the length of a wave's chain: two
-    // lanes per query halve the per-query share of the fixed work (prologue, bounds, epilogue).
-    // Against sparse voxels — scans of a point or two per voxel, little to split — that pays from
-    // 80k queries on (c5, 200k: 188 -> 211 frames/s; 100k: 301 -> 321; 50k: 728 -> 707), against
-    // dense ones only at c4's size (500k: 47.4 -> 47.8, cold 63.3 -> 64.6; c2, 120k: 132 -> 118)
-    if (n >= (sparse_voxels ? 80000u : 400000u)) return 1;
-    // eight lanes stride through a query's voxels in flat order (kernels.hip) since late round 4 and hold
-    // against dense voxels up to ~110k queries (50k: 25.7 against 31.1 us per iteration with four; 60k: 28.0 /
-    // 31.5; 80k: 32.3 / 34.5; 100k: 36.2 / 37.1; 120k: 40.8 / 40.6 — profiles/r04/lanes_probe2.txt); the
-    // switch used to sit at 50k
-    if (n >= (sparse_voxels ? 50000u : 110000u)) return 2;
-    // against voxels that hold a few points each a scan is two or three points per lane whatever
-    // the split: four lanes per query then beat eight from 4k queries on (c1: 632 vs 616 frames/s)
-    if (sparse_voxels && n >= 4096) return 2;
-    if (n >= 10000) return 3;
+    // lanes per query halve the per-query share of the fixed work (prologue, bounds, epilogue) — against
+    // dense voxels only at c4's size (500k: 90.7 against 92.9 with four, 400k a tie), against sparse ones
+    // from ~150k (c5, 200k: 42.8 / 43.2; 100k: 33.3 / 31.6)
+    if (n >= (sparse_voxels ? 150000u : 400000u)) return 1;
+    // eight lanes stride through a query's voxels in flat order (kernels.hip) and hold against dense voxels
+    // up to ~110k queries (50k: 25.7 against 31.1 with four; 60k: 28.0 / 31.5; 80k: 32.3 / 34.5; 100k: 36.2 /
+    // 37.1; 120k: 40.8 / 40.6), against sparse ones up to ~60k (25k: 19.8 / 22.9; 50k: 24.7 / 25.1; 100k:
+    // 34.9 / 31.6); until late round 4 the switch to four sat at 50k and, for sparse voxels, at 4k
+    if (n >= (sparse_voxels ? 60000u : 110000u)) return 2;
+    // sixteen lanes only for small frames against dense voxels: a scan against sparse ones is a handful of
+    // points whatever the split (c1, 10k: 17.6 with eight, 20.7 with four)
+    if (n >= (sparse_voxels ? 4096u : 10000u)) return 3;
     return 4;
 }
 
