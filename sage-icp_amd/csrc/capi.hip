@@ -78,9 +78,11 @@ static int icp_lw(uint64_t n, bool sparse_voxels) {
     // 37.1; 120k: 40.8 / 40.6), against sparse ones up to ~60k (25k: 19.8 / 22.9; 50k: 24.7 / 25.1; 100k:
     // 34.9 / 31.6); until late round 4 the switch to four sat at 50k and, for sparse voxels, at 4k
     if (n >= (sparse_voxels ? 60000u : 110000u)) return 2;
-    // sixteen lanes only for small frames against dense voxels: a scan against sparse ones is a handful of
-    // points whatever the split (c1, 10k: 17.6 with eight, 20.7 with four)
-    if (n >= (sparse_voxels ? 4096u : 10000u)) return 3;
+    // sixteen lanes only for small frames against dense voxels (in flat order they hold up to ~20k queries:
+    // 10k 17.8 against 18.9 with eight, 15k 19.1 / 20.0, 30k 24.7 / 22.6 — lanes_probe4.txt; the switch used
+    // to sit at 10k): a scan against sparse ones is a handful of points whatever the split (c1, 10k: 17.6
+    // with eight, 20.7 with four)
+    if (n >= (sparse_voxels ? 4096u : 20000u)) return 3;
     return 4;
 }
 
