@@ -22,7 +22,7 @@ os.environ["SAGEICP_LOOP"] = "2"
 for _ in range(3):
     pose, st = sage.register_frame(f, w["map"], sage.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"], return_stats=True)
 assert st.single_launch == 1
-IT, WG = 64, 512
+IT, WG = 32, 1024
 wg = np.zeros((IT, WG, 2), dtype=np.uint64)
 sv = np.zeros((IT, 4), dtype=np.uint64)
 sage.lib().sageicp_debug_loop_times(wg.ctypes.data_as(C.c_void_p), sv.ctypes.data_as(C.c_void_p))

@@ -124,7 +124,12 @@ struct Scratch {
     double *d_partials2 = nullptr; size_t partials2_cap = 0;   // second stage of the reduction (k_red, big frames)
     long long *d_acc = nullptr;    // fixed-point accumulators of the Gauss-Newton sums (kernels.h, kAcc*)
     LoopShared *d_loop = nullptr;  // what the workgroups of k_loop share inside its launch (kernels.h)
-    int num_cus = 0;
+    hipStream_t stream2 = nullptr; // the solving wave of the one-launch loop runs here, beside the grid on `stream`
+    hipEvent_t ev_solve = nullptr; // ... and this says that it has finished
+    unsigned long long loop_epoch = 0;
+    int num_cus = 0;               // CUs the streams of this handle may use (the whole device, or its share: below)
+    int cu_share_i = 0, cu_share_k = 1;   // SAGEICP_CU_SHARE=i/k: the i-th of k equal parts of the device's CUs (several
+                                   // ranks on ONE GPU — tests, or a small node — each keep a persistent grid resident)
     int loop_cooldown = 0;         // calls that stay away from k_loop after one of its launches timed out
     unsigned long long *d_cand = nullptr;      // per-wave counters of k_icp [2 x sort_cap]
     IcpState *d_state = nullptr;
@@ -141,14 +146,39 @@ struct Scratch {
         if (dev < 0 || dev >= count) return fail(SAGEICP_ERR_INVALID, "device ordinal out of range");
         device = dev;
         HIPCHK(hipSetDevice(device));
-        HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        HIPCHK(hipMalloc(&d_state, sizeof(IcpState)));
-        HIPCHK(hipMalloc(&d_acc, sizeof(long long) * kAccReplicas * kAccWords));
-        HIPCHK(hipMalloc(&d_loop, sizeof(LoopShared)));
         {
             int cus = 0;
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) num_cus = cus;
         }
+        if (cu_share_k <= 1) {
+            if (const char *e = std::getenv("SAGEICP_CU_SHARE")) {
+                int i = 0, k = 1;
+                if (std::sscanf(e, "%d/%d", &i, &k) == 2 && k >= 1 && k <= 16 && i >= 0 && i < k) {
+                    cu_share_i = i;
+                    cu_share_k = k;
+                }
+            }
+        }
+        if (cu_share_k > 1 && num_cus >= 8 * cu_share_k) {
+            // this handle's kernels run on CUs [i, i + 1) * num_cus / k only: the persistent grids of k ranks
+            // that share one GPU are then resident side by side instead of waiting for each other
+            const int per = num_cus / cu_share_k, lo = cu_share_i * per;
+            std::vector<uint32_t> mask((num_cus + 31) / 32, 0u);
+            for (int c = lo; c < lo + per; ++c) mask[c / 32] |= 1u << (c % 32);
+            HIPCHK(hipExtStreamCreateWithCUMask(&stream, static_cast<uint32_t>(mask.size()), mask.data()));
+            HIPCHK(hipExtStreamCreateWithCUMask(&stream2, static_cast<uint32_t>(mask.size()), mask.data()));
+            num_cus = per;
+        } else {
+            cu_share_i = 0;
+            cu_share_k = 1;
+            HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+            HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+        }
+        HIPCHK(hipEventCreateWithFlags(&ev_solve, hipEventDisableTiming));
+        HIPCHK(hipMalloc(&d_state, sizeof(IcpState)));
+        HIPCHK(hipMalloc(&d_acc, sizeof(long long) * kAccReplicas * kAccWords));
+        HIPCHK(hipMalloc(&d_loop, sizeof(LoopShared)));
+        HIPCHK(hipMemset(d_loop, 0, sizeof(LoopShared)));
 
         HIPCHK(hipHostMalloc(&h_state, sizeof(IcpState), hipHostMallocDefault));
         HIPCHK(hipHostMalloc(&h_prog, sizeof(IcpProgress), hipHostMallocMapped | hipHostMallocCoherent));
@@ -241,6 +271,9 @@ struct Scratch {
         if (!stream) return;
         (void)hipSetDevice(device);
         (void)hipStreamSynchronize(stream);
+        if (stream2) (void)hipStreamSynchronize(stream2);
+        if (ev_solve) (void)hipEventDestroy(ev_solve);
+        if (stream2) (void)hipStreamDestroy(stream2);
         for (auto &e : events) (void)hipEventDestroy(e);
         events.clear();
         if (d_frame) (void)hipFree(d_frame);
@@ -1351,73 +1384,114 @@ IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, 
 }
 
 // Shape of the one-launch loop (k_loop) for a frame of n points, or false when the frame does not fit
-// the machine in that form: every wave keeps 64 >> lw queries for the whole call, so all of them have
-// to be resident at once — at most two workgroups of up to eight waves per CU (128 registers a lane),
-// plus the one-wave solving workgroup.
+// the machine in that form.  The frame is cut into groups of 64 >> lw queries; a workgroup of nw waves
+// owns gpw of them for the whole call, rows and per-query state in LDS (kernels.h), and every workgroup
+// has to be resident at once: what bounds a frame is the LDS of the machine (232 B per query: ~170k
+// queries on 256 CUs), not its wave slots.
 struct LoopPlan {
-    int lw, nw, grid;          // lanes per query (log2), waves per workgroup, workgroups incl. the solving one
+    int lw, nw, gpw, wgs;      // lanes per query (log2), waves per workgroup, groups per workgroup, query workgroups
     bool filter;
 };
-static bool plan_loop(const sageicp_map *m, uint64_t n, double sem_th, LoopPlan *out) {
-    const Scratch &sc = m->sc;
-    const int mode = env_int("SAGEICP_LOOP", 1);       // 0: never, 1: where it fits and pays, 2: wherever it fits
-    if (mode == 0 || n == 0 || sc.num_cus < 8) return false;
-    // a launch that timed out (its grid was not resident as a whole: the GPU is shared with other work)
-    // cost 50 ms before the frame went through the other loop: the next calls do not try again
-    if (m->sc.loop_cooldown > 0) {
-        --m->sc.loop_cooldown;
-        return false;
-    }
-    int lw = icp_lw(n, sparse_voxels(m));
-    bool filter = wants_filter(m, n, sem_th);
-    if (lw < 1) return false;                          // (k_loop is built for 2..16 lanes per query)
-    const uint64_t cap_waves = (2ull * static_cast<uint64_t>(sc.num_cus) - 1) / 32 * 32 * kLoopMaxWavesHost;
-    auto waves_at = [n](int l) { return (n + (64u >> l) - 1) / (64u >> l); };
-    if (env_int("SAGEICP_LW", -1) < 0) {
-        // An iteration of k_loop ends with its slowest wave, and with eight or more lanes per query the
-        // lanes stride through a query's voxels in flat order (kernels.hip): more lanes than the
-        // launch-per-iteration loop would take pay here as long as the waves fit the machine — 8 where it
-        // would take 4 (c1: 17.8 -> 13.4 us per iteration), 16 against dense voxels (15k queries: 16.3 ->
-        // 15.8; c1's sparse ones: 13.4 -> 14.4); profiles/r04/flat_where.txt
-        if (lw < 3 && waves_at(3) <= cap_waves) lw = 3;
-        if (lw == 3 && !sparse_voxels(m) && waves_at(4) <= cap_waves) lw = 4;
-    }
-    uint64_t waves = waves_at(lw);
-    if (env_int("SAGEICP_LW", -1) < 0) {
-        // fewer lanes per query than the launch-per-iteration loop would take, if that is what makes the frame
-        // fit: four instead of eight pay (32k .. 61k queries: 22.8 against 23.3 us per iteration at 40k, 23.7 /
-        // 25.7 at 50k, 23.8 / 28.0 at 60k — profiles/r04/loop_mid2.txt, lanes_probe2.txt), two do not (70k: 35.4
-        // against 29.9) and are taken only where the loop is forced (SAGEICP_LOOP=2)
-        while (waves > cap_waves && lw > (mode == 2 ? 1 : 2)) {
-            --lw;
-            waves = waves_at(lw);
-        }
-    }
-    if (waves > cap_waves) return false;
-    // (query workgroups come in XCD stripes: 8 x kLoopStripe = 32 of them, kernels.hip)
-    const uint64_t max_wgs = (2ull * static_cast<uint64_t>(sc.num_cus) - 1) / 32 * 32;
-    int nw = static_cast<int>((waves + max_wgs - 1) / max_wgs);
-    nw = std::max(nw, std::min(kLoopMaxWavesHost, std::max(1, env_int("SAGEICP_LOOP_WAVES", 4))));
-    if (nw > kLoopMaxWavesHost) return false;
-    const uint64_t wgs = ((waves + nw - 1) / nw + 31) / 32 * 32;
-    if (wgs / 8 > 255) return false;                   // (a word of the accumulators counts its workgroups in 8 bits)
+static int loop_wgs_per_cu(const Scratch &sc, int lw, bool filter, int nw, size_t lds) {
     // (cached per shape: the occupancy query costs microseconds)
     static std::mutex mu;
-    static std::map<int, int> cache;
-    int per_cu;
+    static std::map<std::array<long, 5>, int> cache;
+    const std::array<long, 5> key{sc.device, lw, filter ? 1 : 0, nw, static_cast<long>(lds)};
+    int v;
     {
         std::lock_guard<std::mutex> lk(mu);
-        const int key = (sc.device << 16) | (lw << 8) | (filter ? 128 : 0) | nw;
         auto it = cache.find(key);
-        if (it == cache.end()) it = cache.emplace(key, loop_blocks_per_cu(lw, filter, nw)).first;
-        per_cu = it->second;
+        if (it == cache.end()) it = cache.emplace(key, loop_blocks_per_cu(lw, filter, nw, lds)).first;
+        v = it->second;
     }
-    if (std::min(per_cu, 2) * static_cast<uint64_t>(sc.num_cus) < wgs + 1) return false;
-    out->lw = lw;
-    out->nw = nw;
-    out->grid = static_cast<int>(wgs) + 1;
-    out->filter = filter;
-    return true;
+    // The kernel is built for SAGE_LOOP_OCC waves per SIMD, and the occupancy query assumes that the waves of the
+    // resident workgroups spread evenly over the four SIMDs of a CU.  They do not: four workgroups of seven waves
+    // (28 waves: seven per SIMD by the query) are NOT resident together on gfx950 (profiles/r05: the launch timed
+    // out) — a workgroup's waves go to the SIMDs in turn, so what fits is what fits when every workgroup puts
+    // its ceil(nw / 4) waves on the same SIMD.  Four waves per workgroup, seven workgroups per CU fill the CU.
+    return std::min(v, SAGE_LOOP_OCC / ((nw + 3) / 4));
+}
+static bool plan_loop(const sageicp_map *m, uint64_t n, double sem_th, LoopPlan *out) {
+    const Scratch &sc = m->sc;
+    const int mode = env_int("SAGEICP_LOOP", 1);       // 0: never, 1 / 2: wherever the frame fits
+    if (mode == 0 || n == 0 || sc.num_cus < 8) return false;
+    const bool sparse = sparse_voxels(m);
+    const bool filter = wants_filter(m, n, sem_th);
+    const uint64_t cus = static_cast<uint64_t>(sc.num_cus);
+    const int env_nw = std::min(kLoopMaxWavesHost, std::max(0, env_int("SAGEICP_LOOP_WAVES", 0)));
+    const int env_gpw = std::max(0, env_int("SAGEICP_LOOP_GPW", 0));
+    auto groups_at = [n](int l) { return (n + (64u >> l) - 1) / (64u >> l); };
+    auto round32 = [](uint64_t w) { return std::max<uint64_t>(32, (w + 31) / 32 * 32); };   // (XCD stripes: 8 x kLoopStripe)
+    // the accumulator words count their workgroups in 8 bits, and (digit << 8) summed over a copy's workgroups
+    // and their groups must stay inside 63 bits: |digit| < 2^42 per group (kernels.hip, wg_sums_to_acc)
+    auto countable = [](uint64_t wgs, uint64_t gpw) { return wgs / 8 <= 255 && (wgs / 8) * gpw <= 4096; };
+    // one wave per group: nw groups per workgroup of nw waves
+    auto one_pass = [&](int lw, int nw, LoopPlan *pl) {
+        const uint64_t wgs = round32((groups_at(lw) + nw - 1) / nw);
+        const size_t lds = loop_lds_bytes(lw, nw, nw);
+        const int k = loop_wgs_per_cu(sc, lw, filter, nw, lds);
+        if (k < 1 || wgs + 2 > static_cast<uint64_t>(k) * cus || !countable(wgs, nw)) return false;
+        *pl = LoopPlan{lw, nw, nw, static_cast<int>(wgs), filter};
+        return true;
+    };
+    // the waves of a workgroup take several groups each, one after another: as many resident waves as the
+    // registers allow, the groups spread over all the workgroups that fit
+    auto multi_pass = [&](int lw, LoopPlan *pl) {
+        const uint64_t groups = groups_at(lw);
+        int best = -1;
+        const int order[] = {4, 8, 7, 6, 5, 3, 2, 1};
+        for (int nw : order) {
+            if (env_nw && nw != env_nw) continue;
+            if (!env_nw && nw < 4) continue;
+            for (int k = SAGE_LOOP_OCC / ((nw + 3) / 4); k >= 1; --k) {
+                if (static_cast<uint64_t>(k) * cus < 34) break;
+                const uint64_t cap = (static_cast<uint64_t>(k) * cus - 2) / 32 * 32;
+                uint64_t gpw = env_gpw ? static_cast<uint64_t>(env_gpw) : (groups + cap - 1) / cap;
+                const uint64_t wgs = round32((groups + gpw - 1) / gpw);
+                if (wgs > cap) continue;
+                if (!env_gpw) gpw = (groups + wgs - 1) / wgs;
+                const size_t lds = loop_lds_bytes(lw, nw, static_cast<int>(gpw));
+                if (lds > 160 * 1024 || !countable(wgs, gpw)) continue;
+                if (loop_wgs_per_cu(sc, lw, filter, nw, lds) < k) continue;
+                if (k * nw > best) {
+                    best = k * nw;
+                    *pl = LoopPlan{lw, nw, static_cast<int>(gpw), static_cast<int>(wgs), filter};
+                }
+                break;                          // (fewer workgroups per CU only mean fewer resident waves)
+            }
+        }
+        return best > 0;
+    };
+    const int forced = env_int("SAGEICP_LW", -1);
+    int lw = forced >= 0 ? std::min(forced, 4) : icp_lw(n, sparse);
+    if (lw < 1) return false;                          // (k_loop is built for 2..16 lanes per query)
+    if (forced < 0 && !env_gpw) {
+        // An iteration of k_loop ends with its slowest wave, and with eight or more lanes per query the
+        // lanes stride through a query's voxels in flat order (kernels.hip): while every group still gets a
+        // wave of its own, more lanes than the launch-per-iteration loop would take pay — 8 where it
+        // would take 4 (c1: 17.8 -> 13.4 us per iteration), 16 against dense voxels (15k queries: 16.3 ->
+        // 15.8; c1's sparse ones: 13.4 -> 14.4); profiles/r04/flat_where.txt
+        const uint64_t few = 15 * cus;                 // (3,840 waves on 256 CUs: where round 4 measured it)
+        if (lw < 3 && groups_at(3) <= few) lw = 3;
+        if (lw == 3 && !sparse && groups_at(4) <= few) lw = 4;
+    }
+    const bool dbg = env_int("SAGEICP_LOOP_DEBUG", 0) != 0;
+    bool ok = !env_gpw && one_pass(lw, env_nw ? env_nw : 4, out);
+    if (!ok) ok = multi_pass(lw, out);
+    if (dbg) {
+        if (ok)
+            std::fprintf(stderr, "sageicp: one-launch loop for %llu queries: %d lanes/query, %d workgroups of %d waves, %d groups each, "
+                                 "%zu B of LDS (%d workgroups per CU by the occupancy query, %d CUs)\n",
+                         static_cast<unsigned long long>(n), 1 << out->lw, out->wgs, out->nw, out->gpw,
+                         loop_lds_bytes(out->lw, out->nw, out->gpw),
+                         loop_wgs_per_cu(sc, out->lw, filter, out->nw, loop_lds_bytes(out->lw, out->nw, out->gpw)), sc.num_cus);
+        else
+            std::fprintf(stderr, "sageicp: %llu queries at %d lanes/query do not fit the one-launch loop (7 waves x 4 workgroups "
+                                 "of 36 KB per CU by the occupancy query: %d)\n",
+                         static_cast<unsigned long long>(n), 1 << lw,
+                         loop_wgs_per_cu(sc, lw, filter, 7, 36 * 1024));
+    }
+    return ok;
 }
 
 // The ICP loop of Registration.cpp:127-138 as a stream of launches: k_icp (search + accumulation)
@@ -1446,6 +1520,8 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     // (the direct exchange enqueues no collective, so its loop can be polled like the 1-GPU one)
     const bool polled = (!comm || p2p) && env_int("SAGEICP_CHUNKED", 0) == 0;
     if (prof && (rc = sc.reserve_events(polled ? kMaxIterations : kChunkMax))) return rc;
+    // (probes only: SAGEICP_MAX_ITER stops either loop early — the launch-per-iteration loop then simply runs out of launches)
+    const int max_it = std::min(kMaxIterations, std::max(1, env_int("SAGEICP_MAX_ITER", kMaxIterations)));
 
     fill_state(sc.h_state, init);
     if (polled) {
@@ -1454,11 +1530,20 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     }
     HIPCHK(hipMemcpyAsync(sc.d_state, sc.h_state, sizeof(IcpState), hipMemcpyHostToDevice, s));
 
-    int lw = icp_lw(n, sparse_voxels(m));
+    // Lanes per query are decided in ONE place, whichever loop then runs: a frame that fits the one-launch
+    // loop takes that loop's choice also when the launch-per-iteration loop registers it (a launch that timed
+    // out, the calls of the cool-down after it) — the fixed-point sums are rounded once per group of queries,
+    // so their bits depend on the lanes per query and on nothing else, and a call repeated gives the same bits.
     LoopPlan plan{};
-    bool use_loop = !comm && !g_fp64_partials && plan_loop(m, n, sem_th, &plan);
-    // (the one-launch loop chooses its own lanes per query, plan.lw; `lw` stays what the launch-per-iteration
-    // loop takes — also when it has to finish a frame the one-launch loop gave up on)
+    const bool loop_shape = !g_fp64_partials && (!comm || p2p) && plan_loop(m, n, sem_th, &plan);
+    const int lw = loop_shape ? plan.lw : icp_lw(n, sparse_voxels(m));
+    // a launch that timed out (its grid was not resident as a whole: the GPU is shared with other work)
+    // cost 50 ms before the frame went through the other loop: the next calls do not try again
+    bool use_loop = loop_shape;
+    if (use_loop && sc.loop_cooldown > 0) {
+        --sc.loop_cooldown;
+        use_loop = false;
+    }
     const unsigned loop_waves = use_loop ? static_cast<unsigned>((n + (64u >> plan.lw) - 1) / (64u >> plan.lw)) : 0u;
     const int blocks = n ? icp_blocks_for(static_cast<int>(n), lw) : 1;
     if ((rc = ensure_cand(m, wants_filter(m, n, sem_th)))) return rc;
@@ -1471,6 +1556,52 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     ip.accept_r2 = accept_threshold(max_dist);
     ip.counters = stats ? sc.d_cand : nullptr;
     if (stats) HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * 2 * (std::max(ip.nwaves, loop_waves) + 1), s));
+
+    // direct exchange of the sums with the peer GPUs (k_fin mode 3, or the solving wave of the one-launch loop)
+    P2pParams xp{};
+    xp.nranks = 1;
+    if (p2p) {
+        xp.nranks = comm->nranks;
+        xp.rank = comm->rank;
+        for (int r = 0; r < comm->nranks; ++r) xp.block[r] = comm->blocks[r];
+        xp.exchanges = comm->d_exchanges;
+        // a peer's sums normally arrive within microseconds, but its FIRST launches of a process (code
+        // object loading) or a GPU shared with other work can take a second: five seconds of in-kernel
+        // waiting is a failure (SAGEICP_P2P_TIMEOUT_S overrides, e.g. under a debugger)
+        xp.timeout_ticks = 100000000ull * static_cast<unsigned long long>(
+                               std::max(1, env_int("SAGEICP_P2P_TIMEOUT_S", 5)));
+        if (const int ticks = env_int("SAGEICP_P2P_TIMEOUT_TICKS", 0))      // tests: provoke a timeout
+            xp.timeout_ticks = static_cast<unsigned long long>(ticks);
+    }
+    LoopParams L{};
+    if (use_loop) {
+        // ---- the whole loop in one launch (kernels.hip, k_loop): first its solving wave, on its own stream —
+        // it has to hold its registers before the grid fills the machine; it waits for the grid's go
+        L.sh = sc.d_loop;
+        L.st = sc.d_state;
+        L.nw = plan.nw;
+        L.gpw = plan.gpw;
+        L.wgs = plan.wgs;
+        L.contiguous = env_int("SAGEICP_LOOP_CONTIGUOUS", 0) ? 1 : 0;
+        {
+            const uint64_t qw = 64u >> plan.lw, groups = (n + qw - 1) / qw;
+            const uint64_t per = std::min<uint64_t>((groups + 7) / 8, static_cast<uint64_t>(plan.wgs / 8) * plan.gpw);
+            for (int x = 0; x <= 8; ++x) L.xcd_first[x] = static_cast<uint32_t>(std::min<uint64_t>(groups, x * per));
+            if (per * 8 < groups) L.contiguous = 0;
+        }
+        // a wait inside the launch normally takes microseconds; 50 ms of it means the grid is not
+        // resident as a whole (SAGEICP_LOOP_TIMEOUT_MS overrides, e.g. under a debugger)
+        L.timeout_ticks = 100000ull * static_cast<unsigned long long>(std::max(1, env_int("SAGEICP_LOOP_TIMEOUT_MS", 50)));
+        if (const int ticks = env_int("SAGEICP_LOOP_TIMEOUT_TICKS", 0))      // tests: provoke a timeout
+            L.timeout_ticks = static_cast<unsigned long long>(ticks);
+        L.max_iterations = max_it;
+        L.epoch = ++sc.loop_epoch;
+        for (int i = 0; i < 7; ++i) L.T0[i] = init[i];
+        L.shared_loop = comm ? 1 : 0;
+        launch_loop_solve(L, xp, sc.stream2);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(sc.ev_solve, sc.stream2));
+    }
 
     // Spatial ordering of the frame: the loop runs on a copy sorted by map-frame voxel under the
     // initial guess, so that the queries of a wave share home voxels and neighbouring waves touch
@@ -1488,35 +1619,36 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     uint32_t nn_launches = 0;
     bool looped = false;
     if (use_loop) {
-        // ---- the whole loop in one launch (kernels.hip, k_loop) ------------------------------------------
+        // ---- ... then the grid (the shared block zeroed first: the solving wave starts on the grid's go)
         if (prof && (rc = sc.reserve_events(1))) return rc;
         IcpParams lp = ip;
         lp.filter = plan.filter ? ip.filter : 0;
         lp.nwaves = loop_waves;
-        LoopParams L{};
-        L.sh = sc.d_loop;
-        L.st = sc.d_state;
-        L.nw = plan.nw;
-        // a wait inside the launch normally takes microseconds; 50 ms of it means the grid is not
-        // resident as a whole (SAGEICP_LOOP_TIMEOUT_MS overrides, e.g. under a debugger)
-        L.timeout_ticks = 100000ull * static_cast<unsigned long long>(std::max(1, env_int("SAGEICP_LOOP_TIMEOUT_MS", 50)));
-        if (const int ticks = env_int("SAGEICP_LOOP_TIMEOUT_TICKS", 0))      // tests: provoke a timeout
-            L.timeout_ticks = static_cast<unsigned long long>(ticks);
-        L.max_iterations = kMaxIterations;
         HIPCHK(hipMemsetAsync(sc.d_loop, 0, sizeof(LoopShared), s));
         if (prof) HIPCHK(hipEventRecord(sc.events[1], s));
-        launch_loop(lp, L, plan.lw, plan.grid, s);
+        launch_loop(lp, L, plan.lw, s);
         if (prof) HIPCHK(hipEventRecord(sc.events[2], s));
+        HIPCHK(hipStreamWaitEvent(s, sc.ev_solve, 0));             // the solving wave writes the final state
         if (stats) launch_sum_counters(sc.d_cand, static_cast<int>(lp.nwaves), sc.d_state, s);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(sc.h_state, sc.d_state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        if (sc.h_state->bad_input) {
+        if (sc.h_state->bad_input && !comm) {
+            looped = true;                     // (reported below)
+        } else if (sc.h_state->exchange_failed) {
             looped = true;                     // (reported below)
         } else if (sc.h_state->loop_aborted || !sc.h_state->done) {
             // a wait inside the launch timed out (the grid was not resident as a whole: another stream
-            // or process held CUs): the launch-per-iteration loop below registers the frame instead
+            // or process held CUs): the launch-per-iteration loop below registers the frame instead,
+            // with the same lanes per query
             sc.loop_cooldown = std::max(0, env_int("SAGEICP_LOOP_COOLDOWN", 256));
+            if (comm) {
+                // (the peers are somewhere inside their loops: there is no starting again in step)
+                comm->p2p = false;
+                comm->poisoned = true;
+                return fail(SAGEICP_ERR_RCCL, "one-launch loop under a communicator: a wait inside the launch timed out "
+                                              "(the GPU is shared with other work?); SAGEICP_LOOP=0 selects the launch-per-iteration loop");
+            }
             fill_state(sc.h_state, init);
             if (polled) {
                 std::memset(sc.h_prog, 0, sizeof(IcpProgress));
@@ -1557,19 +1689,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     fp.nparts = n ? (red_rows ? red_rows : blocks) : 0;
     fp.mode = p2p ? 3 : (comm ? 1 : 0);
     fp.standalone = 0;
-    if (p2p) {
-        fp.p2p.nranks = comm->nranks;
-        fp.p2p.rank = comm->rank;
-        for (int r = 0; r < comm->nranks; ++r) fp.p2p.block[r] = comm->blocks[r];
-        fp.p2p.exchanges = comm->d_exchanges;
-        // a peer's sums normally arrive within microseconds, but its FIRST launches of a process (code
-        // object loading) or a GPU shared with other work can take a second: five seconds of in-kernel
-        // waiting is a failure (SAGEICP_P2P_TIMEOUT_S overrides, e.g. under a debugger)
-        fp.p2p.timeout_ticks = 100000000ull * static_cast<unsigned long long>(
-                                   std::max(1, env_int("SAGEICP_P2P_TIMEOUT_S", 5)));
-        if (const int ticks = env_int("SAGEICP_P2P_TIMEOUT_TICKS", 0))      // tests: provoke a timeout
-            fp.p2p.timeout_ticks = static_cast<unsigned long long>(ticks);
-    }
+    if (p2p) fp.p2p = xp;
 
     // one iteration; `slot` indexes its 5 profiling events
     // Profiling level 1 brackets k_icp in one iteration out of 8 (two event records cost ~6 us of
@@ -1616,7 +1736,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
             const unsigned long long w = *word;
             const int comp = static_cast<int>(w & 0xFFFFFFFFull);
             if (w >> 32) break;                                  // converged or out of iterations
-            if (enq < kMaxIterations && enq - comp < depth) {
+            if (enq < max_it && enq - comp < depth) {
                 if ((rc = enqueue_iteration(enq, enq))) return rc;
                 ++enq;
                 spins = 0;
@@ -1627,7 +1747,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
                 const hipError_t q = hipStreamQuery(s);
                 if (q != hipSuccess && q != hipErrorNotReady)
                     return fail(SAGEICP_ERR_HIP, std::string("ICP loop: ") + hipGetErrorString(q));
-                if (q == hipSuccess && (*word >> 32) == 0 && enq >= kMaxIterations)
+                if (q == hipSuccess && (*word >> 32) == 0 && enq >= max_it)
                     break;     // everything ran and nothing flagged the end: read the state below
             }
         }
@@ -1698,7 +1818,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         stats->nn_launches = nn_launches;
         stats->sum_candidates = st.sum_candidates;
         stats->pairs_evaluated = st.sum_pairs;
-        stats->lanes_per_query = 1u << (looped ? plan.lw : lw);
+        stats->lanes_per_query = 1u << lw;
         stats->compact_scan = (looped ? plan.filter && ip.filter : ip.filter != 0) ? 1u : 0u;
         stats->single_launch = looped ? 1u : 0u;
         for (int i = 0; i < 64 && i < st.iter; ++i) stats->n_corr_hist[i] = st.n_corr[i];
@@ -2882,6 +3002,19 @@ int sageicp_metrics_absolute_trajectory_error(const double *poses_gt, const doub
 }
 
 }  // extern "C"
+
+// probes: the loop state the last RegisterFrame of this map left on the host (pose T[7], T_icp[7], the last
+// reduced sums [20], iterations, last step)
+extern "C" int sageicp_debug_last_state(const sageicp_map *m, double *out36) {
+    if (!m || !m->sc.h_state) return SAGEICP_ERR_INVALID;
+    const sageicp::IcpState &st = *m->sc.h_state;
+    for (int i = 0; i < 7; ++i) out36[i] = st.T[i];
+    for (int i = 0; i < 7; ++i) out36[7 + i] = st.T_icp[i];
+    for (int i = 0; i < sageicp::kNumSums; ++i) out36[14 + i] = st.sums[i];
+    out36[34] = st.iter;
+    out36[35] = st.last_step_norm;
+    return SAGEICP_OK;
+}
 
 #ifdef SAGE_NN_TIMING
 // probe: map points handed to every query in the last iteration (sorted order)

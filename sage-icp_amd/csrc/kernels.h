@@ -137,14 +137,21 @@ struct RedParams {
 int red_rows_for(int nparts);                 // 0: single stage
 void launch_red(const RedParams &p, hipStream_t s);
 
-// ---- k_loop: the whole ICP loop of a frame that fits the machine in ONE launch -----------------
-// Every wave keeps its queries (frame point, previous answer and its record in registers, the
-// neighbourhood row in LDS) for the whole call; an iteration ends with the workgroups adding their
-// sums into fixed-point accumulators whose words count their contributors, a one-wave solving workgroup
-// reading them when they are complete, solving and publishing the next pose, and one wave per
-// workgroup waiting for it — no kernel boundary, no k_fin, L2s that stay warm.  Everything the workgroups share inside the launch is
-// accessed with agent-scope atomics only (per-XCD L2s are not coherent with each other); the block
-// is zeroed before every launch.
+// ---- k_loop: the whole ICP loop of a frame that fits the machine's LDS in ONE launch -------------
+// (Registration.cpp:127-138.)  The frame is cut into GROUPS of 64 >> lw consecutive queries — what one
+// wave of k_icp holds.  A workgroup owns `gpw` groups for the whole call and keeps, per query, in LDS:
+// the 128-B neighbourhood row and a 96-B state record (pristine frame point, the previous answer's key
+// and fp64 record, the home voxel the row was built for).  Its waves take the groups one after another
+// from an LDS counter, so what has to be resident is the LDS, not one wave per group: the c2 frame
+// (7,500 groups at four lanes per query) runs on 28 waves per CU.  Nothing per-query is read from or
+// written to HBM after the first pass; the L2s stay warm across iterations.
+// An iteration ends with the workgroups adding their sums into fixed-point accumulators whose words
+// count their contributors, ONE solving wave — its own kernel (k_loop_solve, ~120 registers against
+// the search's 72) on a second stream, resident beside the grid — reading them when they are
+// complete, [exchanging the sums with the peer GPUs,] solving and publishing the next pose, and one
+// wave per workgroup waiting for it: no kernel boundary, no k_fin.  Everything the workgroups share
+// inside the launch is accessed with agent-scope atomics only (per-XCD L2s are not coherent with each
+// other); the block is zeroed before every launch; every wait is bounded.
 constexpr int kLoopReplicas = 8;           // accumulator copies (workgroup b adds into copy b & 7)
 constexpr int kLoopPoseGranules = 25;      // R[9], t[3] as 24 x {tag, 32 bits} + {tag, done}
 struct LoopShared {
@@ -152,20 +159,42 @@ struct LoopShared {
                                                         // (digit << 8) | workgroups in it; word 63 of copy 0: overflow flag
     unsigned long long pose[32];                        // granules (tag << 32) | payload, tag = iteration + 1
     unsigned long long abort_word[16];                  // [0] != 0: a wait timed out somewhere — everybody leaves
+    unsigned long long go[16];                          // [0]: the call's epoch, stored by k_loop's first workgroup when the
+                                                        // grid has started (bit 63: the frame holds a non-finite point)
 };
 struct LoopParams {
     LoopShared *sh;
     IcpState *st;                  // in: the initial pose; out: the final loop state (written by the solving wave)
     int nw;                        // waves per workgroup (<= kLoopMaxWaves)
+    int gpw;                       // groups of (64 >> lw) queries a workgroup owns
+    int wgs;                       // query workgroups (a multiple of 8 x kLoopStripe); each accumulator copy counts wgs / 8
+    int contiguous;                // 0: XCD x serves stripes x, x + 8, ... of kLoopStripe workgroups; 1: XCD x serves the
+                                   // groups [xcd_first[x], xcd_first[x + 1]) of the (spatially sorted) frame
+    uint32_t xcd_first[9];
     unsigned long long timeout_ticks;      // s_memrealtime ticks (100 MHz) any wait may take
     int max_iterations;            // kMaxIterations (tests: fewer)
+    unsigned long long epoch;      // identifies this call: the solving wave is launched FIRST (it must be resident when the
+                                   // grid fills the machine) and waits for LoopShared::go to carry this number
+    double T0[7];                  // the initial pose (the solving wave starts before the loop state is uploaded)
+    int shared_loop;               // 1: under a communicator — an overflowing sum or a bad frame point does not end
+                                   // this rank's loop on its own (the ranks must keep exchanging in step)
 };
+struct LoopArgs {                  // k_loop's one argument: its passes re-read it from the kernel-argument segment
+    IcpParams P;
+    LoopParams L;
+};
+#ifndef SAGE_LOOP_OCC
+#define SAGE_LOOP_OCC 7        // waves per SIMD k_loop's register allocation allows (72 registers), i.e. 28 waves per CU
+#endif
 constexpr int kLoopMaxWavesHost = 8;
-size_t loop_lds_bytes(int lw, int nw);
-// workgroups of `nw` waves resident per CU for the variant (lw, filter): 0 = the kernel cannot be
-// used on this device; the grid must not exceed this number x CUs
-int loop_blocks_per_cu(int lw, bool filter, int nw);
-void launch_loop(const IcpParams &p, const LoopParams &l, int lw, int grid, hipStream_t s);
+constexpr int kLoopStripeHost = 4;
+constexpr int kLoopStateWords = 24;        // per query: f[8] | pp[8] | prev key, prev offset, kx, ky | kz, occ, -, -
+size_t loop_lds_bytes(int lw, int nw, int gpw);
+// workgroups of `nw` waves and `lds` bytes resident per CU for the variant (lw, filter): 0 = the kernel
+// cannot be used on this device; the grid must not exceed this number x CUs (less one slot for the solver)
+int loop_blocks_per_cu(int lw, bool filter, int nw, size_t lds);
+void launch_loop(const IcpParams &p, const LoopParams &l, int lw, hipStream_t s);
+void launch_loop_solve(const LoopParams &l, const P2pParams &x, hipStream_t s);
 
 constexpr int kMaxPartials = 1 << 16;
 constexpr uint64_t kMaxQueries = (1ull << 26) - 1;

@@ -386,57 +386,62 @@ __device__ __forceinline__ void wg_sums_to_acc(const double *ws, const uint32_t 
 }
 
 // ---- k_loop (the whole ICP loop in one launch, below) shares the body --------------------------
-// What a lane of k_loop keeps in registers across the iterations of a call: its query's pristine
-// frame point, the previous iteration's answer and that point's record (the seed of the next
-// search and, while the answer stays, the target of the pair: no load), and the home voxel its
-// neighbourhood row — which stays in LDS for the whole call — was built for.
-struct LoopLane {
-    Point4 f;
-    Point4 pp;
-    uint2 prev;
-    int kx, ky, kz;
-    unsigned occ;
+// A GROUP = the 64 >> LW consecutive queries one wave of k_icp would hold.  A workgroup of k_loop owns
+// a few groups for the whole call and keeps per query, in LDS: the neighbourhood row (kRowLdsStride
+// words) and a state record of kLoopStateWords words —
+//   [0..7]   f   the pristine frame point (fp64 x, y, z, label)
+//   [8..15]  pp  the previous answer's fp64 record (the seed of the next search and, while the
+//                answer stays, the target of the pair: no load)
+//   [16,17]  the previous answer {key = (voxel << 8) | slot, byte offset of its record}
+//   [18..21] the home voxel the row was built for | the row's occupancy mask
+// One copy per QUERY (its lanes read the same address: a broadcast), where the first k_loop kept a
+// copy per LANE in 22 registers: the search now compiles at k_icp's budget (7 waves per SIMD) and a
+// wave is no longer tied to one group — the waves of a workgroup take its groups from an LDS counter.
+struct LoopGroup {
+    uint32_t *rows;            // LDS [QW][kRowLdsStride]
+    uint32_t *state;           // LDS [QW][kLoopStateWords]
+    double *red;               // LDS: the running wave's scratch for the epilogue's transposed reduction
+    double *ws;                // LDS [16]: where the group's fp64 sums are parked
+    uint32_t *pairs;           // LDS: ... and its accepted pairs
+    unsigned group;            // index of the group in the frame: queries group * QW ...
 #ifdef SAGE_LOOP_TIMING
     unsigned long long ph[8], tprev;           // probe builds: cycles per phase of the body, summed over the iterations
 #endif
 };
 #ifdef SAGE_LOOP_TIMING
-#define LP_T(i) do { if constexpr (PERSIST) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); LL->ph[i] += _t - LL->tprev; LL->tprev = _t; } } while (0)
+#define LP_T(i) do { if constexpr (PERSIST) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); G->ph[i] += _t - G->tprev; G->tprev = _t; } } while (0)
 #else
 #define LP_T(i) do { } while (0)
 #endif
 constexpr int kLoopMaxWaves = kLoopMaxWavesHost;   // waves per workgroup of k_loop (<= 512 threads)
-constexpr unsigned kLoopStripe = 4;          // workgroups of k_loop per XCD stripe (its grid: 32 k + 1 workgroups)
+constexpr unsigned kLoopStripe = kLoopStripeHost;  // workgroups of k_loop per XCD stripe (its grid: a multiple of 32)
 constexpr int kNoVoxel = 0x7FFFFFFF;        // a home voxel no point has (|index| < 2^20): row not built yet
-// LDS header of a k_loop workgroup (words): ws[8][16] fp64 sums | accepted pairs [8] | arrival
-// counter | the pose of this iteration (R[9], t[3]) | done | loop state of the solving workgroup
-constexpr unsigned kLpSums = 0, kLpPairs = 2u * 16u * kLoopMaxWaves, kLpArrive = kLpPairs + kLoopMaxWaves;
-constexpr unsigned kLpPose = (kLpArrive + 1u + 3u) & ~3u;          // 12 doubles, 16-B aligned
-constexpr unsigned kLpDone = kLpPose + 24u;
-// (used by workgroup 0 only) T[7] | T_icp[7] | the reduced sums S[kNumSums] | the pose being published
-// [12] | the 64 accumulator words
-constexpr unsigned kLpT = (kLpDone + 1u + 1u) & ~1u;
-constexpr unsigned kLpS = kLpT + 28u;
-constexpr unsigned kLpPub = kLpS + 2u * kNumSums;
-constexpr unsigned kLpDigits = kLpPub + 24u;
-constexpr unsigned kLpDbg = kLpDigits + 2u * kAccWords;      // probe builds: max points of a query | stale queries | points, per workgroup
+constexpr unsigned kStPrev = 16, kStKey = 18;
+// LDS of a k_loop workgroup (words): header { arrival counter | next group | the pose of this iteration
+// (R[9], t[3]) | done } | ws[gpw][16] fp64 sums | accepted pairs [gpw] | the groups { rows, state } |
+// one reduction scratch per wave
+constexpr unsigned kLpArrive = 0, kLpNext = 1, kLpDone = 2;
+constexpr unsigned kLpPose = 4;                                    // 12 doubles, 16-B aligned
+constexpr unsigned kLpDbg = kLpPose + 24u;                         // probe builds: max points of a query | stale queries | points
 constexpr unsigned kLpHeaderWords = (kLpDbg + 4u + 15u) & ~15u;
-__host__ __device__ constexpr unsigned loop_wave_words(int lw) {
-    // the rows of the wave's queries (they stay for the whole call) + the epilogue's transposed
-    // reduction, 16 components x (queries + 2) fp64
-    return static_cast<unsigned>(kRowLdsStride * (64 >> lw) + 64 + 2 * 16 * ((64 >> lw) + 2));
+constexpr int kLoopRedRounds = 4;           // the 16 components are reduced four at a time (LDS: 4 x (QW + 2) fp64 per wave)
+__host__ __device__ constexpr unsigned loop_group_words(int lw) {
+    return static_cast<unsigned>((kRowLdsStride + kLoopStateWords) * (64 >> lw));
 }
+__host__ __device__ constexpr unsigned loop_red_words(int lw) {
+    return static_cast<unsigned>(2 * (kCount / kLoopRedRounds) * ((64 >> lw) + 2));
+}
+__host__ __device__ constexpr unsigned loop_ws_words(unsigned gpw) { return gpw * 2u * kCount + ((gpw + 7u) & ~7u); }
 
-// PERSIST (k_loop): the per-query state comes from / goes back to `LL` (registers), the pose from
+// PERSIST (k_loop): the body runs on group `G` — rows and per-query state in LDS — with the pose from
 // `pose` (LDS: R[9], t[3]); nothing is read from or written to the global rows / nn_prev arrays;
-// the body ends with the wave's sums parked in the workgroup's LDS header and returns true on the
-// last wave of the workgroup to arrive (`nw` waves), which the caller lets finish the iteration.
+// the body ends with the group's sums parked at G->ws.
 #ifndef SAGE_LOOP_FLAT_MINW
 #define SAGE_LOOP_FLAT_MINW 8      // k_loop: flat-order scan from this many lanes per query (icp_body)
 #endif
 template <int LW, bool FUSED, bool FILT, bool PERSIST = false, bool FLATQ = false>
-__device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, LoopLane *LL = nullptr,
-                                         const double *pose = nullptr, int nw = kIcpWavesPerBlock);
+__device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, LoopGroup *G = nullptr,
+                                         const double *pose = nullptr);
 
 // a pair of scanned points in flight: compact records (FILT) or full ones
 struct PairCompact {
@@ -478,8 +483,7 @@ void k_icp(IcpParams P) {
 }
 
 template <int LW, bool FUSED, bool FILT, bool PERSIST, bool FLATQ>
-__device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, LoopLane *LL, const double *pose,
-                                         int nw) {
+__device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, LoopGroup *G, const double *pose) {
     static_assert(!PERSIST || FUSED, "the persistent loop always accumulates");
     constexpr int W = 1 << LW;                 // lanes per query
     constexpr int QW = 64 >> LW;               // queries per wave
@@ -493,14 +497,24 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
 #ifdef SAGE_ICP_DELAY_PROBE
     const unsigned long long probe_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    const int lane = static_cast<int>(threadIdx.x & 63u);
+    int lane;
+    if constexpr (PERSIST) {
+        // (k_loop: re-derived in every pass — what the compiler knows to be invariant across the iteration
+        // loop it hoists out of it and keeps, with everything computed from it, in registers the scan needs)
+        unsigned l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        lane = static_cast<int>(l);
+    } else {
+        lane = static_cast<int>(threadIdx.x & 63u);
+    }
     const int wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     if (FUSED && !PERSIST) {
         if (threadIdx.x == 0) smem[kWgArrive] = 0u;
         __syncthreads();
     }
-    uint32_t *wl = PERSIST ? smem + kLpHeaderWords + static_cast<unsigned>(wv) * loop_wave_words(LW)
-                           : smem + kWgHeaderWords + static_cast<unsigned>(wv) * icp_wave_words(LW);
+    uint32_t *wl;
+    if constexpr (PERSIST) wl = G->rows;
+    else wl = smem + kWgHeaderWords + static_cast<unsigned>(wv) * icp_wave_words(LW);
 
     // Workgroup b is dispatched to XCD b % 8 (observed; speed only): XCD x serves the stripes
     // x, x+8, x+16, ... of kStripe consecutive workgroups' worth of the spatially sorted frame,
@@ -509,11 +523,14 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
     // of the frame per XCD left the XCDs with 57k to 97k points to look at per iteration on a c2 shard,
     // and the iteration ends with the slowest, profiles/r04/loop_times.txt.)
     constexpr unsigned kStripe = SAGE_ICP_STRIPE;
-    const unsigned xcd = blockIdx.x & 7u, jb = blockIdx.x >> 3;
-    const unsigned wg = PERSIST ? ((jb / kLoopStripe) * 8u + xcd) * kLoopStripe + (jb % kLoopStripe)
-                                : ((jb / kStripe) * 8u + xcd) * kStripe + (jb % kStripe);
-    const unsigned wave_id = wg * static_cast<unsigned>(PERSIST ? nw : kIcpWavesPerBlock) +
-                             static_cast<unsigned>(wv);                            // wave-uniform
+    unsigned wave_id;                                                               // wave-uniform
+    if constexpr (PERSIST) {
+        wave_id = G->group;                    // (k_loop maps its workgroups to groups itself)
+    } else {
+        const unsigned xcd = blockIdx.x & 7u, jb = blockIdx.x >> 3;
+        const unsigned wg = ((jb / kStripe) * 8u + xcd) * kStripe + (jb % kStripe);
+        wave_id = wg * static_cast<unsigned>(kIcpWavesPerBlock) + static_cast<unsigned>(wv);
+    }
 
     const int qw = lane >> LW;                 // this lane's query within the wave
     const unsigned ci = static_cast<unsigned>(lane) & (W - 1u);
@@ -541,12 +558,19 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
     Point4 f;
     // (named registers, not an array: the compiler leaves a uint4 array in scratch memory)
     uint4 pc0 = make_uint4(0u, 0u, 0u, 0u), pc1 = pc0, pc2 = pc0, pc3 = pc0, pc4 = pc0, pc5 = pc0, pc6 = pc0;
+    uint32_t *lst = nullptr;                   // k_loop: this query's state record (LDS)
     if constexpr (PERSIST) {
-        // k_loop: everything is already here — registers and the row in LDS
-        f = LL->f;
-        prev = LL->prev;
-        rk = make_uint4(static_cast<uint32_t>(LL->kx), static_cast<uint32_t>(LL->ky),
-                        static_cast<uint32_t>(LL->kz), LL->occ);
+        // k_loop: everything is already here, in LDS — the state record and the row
+        lst = G->state + qw * kLoopStateWords;
+        const uint4 fa = *reinterpret_cast<const uint4 *>(lst), fb = *reinterpret_cast<const uint4 *>(lst + 4);
+        const uint4 pk = *reinterpret_cast<const uint4 *>(lst + kStPrev);
+        const uint2 ko = *reinterpret_cast<const uint2 *>(lst + kStPrev + 4);
+        f.x = __hiloint2double(static_cast<int>(fa.y), static_cast<int>(fa.x));
+        f.y = __hiloint2double(static_cast<int>(fa.w), static_cast<int>(fa.z));
+        f.z = __hiloint2double(static_cast<int>(fb.y), static_cast<int>(fb.x));
+        f.l = __hiloint2double(static_cast<int>(fb.w), static_cast<int>(fb.z));
+        prev = make_uint2(pk.x, pk.y);
+        rk = make_uint4(pk.z, pk.w, ko.x, ko.y);
     } else {
         rk = *reinterpret_cast<const uint4 *>(grow + kRowKey);
         if (FUSED) prev = P.nn_prev[qc];
@@ -699,8 +723,10 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
                 }
             }
             if constexpr (PERSIST) {
-                LL->kx = s.kx; LL->ky = s.ky; LL->kz = s.kz;
-                LL->occ = o;
+                if (ci == 0u) {
+                    *reinterpret_cast<uint2 *>(lst + kStKey) = make_uint2(static_cast<uint32_t>(s.kx), static_cast<uint32_t>(s.ky));
+                    *reinterpret_cast<uint2 *>(lst + kStKey + 2) = make_uint2(static_cast<uint32_t>(s.kz), o);
+                }
             }
         }
     }
@@ -1017,7 +1043,7 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
         // one).  Only queries without a seed (the first pass of a call, a rebuilt row) scan their
         // home voxel first; a wave without such a query skips that pass altogether.
         const bool seeded = valid && prev.x != 0xFFFFFFFFu;          // (a rebuilt row re-keyed or dropped it)
-        const Point4 pp = LL->pp;
+        const Point4 pp = *reinterpret_cast<const Point4 *>(lst + 8);
         evaluate(pp, seeded, prev.x);
         merged = seeded;
         const unsigned first = seeded ? 0u : (occ & (1u << kHome));
@@ -1120,13 +1146,15 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
             // only a query whose answer changed fetches a record, on all of its lanes (one request:
             // the same address), since every lane evaluates the seed.
             const bool changed = found && mkey != prev.x;
-            g = LL->pp;
+            g = *reinterpret_cast<const Point4 *>(lst + 8);
             if (__ballot(changed)) {
                 const Point4 t = load_point(pts, changed ? woff : 0u);
-                if (changed) g = t;
+                if (changed) {
+                    g = t;
+                    if (ci == 0u) *reinterpret_cast<Point4 *>(lst + 8) = t;
+                }
             }
-            LL->pp = g;
-            LL->prev = make_uint2(found ? mkey : 0xFFFFFFFFu, woff);
+            if (ci == 0u) *reinterpret_cast<uint2 *>(lst + kStPrev) = make_uint2(found ? mkey : 0xFFFFFFFFu, woff);
             LP_T(6);
         }
 #ifdef SAGE_NN_TIMING
@@ -1160,10 +1188,56 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
         }
         const unsigned pairs = static_cast<unsigned>(__popcll(__ballot(use)));
         // Wave reduction in a fixed order (bit-reproducible): the query lanes park their 16 terms
-        // transposed in LDS (the rows are no longer needed), four lanes per component add QW / 4
+        // transposed in LDS (k_icp: the rows are no longer needed), four lanes per component add QW / 4
         // parked values each and finish with two DPP exchanges.
-        double *red = reinterpret_cast<double *>(PERSIST ? wl + kRowLdsStride * QW + 64 : wl);
         constexpr int S = QW + 2;              // fp64 stride of one component
+        if constexpr (PERSIST) {
+            // k_loop: the rows stay, the scratch is the running wave's own and holds four components
+            // at a time — the same additions in the same order, component by component
+            double *red = G->red;
+            const int c = lane >> 2, r = lane & 3;
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < kLoopRedRounds; ++k) {
+                constexpr int NC = kCount / kLoopRedRounds;
+                if (ci == 0u) {
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) red[cc * S + qw] = t[NC * k + cc];
+                }
+                // (values pass from lane to lane through LDS here: the hardware serves a wave's LDS
+                // instructions in order, but the COMPILER has to be told that the loads below see other
+                // lanes' stores — without the fences it keeps a non-writing lane's loads of round 0 for all
+                // four rounds, the addresses being the same)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                double u = 0.0;
+#pragma unroll
+                for (int e = 0; e < QW / 4; ++e) u += red[(c % NC) * S + r + 4 * e];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                v = (c / NC == k) ? u : v;
+            }
+            v += dpp_f64<kDppXor1>(v);
+            v += dpp_f64<kDppXor2>(v);
+            if (r == 0) G->ws[c] = v;
+            if (lane == 0) *G->pairs = pairs;
+#ifdef SAGE_LOOP_TIMING
+            {
+                unsigned mx = valid ? npairs : 0u, sm = (valid && ci == 0u) ? npairs : 0u, stl = (stale && ci == 0u) ? 1u : 0u;
+                for (int d = 1; d < 64; d <<= 1) {
+                    mx = max(mx, static_cast<unsigned>(__shfl_xor(mx, d, 64)));
+                    sm += __shfl_xor(sm, d, 64);
+                    stl += __shfl_xor(stl, d, 64);
+                }
+                if (lane == 0) {
+                    atomicMax(&smem[kLpDbg], mx);
+                    atomicAdd(&smem[kLpDbg + 1], stl);
+                    atomicAdd(&smem[kLpDbg + 2], sm);
+                }
+            }
+#endif
+            LP_T(7);
+            return;                             // (k_loop closes the workgroup's iteration itself)
+        }
+        double *red = reinterpret_cast<double *>(wl);
         if (ci == 0u) {
 #pragma unroll
             for (int c = 0; c < kCount; ++c) red[c * S + qw] = t[c];
@@ -1175,9 +1249,9 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
             for (int e = 0; e < QW / 4; ++e) v += red[c * S + r + 4 * e];
             v += dpp_f64<kDppXor1>(v);
             v += dpp_f64<kDppXor2>(v);
-            double *ws = reinterpret_cast<double *>(smem + (PERSIST ? kLpSums : kWgSums)) + wv * kCount;
+            double *ws = reinterpret_cast<double *>(smem + kWgSums) + wv * kCount;
             if (r == 0) ws[c] = v;
-            if (lane == 0) smem[(PERSIST ? kLpPairs : kWgPairs) + wv] = pairs;
+            if (lane == 0) smem[kWgPairs + wv] = pairs;
         }
         // Workgroup partial: the last wave to arrive adds the four rows in wave order.
         // (what the ticket orders — the waves' sums — lives in LDS, which serves a CU's waves in order: the
@@ -1187,31 +1261,9 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
         unsigned prior = 0u;
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         if (lane == 0)
-            prior = __hip_atomic_fetch_add(&smem[PERSIST ? kLpArrive : kWgArrive], 1u, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+            prior = __hip_atomic_fetch_add(&smem[kWgArrive], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         prior = __builtin_amdgcn_readfirstlane(prior);
-#ifdef SAGE_LOOP_TIMING
-        if constexpr (PERSIST) {
-            unsigned mx = valid ? npairs : 0u, sm = (valid && ci == 0u) ? npairs : 0u, stl = (stale && ci == 0u) ? 1u : 0u;
-            for (int d = 1; d < 64; d <<= 1) {
-                mx = max(mx, static_cast<unsigned>(__shfl_xor(mx, d, 64)));
-                sm += __shfl_xor(sm, d, 64);
-                stl += __shfl_xor(stl, d, 64);
-            }
-            if (lane == 0) {
-                atomicMax(&smem[kLpDbg], mx);
-                atomicAdd(&smem[kLpDbg + 1], stl);
-                atomicAdd(&smem[kLpDbg + 2], sm);
-            }
-        }
-#endif
-        LP_T(7);
-        if constexpr (PERSIST) {
-            // k_loop finishes the iteration itself (wg_sums_to_acc, arrival, solve)
-            const bool last = prior == static_cast<unsigned>(nw) - 1u;
-            return last;
-        }
         if (prior == kIcpWavesPerBlock - 1u && P.acc) {
             wg_sums_to_acc(reinterpret_cast<const double *>(smem + kWgSums), smem + kWgPairs, kIcpWavesPerBlock,
                            P.acc + static_cast<size_t>(blockIdx.x & (kAccReplicas - 1)) * kAccWords,
@@ -1264,7 +1316,6 @@ __device__ __forceinline__ bool icp_body(const IcpParams &P, uint32_t *smem, Loo
         }
     }
 #endif
-    return false;
 }
 
 // ------------------------------------------------------------------------------------ WaveLanes
@@ -1611,17 +1662,18 @@ __global__ __launch_bounds__(kFinThreads) void k_fin(FinParams P) {
 }
 
 // ------------------------------------------------------------------------------------ k_loop
-// The whole loop of Registration.cpp:127-138 in one launch (kernels.h, LoopShared).  Per iteration:
-//   every wave        icp_body<PERSIST> on the queries it keeps — pose from LDS, state in registers,
-//                     rows in LDS — and parks its sums in the workgroup's LDS header;
+// The whole loop of Registration.cpp:127-138 in one launch of the query workgroups (k_loop) beside a
+// one-wave solving kernel (k_loop_solve) on a second stream (kernels.h, LoopShared).  Per iteration:
+//   every wave        takes the workgroup's groups one after another from an LDS counter and runs
+//                     icp_body<PERSIST> on each — pose from LDS, per-query state and rows in LDS —,
+//                     which parks the group's sums in the workgroup's LDS;
 //   last wave of a    adds the workgroup's sums into the fixed-point accumulators: (digit << 8) + 1 per
 //   workgroup         word, fire and forget — the low byte of every word counts who is in it;
-//   the solving       (one wave, the last workgroup of the grid, no queries) reads this iteration's set of
-//   workgroup         accumulators until every word counts all its workgroups (two sets alternate; the one
-//                     just read is cleared for the iteration after the next), solves, composes, tests,
-//                     and publishes the next pose as 25
-//                     self-tagged 8-byte granules (tag = iteration + 1: the data is the flag, no fence
-//                     on either side);
+//   the solving       reads this iteration's set of accumulators until every word counts all its
+//   wave              workgroups (two sets alternate; the one just read is cleared for the iteration
+//                     after the next), [exchanges the sums with the peer GPUs,] solves, composes, tests,
+//                     and publishes the next pose as 25 self-tagged 8-byte granules (tag = iteration
+//                     + 1: the data is the flag, no fence on either side);
 //   wave 0 of every   polls the granules (one relaxed agent-scope load per lane and pass), hands the
 //   workgroup         pose to its workgroup through LDS;  __syncthreads();  next iteration.
 // Every word the workgroups share is accessed with agent-scope atomics only.  Every wait is bounded:
@@ -1632,11 +1684,11 @@ __global__ __launch_bounds__(kFinThreads) void k_fin(FinParams P) {
 // probe builds: 100-MHz stamps of the first kLoopTimedIters iterations — per workgroup when it counted
 // itself in and when it had the next pose; for the solving wave when all counts were in, the sums
 // read, the step solved, the pose published
-constexpr int kLoopTimedIters = 64, kLoopTimedWgs = 512;
+constexpr int kLoopTimedIters = 32, kLoopTimedWgs = 1024;
 __device__ unsigned long long g_loop_wg[kLoopTimedIters][kLoopTimedWgs][2];
 __device__ unsigned g_loop_wginfo[kLoopTimedIters][kLoopTimedWgs][4];     // HW_ID | max points of a query | stale queries | points
 __device__ unsigned long long g_loop_solver[kLoopTimedIters][4];
-__device__ unsigned long long g_loop_phase[16];     // [0..7] cycles per body phase, [8] wait for the pose, [9] closing a workgroup, [10] wave-iterations
+__device__ unsigned long long g_loop_phase[16];     // [0..7] cycles per body phase, [8] wait for the pose, [9] closing a workgroup, [10] group passes
 #define LOOP_STAMP_SOLVER(it, k) do { if ((it) < kLoopTimedIters && (threadIdx.x & 63u) == 0u) g_loop_solver[it][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define LOOP_STAMP_WG(it, k) do { if ((it) < kLoopTimedIters && blockIdx.x < kLoopTimedWgs && (threadIdx.x & 63u) == 0u) g_loop_wg[it][blockIdx.x][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 extern "C" void sageicp_debug_loop_phases(unsigned long long *out, int reset) {
@@ -1665,16 +1717,63 @@ __device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long lo
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// The solving wave (all 64 lanes, uniform data).  Returns the value of the done granule it
-// published: 0 go on, 1 finished, 2 aborted.
-__device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, uint32_t *smem, int it) {
+// exchange_sums for ONE wave (the solving wave of k_loop_solve): S (LDS) holds this rank's sums on entry
+// and the sums over all ranks, added in rank order, on exit; `g` is the exchange counter (the same on
+// every rank).  Returns false when a peer's sums did not arrive in time.
+__device__ __forceinline__ bool exchange_sums_wave(double *S, const P2pParams &X, unsigned long long g) {
+    const int lane = static_cast<int>(threadIdx.x & 63u);
+    const int slot = static_cast<int>(g & 1ull);
+    const unsigned long long tag = g + 1ull;
+    if (lane < kNumSums) {
+        const double v = S[lane];
+        for (int r = 0; r < X.nranks; ++r)
+            __hip_atomic_store(&X.block[r]->sums[slot][X.rank][lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0)
+        for (int r = 0; r < X.nranks; ++r)
+            __hip_atomic_store(&X.block[r]->flag[X.rank], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    P2pBlock *mine = X.block[X.rank];
+    bool late = false;
+    if (lane < X.nranks) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(&mine->flag[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < tag) {
+            __builtin_amdgcn_s_sleep(2);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > X.timeout_ticks) {
+                late = true;
+                break;
+            }
+        }
+    }
+    late = __any(late);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    if (lane < kNumSums) {
+        double s = 0.0;
+        for (int r = 0; r < X.nranks; ++r)       // rank order: the same sum on every rank
+            s += __hip_atomic_load(&mine->sums[slot][r][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        S[lane] = s;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return !late;
+}
+
+// One iteration's finish by the solving wave (all 64 lanes, uniform data).  Returns the value of the
+// done granule it published: 0 go on, 1 finished, 2 aborted.
+struct SolveLds {
+    double T[14];              // T[7] | T_icp[7]
+    double S[kNumSums];
+    double pub[12];
+    long long digits[kAccWords];
+};
+__device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, const P2pParams &X, SolveLds &m, int it,
+                                                          unsigned long long &xg) {
     LoopShared *sh = L.sh;
     IcpState *st = L.st;
-    const int lane = static_cast<int>(threadIdx.x & 63u);
-    double *sT = reinterpret_cast<double *>(smem + kLpT);
-    double *S = reinterpret_cast<double *>(smem + kLpS);
-    double *pub = reinterpret_cast<double *>(smem + kLpPub);
-    long long *digits = reinterpret_cast<long long *>(smem + kLpDigits);
+    const int lane = static_cast<int>(threadIdx.x & 63u);          // (one wave)
+    double *sT = m.T, *S = m.S, *pub = m.pub;
+    long long *digits = m.digits;
     const unsigned long long tag = static_cast<unsigned long long>(it) + 1ull;
 
     // 1. the sums of this iteration's set of accumulators: read (one round trip per pass) until every word
@@ -1683,8 +1782,7 @@ __device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, u
     // iteration after the next (the clears are complete long before that pose is published: the waits
     // of the next iteration's passes cover them).
     {
-        // (the grid is 8 k query workgroups + this one: k of them add into each copy)
-        const long long per = static_cast<long long>((gridDim.x - 1u) >> 3);
+        const long long per = static_cast<long long>(L.wgs >> 3);      // workgroups adding into each copy
         long long (*acc)[kAccWords] = sh->acc[it & 1];
         long long v[kLoopReplicas];
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -1740,6 +1838,14 @@ __device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, u
     const bool overflow = digits[kAccWords - 1] != 0;
     LOOP_STAMP_SOLVER(it, 1);
 
+    // 2. multi-GPU: this rank's sums -> the sums over all ranks (direct exchange over xGMI, P2pBlock)
+    bool exchange_failed = false;
+    if (X.nranks > 1) {
+        exchange_failed = !exchange_sums_wave(S, X, xg);
+        xg += 1ull;
+        if (lane == 0) *X.exchanges = xg;
+    }
+
     // 3. solve, compose, test (Registration.cpp:92-93,135-137) — as k_fin's solve_and_publish
     double JTJ[36], JTr[6], neg[6], x[6], est[7];
     assemble_normal_equations(S, JTJ, JTr);
@@ -1770,12 +1876,17 @@ __device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, u
     }
     const bool converged = nrm < kEstimationThreshold;
     unsigned done = (converged || it + 1 >= L.max_iterations) ? 1u : 0u;
-    if (overflow) done = 1u;
+    // (under a communicator an overflow on this rank alone must not end its loop: the peers would wait
+    // for its sums; the flag is raised and the host reports it when the loop has ended everywhere)
+    if (overflow && !L.shared_loop) done = 1u;
+    if (exchange_failed) done = 1u;
     if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) pub[i] = Rn[i];
         pub[9] = Tn[4]; pub[10] = Tn[5]; pub[11] = Tn[6];
         if (it < kHistory) st->n_corr[it] = static_cast<uint32_t>(S[kCount]);
+        if (overflow) st->acc_overflow = 1;
+        if (exchange_failed) st->exchange_failed = 1;
         if (done) {
             // the final loop state, for the host (ordinary stores: the end of the kernel publishes them)
 #pragma unroll
@@ -1785,8 +1896,7 @@ __device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, u
             st->last_step_norm = nrm;
             st->iter = it + 1;
             st->done = 1;
-            st->converged = converged ? 1 : 0;
-            if (overflow) st->acc_overflow = 1;
+            st->converged = (converged && !exchange_failed) ? 1 : 0;
         }
     }
     if (done && lane == 1) {
@@ -1797,79 +1907,196 @@ __device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, u
     __builtin_amdgcn_wave_barrier();
     LOOP_STAMP_SOLVER(it, 2);
     // 4. publish: 24 halves of R, t and the done word, each with its tag
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the clears of step 2, issued microseconds ago)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the clears of step 1, issued microseconds ago)
     if (lane < 24) st_agent(&sh->pose[lane], (tag << 32) | reinterpret_cast<const uint32_t *>(pub)[lane]);
     if (lane == 24) st_agent(&sh->pose[24], (tag << 32) | done);
     LOOP_STAMP_SOLVER(it, 3);
     return done;
 }
 
+// The solving wave: one workgroup of one wave, launched on its own stream beside k_loop's grid (the
+// solve needs ~120 registers, the search 72: in one kernel every wave would pay for the solver).
+struct SolveArgs {
+    LoopParams L;
+    P2pParams X;
+};
+__global__ __launch_bounds__(64) void k_loop_solve(SolveArgs A) {
+    __shared__ SolveLds m;
+    {
+        // Launched before the frame is even sorted, so that this wave holds its registers when the grid
+        // of k_loop fills the machine; it waits here until the grid's first workgroup says that the
+        // shared block has been zeroed and the loop has started (LoopShared::go == this call's epoch).
+        const int lane = static_cast<int>(threadIdx.x & 63u);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            const unsigned long long g = ld_agent(&A.L.sh->go[0]);
+            if ((g & 0x7FFFFFFFFFFFFFFFull) == A.L.epoch) {
+                if (g >> 63) return;                        // (sort.hip found a non-finite point: the host reports it)
+                break;
+            }
+            // (the sort, the upload of a frame and a mirror refresh precede the grid: seconds, not the
+            // microseconds of the waits inside the loop)
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 1000ull * A.L.timeout_ticks + 1000000000ull) {
+                if (lane == 0) A.L.st->loop_aborted = 1;
+                return;
+            }
+            __builtin_amdgcn_s_sleep(32);
+        }
+        if (lane < 14) m.T[lane] = lane < 7 ? A.L.T0[lane] : (lane == 10 ? 1.0 : 0.0);     // T | T_icp = identity (x, y, z, w | t)
+    }
+    unsigned long long xg = A.X.nranks > 1 ? *A.X.exchanges : 0ull;
+    __builtin_amdgcn_wave_barrier();
+    for (int it = 0;; ++it) {
+        // (the arguments are re-read from the kernel-argument segment every iteration: see k_loop)
+        auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        const SolveArgs &K = *(const SolveArgs *)(ka);
+        if (loop_finish_iteration(K.L, K.X, m, it, xg)) return;
+    }
+}
+
 template <int LW, bool FILT>
-__global__ __launch_bounds__(64 * kLoopMaxWaves) __attribute__((amdgpu_waves_per_eu(4, 8)))
-void k_loop(IcpParams P, LoopParams L) {
+__global__ __launch_bounds__(64 * kLoopMaxWaves) __attribute__((amdgpu_waves_per_eu(SAGE_LOOP_OCC, 8)))
+void k_loop(LoopArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     constexpr int QW = 64 >> LW;
-    const int lane = static_cast<int>(threadIdx.x & 63u);
+    const IcpParams &P = A.P;
+    const LoopParams &L = A.L;
     const int wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     const int nw = L.nw;
-    LoopShared *sh = L.sh;
+    const unsigned gpw = static_cast<unsigned>(L.gpw);
     double *s_pose = reinterpret_cast<double *>(smem + kLpPose);
 
-    if (P.st->bad_input) return;               // (sort.hip found a non-finite point: the host reports it)
-    // ---- the solving workgroup: the last one of the grid, one wave, no queries --------------------------
-    // (its own path through the kernel: the solve needs ~120 registers, the search ~95 with the state
-    // it keeps, and neither is live in the other)
-    if (blockIdx.x == gridDim.x - 1u) {
-        if (threadIdx.x >= 64u) return;
-        double *sT = reinterpret_cast<double *>(smem + kLpT);
-        if (lane < 14) sT[lane] = lane < 7 ? P.st->T[lane] : P.st->T_icp[lane - 7];
-        __builtin_amdgcn_wave_barrier();
-        for (int it = 0;; ++it)
-            if (loop_finish_iteration(L, smem, it)) return;
+    {
+        // (sort.hip found a non-finite point: nobody starts, the host reports it — except under a communicator,
+        // where the ranks must keep exchanging in step)
+        const bool bad = !L.shared_loop && P.st->bad_input;
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            st_agent(&L.sh->go[0], L.epoch | (bad ? 0x8000000000000000ull : 0ull));      // the solving wave may start
+        if (bad) return;
     }
 
-    // ---- set-up: the initial pose, this lane's query -------------------------------------------------
+    // ---- the groups this workgroup owns for the whole call ------------------------------------------
+    // Workgroup b is dispatched to XCD b % 8 (observed; speed only).  Striped: XCD x serves the stripes
+    // x, x + 8, ... of kLoopStripe workgroups' worth of the spatially sorted frame (every XCD gets the
+    // same mix of dense and sparse regions, every L2 sees the whole map).  Contiguous: XCD x serves the
+    // groups [xcd_first[x], xcd_first[x + 1]) — one compact region of the map per L2, the boundaries
+    // chosen by the host so that the XCDs hold equal work.
+    unsigned g0, gcnt;
+    {
+        const unsigned xcd = blockIdx.x & 7u, jb = blockIdx.x >> 3;
+        const unsigned ngroups = (static_cast<unsigned>(P.n) + QW - 1u) / QW;
+        unsigned hi = ngroups;
+        if (L.contiguous) {
+            g0 = L.xcd_first[xcd] + jb * gpw;
+            hi = L.xcd_first[xcd + 1u];
+        } else {
+            const unsigned wg = ((jb / kLoopStripe) * 8u + xcd) * kLoopStripe + (jb % kLoopStripe);
+            g0 = wg * gpw;
+        }
+        gcnt = g0 < hi ? min(gpw, hi - g0) : 0u;
+    }
+    uint32_t *ws_base = smem + kLpHeaderWords;
+    double *ws = reinterpret_cast<double *>(ws_base);
+    uint32_t *pairs = ws_base + gpw * 2u * kCount;
+    uint32_t *groups = ws_base + loop_ws_words(gpw);
+    double *red = reinterpret_cast<double *>(groups + gpw * loop_group_words(LW) + static_cast<unsigned>(wv) * loop_red_words(LW));
+
+    // ---- set-up: the initial pose, the state records of the groups' queries --------------------------
     if (threadIdx.x < 9) s_pose[threadIdx.x] = P.st->R[threadIdx.x];
     else if (threadIdx.x < 12) s_pose[threadIdx.x] = P.st->T[4 + threadIdx.x - 9];
     if (threadIdx.x == 0) {
         smem[kLpArrive] = 0u;
+        smem[kLpNext] = 0u;
         smem[kLpDone] = 0u;
 #ifdef SAGE_LOOP_TIMING
         smem[kLpDbg] = 0u; smem[kLpDbg + 1] = 0u; smem[kLpDbg + 2] = 0u;
 #endif
     }
-    LoopLane LL;
-    {
-        const unsigned xcd = blockIdx.x & 7u, jb = blockIdx.x >> 3;
-        const unsigned wg = ((jb / kLoopStripe) * 8u + xcd) * kLoopStripe + (jb % kLoopStripe);   // as icp_body<PERSIST>
-        const unsigned q = (wg * static_cast<unsigned>(nw) + static_cast<unsigned>(wv)) * QW +
-                           static_cast<unsigned>(lane >> LW);
-        LL.f = P.frame[q < static_cast<unsigned>(P.n) ? q : 0u];
-        LL.pp.x = LL.pp.y = LL.pp.z = LL.pp.l = 0.0;
-        LL.prev = make_uint2(0xFFFFFFFFu, 0u);
-        LL.kx = LL.ky = LL.kz = kNoVoxel;                               // no row yet: the first pass builds it
-        LL.occ = 0u;
+    // (a group this workgroup does not have — the tail of the frame, of an XCD's range — adds zeros)
+    for (unsigned i = threadIdx.x; i < loop_ws_words(gpw); i += blockDim.x) ws_base[i] = 0u;
+    for (unsigned gi = static_cast<unsigned>(wv); gi < gcnt; gi += static_cast<unsigned>(nw)) {
+        const unsigned lane = threadIdx.x & 63u;
+        const unsigned qw = lane >> LW;
+        const unsigned q = (g0 + gi) * QW + qw;
+        const Point4 f = P.frame[q < static_cast<unsigned>(P.n) ? q : 0u];
+        if ((lane & ((1u << LW) - 1u)) == 0u) {
+            uint32_t *lst = groups + gi * loop_group_words(LW) + kRowLdsStride * QW + qw * kLoopStateWords;
+            *reinterpret_cast<Point4 *>(lst) = f;
+            Point4 z;
+            z.x = z.y = z.z = z.l = 0.0;
+            *reinterpret_cast<Point4 *>(lst + 8) = z;
+            *reinterpret_cast<uint4 *>(lst + kStPrev) = make_uint4(0xFFFFFFFFu, 0u, static_cast<uint32_t>(kNoVoxel),
+                                                                   static_cast<uint32_t>(kNoVoxel));   // no answer, no row yet:
+            *reinterpret_cast<uint4 *>(lst + kStPrev + 4) = make_uint4(static_cast<uint32_t>(kNoVoxel), 0u, 0u, 0u);   // the first pass builds it
+        }
     }
     __syncthreads();
 #ifdef SAGE_LOOP_TIMING
-    for (int i = 0; i < 8; ++i) LL.ph[i] = 0;
-    unsigned long long t_wait = 0, t_close = 0, n_it = 0;
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_wait = 0, t_close = 0, n_pass = 0;
 #endif
 
     for (int it = 0;; ++it) {
+        // Every iteration (and every pass of the body) re-reads its arguments from the kernel-argument
+        // segment — scalar loads from the constant cache, as a wave of k_icp does at its start — and
+        // re-derives its lane index: values the compiler knows to be invariant across this loop it would
+        // hoist out of it and keep alive, ~50 scalars and a dozen vector registers the scan needs.
+        auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        const LoopArgs &K = *(const LoopArgs *)(ka);
+        const LoopParams &L = K.L;
+        LoopShared *sh = L.sh;
+        unsigned lane_u;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_u));
+        const int lane = static_cast<int>(lane_u);
+        // the workgroup's groups, first come first served: a wave held up by a heavy query takes fewer
+        for (;;) {
+            unsigned gi = 0u;
+            if (lane == 0)
+                gi = __hip_atomic_fetch_add(&smem[kLpNext], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            gi = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(gi)));
+            if (gi >= gcnt) break;
+            LoopGroup G;
+            G.rows = groups + gi * loop_group_words(LW);
+            G.state = G.rows + kRowLdsStride * QW;
+            G.red = red;
+            G.ws = ws + gi * kCount;
+            G.pairs = pairs + gi;
+            G.group = g0 + gi;
 #ifdef SAGE_LOOP_TIMING
-        LL.tprev = __builtin_amdgcn_s_memtime();
-        ++n_it;
+            for (int i = 0; i < 8; ++i) G.ph[i] = 0;
+            G.tprev = __builtin_amdgcn_s_memtime();
+            ++n_pass;
 #endif
-        const bool last = icp_body<LW, true, FILT, true>(P, smem, &LL, s_pose, nw);
+            {
+                auto kb = __builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(kb));
+                icp_body<LW, true, FILT, true>(((const LoopArgs *)(kb))->P, smem, &G, s_pose);
+            }
+#ifdef SAGE_LOOP_TIMING
+            for (int i = 0; i < 8; ++i) ph[i] += G.ph[i];
+#endif
+        }
 #ifdef SAGE_LOOP_TIMING
         const unsigned long long t_a = __builtin_amdgcn_s_memtime();
 #endif
+        // (what the ticket orders — the groups' sums — lives in LDS, which serves a CU's waves in order)
+        unsigned prior = 0u;
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        if (lane == 0)
+            prior = __hip_atomic_fetch_add(&smem[kLpArrive], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        prior = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(prior)));
+        const bool last = prior == static_cast<unsigned>(nw) - 1u;
         if (last) {
             // this wave closes the workgroup's iteration
-            wg_sums_to_acc<true>(reinterpret_cast<const double *>(smem + kLpSums), smem + kLpPairs, nw,
-                                 &sh->acc[it & 1][blockIdx.x & (kLoopReplicas - 1)][0], &sh->acc[it & 1][0][kAccWords - 1]);
-            if (lane == 0) smem[kLpArrive] = 0u;          // everybody is in: ready for the next iteration
+            wg_sums_to_acc<true>(ws, pairs, static_cast<int>(gpw), &sh->acc[it & 1][blockIdx.x & (kLoopReplicas - 1)][0],
+                                 &sh->acc[it & 1][0][kAccWords - 1]);
+            if (lane == 0) {                   // everybody is in: ready for the next iteration
+                smem[kLpArrive] = 0u;
+                smem[kLpNext] = 0u;
+            }
 #ifdef SAGE_LOOP_TIMING
             if (lane == 0 && it < kLoopTimedIters && blockIdx.x < kLoopTimedWgs) {
                 unsigned hw;
@@ -1927,10 +2154,10 @@ void k_loop(IcpParams P, LoopParams L) {
     }
 #ifdef SAGE_LOOP_TIMING
     if (lane == 0) {
-        for (int i = 0; i < 8; ++i) atomicAdd(&g_loop_phase[i], LL.ph[i]);
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_loop_phase[i], ph[i]);
         atomicAdd(&g_loop_phase[8], t_wait);
         atomicAdd(&g_loop_phase[9], t_close);
-        atomicAdd(&g_loop_phase[10], n_it);
+        atomicAdd(&g_loop_phase[10], n_pass);
     }
 #endif
 }
@@ -2170,47 +2397,64 @@ void launch_icp(const IcpParams &p, int lw, bool fused, hipStream_t s) {
     }
 }
 
-size_t loop_lds_bytes(int lw, int nw) {
-    return sizeof(uint32_t) * (kLpHeaderWords + static_cast<size_t>(nw) * loop_wave_words(lw));
+size_t loop_lds_bytes(int lw, int nw, int gpw) {
+    return sizeof(uint32_t) * (kLpHeaderWords + loop_ws_words(static_cast<unsigned>(gpw)) +
+                               static_cast<size_t>(gpw) * loop_group_words(lw) + static_cast<size_t>(nw) * loop_red_words(lw));
+}
+// (a workgroup that owns many groups can ask for more than the 64 KB a kernel gets by default)
+template <int LW, bool FILT>
+static bool loop_allow_big_lds() {
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_loop<LW, FILT>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    return ok;
 }
 template <int LW, bool FILT>
-static int loop_blocks_lw(int nw) {
+static int loop_blocks_lw(int nw, size_t lds) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_loop<LW, FILT>, 64 * nw, loop_lds_bytes(LW, nw)) != hipSuccess)
-        return 0;
+    if (lds > 64 * 1024 && !loop_allow_big_lds<LW, FILT>()) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_loop<LW, FILT>, 64 * nw, lds) != hipSuccess) return 0;
     return nb;
 }
-int loop_blocks_per_cu(int lw, bool filter, int nw) {
-    if (nw < 1 || nw > kLoopMaxWaves) return 0;
+int loop_blocks_per_cu(int lw, bool filter, int nw, size_t lds) {
+    if (nw < 1 || nw > kLoopMaxWaves || lds > 160 * 1024) return 0;
     switch (lw) {
-        case 1: return filter ? loop_blocks_lw<1, true>(nw) : loop_blocks_lw<1, false>(nw);
-        case 2: return filter ? loop_blocks_lw<2, true>(nw) : loop_blocks_lw<2, false>(nw);
-        case 3: return filter ? loop_blocks_lw<3, true>(nw) : loop_blocks_lw<3, false>(nw);
-        case 4: return filter ? loop_blocks_lw<4, true>(nw) : loop_blocks_lw<4, false>(nw);
+        case 1: return filter ? loop_blocks_lw<1, true>(nw, lds) : loop_blocks_lw<1, false>(nw, lds);
+        case 2: return filter ? loop_blocks_lw<2, true>(nw, lds) : loop_blocks_lw<2, false>(nw, lds);
+        case 3: return filter ? loop_blocks_lw<3, true>(nw, lds) : loop_blocks_lw<3, false>(nw, lds);
+        case 4: return filter ? loop_blocks_lw<4, true>(nw, lds) : loop_blocks_lw<4, false>(nw, lds);
         default: return 0;
     }
 }
-void launch_loop(const IcpParams &p, const LoopParams &l, int lw, int grid, hipStream_t s) {
-    const dim3 g(grid), b(64 * l.nw);
-    const size_t lds = loop_lds_bytes(lw, l.nw);
+void launch_loop(const IcpParams &p, const LoopParams &l, int lw, hipStream_t s) {
+    const dim3 g(l.wgs), b(64 * l.nw);
+    const size_t lds = loop_lds_bytes(lw, l.nw, l.gpw);
+    LoopArgs a;
+    a.P = p;
+    a.L = l;
     switch (lw) {
         case 1:
-            if (p.filter) hipLaunchKernelGGL((k_loop<1, true>), g, b, lds, s, p, l);
-            else hipLaunchKernelGGL((k_loop<1, false>), g, b, lds, s, p, l);
+            if (p.filter) hipLaunchKernelGGL((k_loop<1, true>), g, b, lds, s, a);
+            else hipLaunchKernelGGL((k_loop<1, false>), g, b, lds, s, a);
             break;
         case 2:
-            if (p.filter) hipLaunchKernelGGL((k_loop<2, true>), g, b, lds, s, p, l);
-            else hipLaunchKernelGGL((k_loop<2, false>), g, b, lds, s, p, l);
+            if (p.filter) hipLaunchKernelGGL((k_loop<2, true>), g, b, lds, s, a);
+            else hipLaunchKernelGGL((k_loop<2, false>), g, b, lds, s, a);
             break;
         case 3:
-            if (p.filter) hipLaunchKernelGGL((k_loop<3, true>), g, b, lds, s, p, l);
-            else hipLaunchKernelGGL((k_loop<3, false>), g, b, lds, s, p, l);
+            if (p.filter) hipLaunchKernelGGL((k_loop<3, true>), g, b, lds, s, a);
+            else hipLaunchKernelGGL((k_loop<3, false>), g, b, lds, s, a);
             break;
         default:
-            if (p.filter) hipLaunchKernelGGL((k_loop<4, true>), g, b, lds, s, p, l);
-            else hipLaunchKernelGGL((k_loop<4, false>), g, b, lds, s, p, l);
+            if (p.filter) hipLaunchKernelGGL((k_loop<4, true>), g, b, lds, s, a);
+            else hipLaunchKernelGGL((k_loop<4, false>), g, b, lds, s, a);
             break;
     }
+}
+void launch_loop_solve(const LoopParams &l, const P2pParams &x, hipStream_t s) {
+    SolveArgs a;
+    a.L = l;
+    a.X = x;
+    hipLaunchKernelGGL(k_loop_solve, dim3(1), dim3(64), 0, s, a);
 }
 
 int launch_gn(const GnParams &p, hipStream_t s) {

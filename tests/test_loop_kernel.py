@@ -175,9 +175,11 @@ def test_initial_guess_and_repeated_calls(gpu_sage, oracle):
 
 
 def test_frame_that_does_not_fit_uses_the_launch_per_iteration_loop(gpu_sage, oracle):
+    """rows and per-query state of every query have to fit the LDS of the machine (232 B per query, 160 KB per
+    CU: ~170k queries on 256 CUs)"""
     from sage_icp_amd import synthetic as syn
     w, om = _workload(gpu_sage, oracle, "c2", 0.1)
-    big = np.ascontiguousarray(np.tile(w["scan"], (12, 1)))         # 144k points at 8 lanes each: 18k waves
+    big = np.ascontiguousarray(np.tile(w["scan"], (20, 1)))         # 240k points
     p = syn.PARAMS["steady"]
     with Env(SAGEICP_LOOP=2, SAGEICP_LW=3):
         _, st = gpu_sage.register_frame(big, w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"],
@@ -185,32 +187,68 @@ def test_frame_that_does_not_fit_uses_the_launch_per_iteration_loop(gpu_sage, or
     assert st.single_launch == 0 and st.converged == 1
 
 
+@pytest.mark.parametrize("lw,waves,gpw", [(2, 7, 3), (3, 4, 9), (2, 8, 2), (4, 5, 7), (1, 7, 2)])
+def test_several_groups_per_wave(gpu_sage, oracle, lw, waves, gpw):
+    """a workgroup that owns more groups of queries than it has waves: its waves take them one after another from
+    an LDS counter (the shape the headline frame runs in) — the same bits as one wave per group"""
+    from sage_icp_amd import synthetic as syn
+    w, om = _workload(gpu_sage, oracle, "c2", 0.1)
+    p = syn.PARAMS["cold"]
+    a, sa, b, sb = _both_loops(gpu_sage, w, p, SAGEICP_LW=lw, SAGEICP_LOOP_WAVES=waves, SAGEICP_LOOP_GPW=gpw)
+    assert sb.single_launch == 1 and sb.lanes_per_query == 1 << lw
+    assert np.array_equal(a, b)
+    _same(sa, sb)
+    with Env(SAGEICP_LOOP=2, SAGEICP_LW=lw, SAGEICP_LOOP_WAVES=waves, SAGEICP_LOOP_GPW=gpw, SAGEICP_LOOP_CONTIGUOUS=1):
+        c, sc = gpu_sage.register_frame(w["scan"], w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"],
+                                        return_stats=True)
+    assert sc.single_launch == 1 and np.array_equal(a, c)       # (one contiguous range of the frame per XCD)
+    opose, ost = om.register_frame(w["scan"], oracle.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"])
+    dt, dr = pose_error(oracle, opose, b)
+    assert dt < 1e-7 and dr < 1e-7 and sb.iterations == ost.iterations
+
+
+def test_headline_frame_in_one_launch(gpu_sage, oracle):
+    """c2 at full size (120k queries against the 1M-point map) fits the one-launch loop as the library shapes it,
+    bit-identical to the launch-per-iteration loop at the same lanes per query"""
+    from sage_icp_amd import synthetic as syn
+    w, om = _workload(gpu_sage, oracle, "c2", 1.0)
+    p = syn.PARAMS["cold"]
+    with Env(SAGEICP_LOOP=1):
+        b, sb = gpu_sage.register_frame(w["scan"], w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"],
+                                        return_stats=True)
+    assert sb.single_launch == 1, "the headline frame was expected to run in one launch"
+    with Env(SAGEICP_LOOP=0, SAGEICP_LW=sb.lanes_per_query.bit_length() - 1):
+        a, sa = gpu_sage.register_frame(w["scan"], w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"],
+                                        return_stats=True)
+    assert np.array_equal(a, b)
+    _same(sa, sb)
+    assert sb.iterations == 185 and sb.converged == 1          # (the golden count of this scene, BENCH r01-r04)
+
+
 def test_timeout_inside_the_launch_falls_back(gpu_sage, oracle):
     """SAGEICP_LOOP_TIMEOUT_TICKS=1: every wait inside the launch gives up at once; the kernel must end
-    (no hang) and the frame must still be registered — by the other loop — with the same pose"""
+    (no hang) and the frame must still be registered — by the other loop, with the lanes per query the one-launch
+    loop would have taken: the same pose to the bit whether the launch succeeds, times out, or is not tried"""
     from sage_icp_amd import synthetic as syn
     w, om = _workload(gpu_sage, oracle, "c2", 0.05)
     p = syn.PARAMS["cold"]
-    with Env(SAGEICP_LOOP=0):
-        a = gpu_sage.register_frame(w["scan"], w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"])
-    # (the frame the one-launch loop gives up on is registered with the lanes per query the other loop takes
-    # by itself: the same pose to the bit, whatever the one-launch loop would have taken)
+    with Env(SAGEICP_LOOP=2):
+        a, sa = gpu_sage.register_frame(w["scan"], w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"],
+                                        return_stats=True)
+    assert sa.single_launch == 1
     with Env(SAGEICP_LOOP=2, SAGEICP_LOOP_TIMEOUT_TICKS=1, SAGEICP_LOOP_COOLDOWN=2):
         b, sb = gpu_sage.register_frame(w["scan"], w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"],
                                         p["sem_th"], return_stats=True)
     assert np.array_equal(a, b)
     # (a tick is 10 ns: a wait that long never succeeds on a grid of this size)
-    assert sb.single_launch == 0
+    assert sb.single_launch == 0 and sb.lanes_per_query == sa.lanes_per_query
     # a map whose launch timed out stays away from k_loop for a while (here: two calls), then tries again
     with Env(SAGEICP_LOOP=2):
         forms = []
         for _ in range(3):
             c, sc = gpu_sage.register_frame(w["scan"], w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"],
                                             p["sem_th"], return_stats=True)
-            if not sc.single_launch:
-                assert np.array_equal(a, c)
-            else:                                # (other lanes per query: other per-wave roundings)
-                assert np.allclose(a, c, rtol=0, atol=1e-12)
+            assert np.array_equal(a, c)
             forms.append(sc.single_launch)
     assert forms == [0, 0, 1]
 
