@@ -34,6 +34,10 @@ def timed(frame, m, p, K, **env):
     return pose, st, dt
 
 
+LWS = tuple(int(x) for x in os.environ.get("SWEEP_LW", "2,3,1,4").split(","))
+NWS = tuple(int(x) for x in os.environ.get("SWEEP_NW", "0,4,8,7").split(","))
+
+
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "c2"
     params = sys.argv[2] if len(sys.argv) > 2 else "cold"
@@ -53,8 +57,8 @@ def main():
     print("  launch per iteration (default: %d lanes) %22s %8.3f ms/frame %4d it %6.2f us/it" % (st.lanes_per_query, "", 1e3 * dt, st.iterations, 1e6 * dt / max(1, st.iterations)), flush=True)
     pose, st, dt = timed(f, w["map"], p, K)
     print("  library default: %s, %d lanes %31s %8.3f ms/frame %4d it %6.2f us/it" % ("one launch" if st.single_launch else "launch per iteration", st.lanes_per_query, "", 1e3 * dt, st.iterations, 1e6 * dt / max(1, st.iterations)), flush=True)
-    for lw in (2, 3, 1, 4):
-        for nw in (0, 4, 8, 7):
+    for lw in LWS:
+        for nw in NWS:
             for contig in (0, 1):
                 for gpw in ((0,) if nw else (0,)):
                     env = dict(SAGEICP_LOOP=2, SAGEICP_LW=lw, SAGEICP_LOOP_CONTIGUOUS=contig)

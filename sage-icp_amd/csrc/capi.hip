@@ -131,6 +131,7 @@ struct Scratch {
     int cu_share_i = 0, cu_share_k = 1;   // SAGEICP_CU_SHARE=i/k: the i-th of k equal parts of the device's CUs (several
                                    // ranks on ONE GPU — tests, or a small node — each keep a persistent grid resident)
     int loop_cooldown = 0;         // calls that stay away from k_loop after one of its launches timed out
+    int loop_derate = 0;           // x 32 workgroups fewer than the residency rule allows: one more after every time-out
     unsigned long long *d_cand = nullptr;      // per-wave counters of k_icp [2 x sort_cap]
     IcpState *d_state = nullptr;
     IcpState *h_state = nullptr;   // pinned
@@ -1430,7 +1431,7 @@ static bool plan_loop(const sageicp_map *m, uint64_t n, double sem_th, LoopPlan 
         const uint64_t wgs = round32((groups_at(lw) + nw - 1) / nw);
         const size_t lds = loop_lds_bytes(lw, nw, nw);
         const int k = loop_wgs_per_cu(sc, lw, filter, nw, lds);
-        if (k < 1 || wgs + 2 > static_cast<uint64_t>(k) * cus || !countable(wgs, nw)) return false;
+        if (k < 1 || wgs + 32ull * static_cast<uint64_t>(sc.loop_derate) > static_cast<uint64_t>(k) * cus * 15 / 16 || !countable(wgs, nw)) return false;
         *pl = LoopPlan{lw, nw, nw, static_cast<int>(wgs), filter};
         return true;
     };
@@ -1445,9 +1446,17 @@ static bool plan_loop(const sageicp_map *m, uint64_t n, double sem_th, LoopPlan 
             if (!env_nw && nw < 4) continue;
             for (int k = SAGE_LOOP_OCC / ((nw + 3) / 4); k >= 1; --k) {
                 if (static_cast<uint64_t>(k) * cus < 34) break;
-                const uint64_t cap = (static_cast<uint64_t>(k) * cus - 2) / 32 * 32;
+                // (measured, profiles/r05/resident_probe: of the 7 x 256 = 1,792 slots for workgroups of four waves
+                // 1,696 are resident together beside the solving wave, 1,728 are not; a sixteenth stays free, and
+                // a launch that still times out takes another 32 workgroups off every later plan of this handle)
+                uint64_t cap = static_cast<uint64_t>(k) * cus * 15 / 16 / 32 * 32;
+                cap = cap > 32ull * static_cast<uint64_t>(sc.loop_derate) ? cap - 32ull * static_cast<uint64_t>(sc.loop_derate) : 0;
+                if (cap < 32) continue;
+                if (const int e = env_int("SAGEICP_LOOP_MAX_WGS", 0)) cap = std::min<uint64_t>(cap, static_cast<uint64_t>(e) / 32 * 32);   // (probes)
+                // (every resident workgroup slot is used: the groups are dealt out evenly over the workgroups,
+                // so more workgroups mean fewer waves that have to make a second pass)
                 uint64_t gpw = env_gpw ? static_cast<uint64_t>(env_gpw) : (groups + cap - 1) / cap;
-                const uint64_t wgs = round32((groups + gpw - 1) / gpw);
+                const uint64_t wgs = env_gpw ? round32((groups + gpw - 1) / gpw) : std::min(cap, round32(groups));
                 if (wgs > cap) continue;
                 if (!env_gpw) gpw = (groups + wgs - 1) / wgs;
                 const size_t lds = loop_lds_bytes(lw, nw, static_cast<int>(gpw));
@@ -1585,9 +1594,11 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         L.contiguous = env_int("SAGEICP_LOOP_CONTIGUOUS", 0) ? 1 : 0;
         {
             const uint64_t qw = 64u >> plan.lw, groups = (n + qw - 1) / qw;
-            const uint64_t per = std::min<uint64_t>((groups + 7) / 8, static_cast<uint64_t>(plan.wgs / 8) * plan.gpw);
-            for (int x = 0; x <= 8; ++x) L.xcd_first[x] = static_cast<uint32_t>(std::min<uint64_t>(groups, x * per));
-            if (per * 8 < groups) L.contiguous = 0;
+            for (int x = 0; x <= 8; ++x) L.xcd_first[x] = static_cast<uint32_t>(groups * x / 8);
+            // (an XCD's workgroups must be able to hold its range)
+            const uint64_t nwg = static_cast<uint64_t>(plan.wgs / 8);
+            for (int x = 0; x < 8; ++x)
+                if ((L.xcd_first[x + 1] - L.xcd_first[x] + nwg - 1) / nwg > static_cast<uint64_t>(plan.gpw)) L.contiguous = 0;
         }
         // a wait inside the launch normally takes microseconds; 50 ms of it means the grid is not
         // resident as a whole (SAGEICP_LOOP_TIMEOUT_MS overrides, e.g. under a debugger)
@@ -1642,6 +1653,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
             // or process held CUs): the launch-per-iteration loop below registers the frame instead,
             // with the same lanes per query
             sc.loop_cooldown = std::max(0, env_int("SAGEICP_LOOP_COOLDOWN", 256));
+            if (env_int("SAGEICP_LOOP_TIMEOUT_TICKS", 0) == 0 && sc.loop_derate < 16) ++sc.loop_derate;
             if (comm) {
                 // (the peers are somewhere inside their loops: there is no starting again in step)
                 comm->p2p = false;

@@ -1955,6 +1955,9 @@ __global__ __launch_bounds__(64) void k_loop_solve(SolveArgs A) {
     }
 }
 
+#ifndef SAGE_LOOP_POLL_SLEEP
+#define SAGE_LOOP_POLL_SLEEP 8     // x 64 clocks between two looks of a workgroup at the pose granules
+#endif
 template <int LW, bool FILT>
 __global__ __launch_bounds__(64 * kLoopMaxWaves) __attribute__((amdgpu_waves_per_eu(SAGE_LOOP_OCC, 8)))
 void k_loop(LoopArgs A) {
@@ -1982,19 +1985,27 @@ void k_loop(LoopArgs A) {
     // same mix of dense and sparse regions, every L2 sees the whole map).  Contiguous: XCD x serves the
     // groups [xcd_first[x], xcd_first[x + 1]) — one compact region of the map per L2, the boundaries
     // chosen by the host so that the XCDs hold equal work.
+    // Either way the groups are dealt out EVENLY over the workgroups that serve them — floor or ceil of
+    // groups / workgroups each, never more than gpw: a frame of 7,500 groups on 1,760 resident workgroups
+    // of four waves gives 460 of them a fifth group instead of leaving 260 with none (an iteration
+    // ends with the workgroup whose waves have to make a second pass; profiles/r05).
     unsigned g0, gcnt;
     {
         const unsigned xcd = blockIdx.x & 7u, jb = blockIdx.x >> 3;
         const unsigned ngroups = (static_cast<unsigned>(P.n) + QW - 1u) / QW;
-        unsigned hi = ngroups;
+        unsigned lo = 0u, cnt = ngroups, idx, nwg;
         if (L.contiguous) {
-            g0 = L.xcd_first[xcd] + jb * gpw;
-            hi = L.xcd_first[xcd + 1u];
+            lo = L.xcd_first[xcd];
+            cnt = L.xcd_first[xcd + 1u] - lo;
+            idx = jb;
+            nwg = gridDim.x >> 3;
         } else {
-            const unsigned wg = ((jb / kLoopStripe) * 8u + xcd) * kLoopStripe + (jb % kLoopStripe);
-            g0 = wg * gpw;
+            idx = ((jb / kLoopStripe) * 8u + xcd) * kLoopStripe + (jb % kLoopStripe);
+            nwg = gridDim.x;
         }
-        gcnt = g0 < hi ? min(gpw, hi - g0) : 0u;
+        const unsigned base = cnt / nwg, extra = cnt - base * nwg;      // `extra` workgroups serve base + 1 groups
+        g0 = lo + idx * base + min(idx, extra);
+        gcnt = min(gpw, base + (idx < extra ? 1u : 0u));
     }
     uint32_t *ws_base = smem + kLpHeaderWords;
     double *ws = reinterpret_cast<double *>(ws_base);
@@ -2132,7 +2143,10 @@ void k_loop(LoopArgs A) {
                     aborted = true;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(1);
+                // (more than a thousand workgroups wait here for most of an iteration, all on the same four
+                // cache lines: a pass every ~0.3 us each leaves the L2 channel that serves them — and the
+                // accumulators the solving wave is reading — alone)
+                __builtin_amdgcn_s_sleep(SAGE_LOOP_POLL_SLEEP);
             }
             if (aborted) {
                 if (lane == 0) smem[kLpDone] = 2u;
@@ -2153,7 +2167,7 @@ void k_loop(LoopArgs A) {
         if (smem[kLpDone]) break;
     }
 #ifdef SAGE_LOOP_TIMING
-    if (lane == 0) {
+    if ((threadIdx.x & 63u) == 0u) {
         for (int i = 0; i < 8; ++i) atomicAdd(&g_loop_phase[i], ph[i]);
         atomicAdd(&g_loop_phase[8], t_wait);
         atomicAdd(&g_loop_phase[9], t_close);
