@@ -224,6 +224,10 @@ def main():
     # only to exercise the direct exchange between processes on a 1-GPU box
     local_dev = int(os.environ.get("SAGEICP_BENCH_DEVICE", local_rank))
     backend = os.environ.get("SAGEICP_BENCH_BACKEND", "nccl")
+    if "SAGEICP_BENCH_DEVICE" in os.environ and world > 1:
+        # the ranks share ONE GPU: each runs on its own part of the CUs (CU-masked streams, capi.hip), so that the
+        # persistent grids of their one-launch loops are resident side by side instead of waiting for each other
+        os.environ.setdefault("SAGEICP_CU_SHARE", "%d/%d" % (rank, world))
     torch.cuda.set_device(local_dev)
     # SAGEICP_FORCE_COMM=1 runs the multi-GPU code path (process group, RCCL communicator, in-stream
     # all-reduce) even with one rank, so it can be exercised on a 1-GPU box under torchrun.
@@ -416,20 +420,36 @@ def main():
     # search of this rank's shard, and the finish (reduction, exchange with the peers, solve).
     breakdown = None
     if use_dist and not args.independent:
+        loop_env = os.environ.get("SAGEICP_LOOP")
         sage.set_profiling(2)
         try:
             fence()
             _, sb = step()
             fence()
-            if sb.nn_launches:
-                breakdown = {"shard_compute_us_per_iteration": round(sb.us_nn / sb.nn_launches, 2),
-                             "exchange_us_per_iteration": round(sb.us_fin / sb.nn_launches, 2),
-                             "note": "rank 0, one frame after the timed region, HIP events around every launch: "
-                                     "k_icp on this rank's shard | k_fin incl. the wait for the peers' sums (direct "
-                                     "exchange) or k_fin + ncclAllReduce + k_fin (RCCL); on one GPU k_fin takes ~6 us"}
+            breakdown = {"loop_form": "one launch for the whole loop (k_loop + its solving wave, the exchange inside)"
+                                      if sb.single_launch else "k_icp + k_fin per iteration",
+                         "lanes_per_query": sb.lanes_per_query}
+            if sb.nn_launches and sb.single_launch:
+                breakdown["iteration_us"] = round(sb.us_nn / sb.nn_launches, 2)
+                # the same frame through the launch-per-iteration loop, whose two launches can be told apart
+                os.environ["SAGEICP_LOOP"] = "0"
+                fence()
+                _, sb = step()
+                fence()
+            if sb.nn_launches and not sb.single_launch:
+                breakdown["launch_per_iteration"] = {
+                    "shard_compute_us_per_iteration": round(sb.us_nn / sb.nn_launches, 2),
+                    "exchange_us_per_iteration": round(sb.us_fin / sb.nn_launches, 2),
+                    "note": "rank 0, one frame after the timed region, HIP events around every launch: "
+                            "k_icp on this rank's shard | k_fin incl. the wait for the peers' sums (direct "
+                            "exchange) or k_fin + ncclAllReduce + k_fin (RCCL); on one GPU k_fin takes ~6 us"}
         except sage.SageIcpError as e:
             sys.stderr.write("rank %d: breakdown frame failed: %s\n" % (rank, e))
         finally:
+            if loop_env is None:
+                os.environ.pop("SAGEICP_LOOP", None)
+            else:
+                os.environ["SAGEICP_LOOP"] = loop_env
             sage.set_profiling(0)
 
     if rank != 0:

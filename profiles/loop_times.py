@@ -71,6 +71,11 @@ if hasattr(sage.lib(), "sageicp_debug_loop_info"):
               + " | points " + " ".join("%.0f" % sm[xcc == x].sum() for x in range(8) if (xcc == x).any()))
         order = np.argsort(-dur)[:8]
         print("   slowest: " + "; ".join("%.1f us (xcd %d se %d cu %d, max %d pts, %d stale, %d pts)" % (dur[o], xcc[o], se[o], cu[o], mx[o], stl[o], sm[o]) for o in order))
+        for lo_, hi_ in ((0, 0), (1, 1), (2, 3), (4, 7), (8, 15), (16, 10 ** 6)):
+            sel = (stl >= lo_) & (stl <= hi_)
+            if sel.any():
+                print("   %5d workgroups with %d..%d stale queries: search time mean %.2f p90 %.2f max %.2f"
+                      % (sel.sum(), lo_, min(hi_, 999), dur[sel].mean(), np.quantile(dur[sel], 0.9), dur[sel].max()))
         q = np.quantile(sm, [0.2, 0.4, 0.6, 0.8])
         b = np.digitize(sm, q)
         print("   search time by quintile of the workgroup's points: " + " ".join("%.2f" % dur[b == k].mean() for k in range(5)))

@@ -121,10 +121,12 @@ struct Scratch {
     uint2 *d_prev = nullptr;       // every query's record of the previous iteration (kernels.h)
     uint32_t *d_work = nullptr;    // instrumented builds: points handed to each query
     double *d_partials = nullptr; size_t partials_cap = 0;
-    double *d_partials2 = nullptr; size_t partials2_cap = 0;   // second stage of the reduction (k_red, big frames)
     long long *d_acc = nullptr;    // fixed-point accumulators of the Gauss-Newton sums (kernels.h, kAcc*)
     LoopShared *d_loop = nullptr;  // what the workgroups of k_loop share inside its launch (kernels.h)
     hipStream_t stream2 = nullptr; // the solving wave of the one-launch loop runs here, beside the grid on `stream`
+                                   // (created with the first such launch: a process has few hardware queues, and
+                                   // streams that never run anything still take their turn on them)
+    std::vector<uint32_t> cu_mask; // of both streams (empty: the whole device)
     hipEvent_t ev_solve = nullptr; // ... and this says that it has finished
     unsigned long long loop_epoch = 0;
     int num_cus = 0;               // CUs the streams of this handle may use (the whole device, or its share: below)
@@ -167,15 +169,13 @@ struct Scratch {
             std::vector<uint32_t> mask((num_cus + 31) / 32, 0u);
             for (int c = lo; c < lo + per; ++c) mask[c / 32] |= 1u << (c % 32);
             HIPCHK(hipExtStreamCreateWithCUMask(&stream, static_cast<uint32_t>(mask.size()), mask.data()));
-            HIPCHK(hipExtStreamCreateWithCUMask(&stream2, static_cast<uint32_t>(mask.size()), mask.data()));
+            cu_mask = mask;
             num_cus = per;
         } else {
             cu_share_i = 0;
             cu_share_k = 1;
             HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-            HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
         }
-        HIPCHK(hipEventCreateWithFlags(&ev_solve, hipEventDisableTiming));
         HIPCHK(hipMalloc(&d_state, sizeof(IcpState)));
         HIPCHK(hipMalloc(&d_acc, sizeof(long long) * kAccReplicas * kAccWords));
         HIPCHK(hipMalloc(&d_loop, sizeof(LoopShared)));
@@ -184,6 +184,14 @@ struct Scratch {
         HIPCHK(hipHostMalloc(&h_state, sizeof(IcpState), hipHostMallocDefault));
         HIPCHK(hipHostMalloc(&h_prog, sizeof(IcpProgress), hipHostMallocMapped | hipHostMallocCoherent));
         HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&d_prog), h_prog, 0));
+        return SAGEICP_OK;
+    }
+    int loop_streams() {
+        if (stream2) return SAGEICP_OK;
+        HIPCHK(hipSetDevice(device));
+        if (!cu_mask.empty()) HIPCHK(hipExtStreamCreateWithCUMask(&stream2, static_cast<uint32_t>(cu_mask.size()), cu_mask.data()));
+        else HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&ev_solve, hipEventDisableTiming));
         return SAGEICP_OK;
     }
     int reserve_frame(size_t n) {
@@ -251,15 +259,6 @@ struct Scratch {
         partials_cap = cap;
         return SAGEICP_OK;
     }
-    int reserve_partials2(size_t rows) {
-        if (rows <= partials2_cap) return SAGEICP_OK;
-        if (d_partials2) HIPCHK(hipFree(d_partials2));
-        d_partials2 = nullptr; partials2_cap = 0;
-        const size_t cap = rows + rows / 4 + 64;
-        HIPCHK(hipMalloc(&d_partials2, cap * kNumSums * sizeof(double)));
-        partials2_cap = cap;
-        return SAGEICP_OK;
-    }
     int reserve_events(size_t iterations) {
         while (events.size() < 5 * iterations) {
             hipEvent_t e;
@@ -288,7 +287,6 @@ struct Scratch {
         if (d_prev) (void)hipFree(d_prev);
         if (d_work) (void)hipFree(d_work);
         if (d_partials) (void)hipFree(d_partials);
-        if (d_partials2) (void)hipFree(d_partials2);
         if (d_state) (void)hipFree(d_state);
         if (d_acc) (void)hipFree(d_acc);
         if (d_loop) (void)hipFree(d_loop);
@@ -710,6 +708,10 @@ struct sageicp_comm {
     P2pBlock *blocks[kMaxRanks] = {};    // every rank's block as mapped here (blocks[rank] == my_block)
     unsigned long long *d_exchanges = nullptr;
     bool peer_mapped = false;            // blocks[] are plain peer pointers of this process (no IPC handles to close)
+    bool device_shared = false;          // several ranks of ONE process run on this device (tests on a 1-GPU box): their
+                                         // streams share the process's few hardware queues, where a solving wave that
+                                         // waits for its peer can sit in front of that very peer's grid — such ranks
+                                         // stay with the launch-per-iteration loop
 };
 
 // ---- RCCL, bound at run time (only multi-GPU runs need it) ------------------------------------
@@ -1330,6 +1332,10 @@ static bool wants_flat(const sageicp_map *m, int lw) {
     return env_int("SAGEICP_FLAT", mp < (2ull << lw) * mv ? 1 : 0) != 0;
 }
 
+// (raised while a frame whose sums left the range of the fixed-point accumulators is registered again at a
+// coarser scale: the sums are accumulated at 2^(-24 g_acc_shift) of their value — see the end of run_icp)
+static thread_local int g_acc_shift = 0;
+
 // k_icp's arguments for a search of `n` queries against the HBM copy of `m`
 IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, double sem_th, int lw) {
     const Scratch &sc = m->sc;
@@ -1373,7 +1379,7 @@ IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, 
     ip.accept_r2 = -1.0;
     ip.nn_prev = sc.d_prev;
     ip.work = sc.d_work;
-    ip.partials = sc.d_partials;
+    ip.acc_scale = std::ldexp(1.0, -24 * std::max(g_acc_shift, std::min(2, std::max(0, env_int("SAGEICP_ACC_SHIFT", 0)))));
     ip.counters = nullptr;
     const uint64_t qw = 64u >> lw;
     ip.nwaves = static_cast<unsigned>((n + qw - 1) / qw);
@@ -1423,15 +1429,17 @@ static bool plan_loop(const sageicp_map *m, uint64_t n, double sem_th, LoopPlan 
     const int env_gpw = std::max(0, env_int("SAGEICP_LOOP_GPW", 0));
     auto groups_at = [n](int l) { return (n + (64u >> l) - 1) / (64u >> l); };
     auto round32 = [](uint64_t w) { return std::max<uint64_t>(32, (w + 31) / 32 * 32); };   // (XCD stripes: 8 x kLoopStripe)
-    // the accumulator words count their workgroups in 8 bits, and (digit << 8) summed over a copy's workgroups
-    // and their groups must stay inside 63 bits: |digit| < 2^42 per group (kernels.hip, wg_sums_to_acc)
-    auto countable = [](uint64_t wgs, uint64_t gpw) { return wgs / 8 <= 255 && (wgs / 8) * gpw <= 4096; };
+    // the accumulator words count their workgroups in 8 bits, and (digit << 8) summed over the blocks of four
+    // queries of a copy's workgroups must stay inside 63 bits: |digit| < 2^40 per block (kernels.hip, to_digits)
+    auto countable = [](uint64_t wgs, uint64_t gpw, int lw) {
+        return wgs / 8 <= 255 && (wgs / 8) * gpw * ((64u >> lw) / 4u) <= 8192;
+    };
     // one wave per group: nw groups per workgroup of nw waves
     auto one_pass = [&](int lw, int nw, LoopPlan *pl) {
         const uint64_t wgs = round32((groups_at(lw) + nw - 1) / nw);
         const size_t lds = loop_lds_bytes(lw, nw, nw);
         const int k = loop_wgs_per_cu(sc, lw, filter, nw, lds);
-        if (k < 1 || wgs + 32ull * static_cast<uint64_t>(sc.loop_derate) > static_cast<uint64_t>(k) * cus * 15 / 16 || !countable(wgs, nw)) return false;
+        if (k < 1 || wgs + 32ull * static_cast<uint64_t>(sc.loop_derate) > static_cast<uint64_t>(k) * cus * 15 / 16 || !countable(wgs, nw, lw)) return false;
         *pl = LoopPlan{lw, nw, nw, static_cast<int>(wgs), filter};
         return true;
     };
@@ -1460,7 +1468,7 @@ static bool plan_loop(const sageicp_map *m, uint64_t n, double sem_th, LoopPlan 
                 if (wgs > cap) continue;
                 if (!env_gpw) gpw = (groups + wgs - 1) / wgs;
                 const size_t lds = loop_lds_bytes(lw, nw, static_cast<int>(gpw));
-                if (lds > 160 * 1024 || !countable(wgs, gpw)) continue;
+                if (lds > 160 * 1024 || !countable(wgs, gpw, lw)) continue;
                 if (loop_wgs_per_cu(sc, lw, filter, nw, lds) < k) continue;
                 if (k * nw > best) {
                     best = k * nw;
@@ -1506,9 +1514,9 @@ static bool plan_loop(const sageicp_map *m, uint64_t n, double sem_th, LoopPlan 
 // The ICP loop of Registration.cpp:127-138 as a stream of launches: k_icp (search + accumulation)
 // and k_fin (reduce, solve, compose, test) per iteration — or, for a frame that fits the machine
 // and is not sharded over GPUs, as ONE launch (k_loop).
-// (set while a frame whose sums left the range of the fixed-point accumulators is registered again
-// with one fp64 partial per workgroup — see the end of run_icp)
-static thread_local bool g_fp64_partials = false;
+// (raised while a frame whose sums left the range of the fixed-point accumulators is registered again
+// at a coarser scale — see the end of run_icp)
+
 
 int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const double init[7],
             double max_dist, double kernel, double sem_th, sageicp_comm *comm, double out[7],
@@ -1544,7 +1552,9 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     // out, the calls of the cool-down after it) — the fixed-point sums are rounded once per group of queries,
     // so their bits depend on the lanes per query and on nothing else, and a call repeated gives the same bits.
     LoopPlan plan{};
-    const bool loop_shape = !g_fp64_partials && (!comm || p2p) && plan_loop(m, n, sem_th, &plan);
+    // (SAGEICP_CHUNKED=1 asks for the chunked launch-per-iteration loop by name)
+    const bool loop_shape = (!comm || (p2p && !comm->device_shared && env_int("SAGEICP_CHUNKED", 0) == 0)) &&
+                            plan_loop(m, n, sem_th, &plan);
     const int lw = loop_shape ? plan.lw : icp_lw(n, sparse_voxels(m));
     // a launch that timed out (its grid was not resident as a whole: the GPU is shared with other work)
     // cost 50 ms before the frame went through the other loop: the next calls do not try again
@@ -1583,6 +1593,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
             xp.timeout_ticks = static_cast<unsigned long long>(ticks);
     }
     LoopParams L{};
+    if (use_loop && (rc = sc.loop_streams())) return rc;
     if (use_loop) {
         // ---- the whole loop in one launch (kernels.hip, k_loop): first its solving wave, on its own stream —
         // it has to hold its registers before the grid fills the machine; it waits for the grid's go
@@ -1608,6 +1619,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         L.max_iterations = max_it;
         L.epoch = ++sc.loop_epoch;
         for (int i = 0; i < 7; ++i) L.T0[i] = init[i];
+        L.acc_unscale = 1.0 / ip.acc_scale;
         L.shared_loop = comm ? 1 : 0;
         launch_loop_solve(L, xp, sc.stream2);
         HIPCHK(hipGetLastError());
@@ -1685,20 +1697,15 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     }
 
     // The workgroups of k_icp add their sums into fixed-point accumulators (kernels.h) that k_fin
-    // reads in one round trip; SAGEICP_PARTIALS=1 keeps the older form — one fp64 partial per
-    // workgroup, reduced by k_fin (big frames: k_red folds them into a few rows first) — for
-    // comparisons.
-    const bool use_acc = env_int("SAGEICP_PARTIALS", 0) == 0 && !g_fp64_partials;
-    if (use_acc) HIPCHK(hipMemsetAsync(sc.d_acc, 0, sizeof(long long) * kAccReplicas * kAccWords, s));
-    ip.acc = use_acc ? sc.d_acc : nullptr;
-    const int red_rows = (n && !use_acc) ? red_rows_for(blocks) : 0;
-    if (red_rows && (rc = sc.reserve_partials2(static_cast<size_t>(red_rows)))) return rc;
-    RedParams rp{sc.d_partials, blocks, sc.d_partials2, &sc.d_state->done};
+    // reads in one round trip.
+    HIPCHK(hipMemsetAsync(sc.d_acc, 0, sizeof(long long) * kAccReplicas * kAccWords, s));
+    ip.acc = sc.d_acc;
     FinParams fp{};
     fp.st = sc.d_state;
-    fp.partials = red_rows ? sc.d_partials2 : sc.d_partials;
+    fp.partials = nullptr;
     fp.acc = ip.acc;
-    fp.nparts = n ? (red_rows ? red_rows : blocks) : 0;
+    fp.acc_unscale = 1.0 / ip.acc_scale;
+    fp.nparts = 0;
     fp.mode = p2p ? 3 : (comm ? 1 : 0);
     fp.standalone = 0;
     if (p2p) fp.p2p = xp;
@@ -1713,7 +1720,6 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         if (ev) HIPCHK(hipEventRecord(sc.events[5 * slot + 1], s));
         launch_icp(ip, lw, true, s);
         if (ev) HIPCHK(hipEventRecord(sc.events[5 * slot + 2], s));
-        if (red_rows) launch_red(rp, s);
         launch_fin(fp, s);
         if (comm && !p2p) {     // k_fin left the local sums in state->sums
             ncclResult_t r = g_rccl.AllReduce(sc.d_state->sums, sc.d_state->sums, kNumSums,
@@ -1794,18 +1800,20 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     const IcpState &st = *sc.h_state;
     if (st.bad_input)
         return fail(SAGEICP_ERR_INVALID, "the frame holds a coordinate or label that is not finite (NaN / Inf)");
-    if (st.acc_overflow && !comm && !g_fp64_partials) {
-        // |sum over a wave| >= 2^50: georeferenced coordinates (UTM: ~3e6 m, s^2 x 64 queries) do that.
-        // The reference has no such limit: the frame is registered again with the fp64 partials of
-        // round 2 (one per workgroup, reduced by k_fin in a fixed order) — slower, not wrong.
-        g_fp64_partials = true;
+    if (st.acc_overflow && !comm && g_acc_shift < 2) {
+        // |sum over four queries| >= 2^46 (2^40 in the one-launch loop): georeferenced coordinates (UTM: ~3e6 m,
+        // 4 s^2 = 4e13; 10^7 m beyond) do that.  The reference has no such limit: the frame is registered again
+        // with the sums accumulated at 2^-24, then 2^-48 of their value — the same exact integer arithmetic on
+        // digits of weight 2^24, 2^-16, 2^-56 (what is dropped lies 2^80 below the limit either way).
+        ++g_acc_shift;
         const int rc2 = run_icp(m, d_frame, n, init, max_dist, kernel, sem_th, comm, out, stats, us_upload, t_begin);
-        g_fp64_partials = false;
+        --g_acc_shift;
         return rc2;
     }
     if (st.acc_overflow)
         return fail(SAGEICP_ERR_CAPACITY, "a Gauss-Newton sum left the range of the fixed-point accumulators "
-                                          "(|sum over a wave| >= 2^50: coordinates beyond ~10^6 m, or a pose guess that is not finite)");
+                                          "(coordinates beyond ~10^13 m, a pose guess that is not finite — or, under a communicator, "
+                                          "|sum over four queries| >= 2^40: every rank would have to take the same decision)");
     if (st.exchange_failed) {
         // the ranks' exchange counters may now differ by one: a later exchange could pass its wait
         // on a stale tag and add rows of another iteration.  The blocks are dead until every rank
@@ -1911,6 +1919,8 @@ int create_ranks(const sageicp_map *m) {
         ranks[k] = c;
         c->rank = k; c->nranks = N; c->device = dev[k];
         c->peer_mapped = true;
+        for (int r = 0; r < N; ++r)
+            if (r != k && dev[r] == dev[k]) c->device_shared = true;
         if (hipSetDevice(dev[k]) != hipSuccess ||
             hipExtMallocWithFlags(reinterpret_cast<void **>(&c->my_block), sizeof(P2pBlock),
                                   hipDeviceMallocFinegrained) != hipSuccess ||

@@ -60,9 +60,11 @@ struct IcpParams {
                               // (voxel << 8) | slot of its nearest neighbour, its byte offset};
                               // key 0xFFFFFFFF: none.  Seeds the next search with a tight bound.
     uint32_t *work;           // instrumented builds only: [n] map points handed to each query
-    double *partials;         // out: [gridDim.x][kNumSums] one partial per workgroup (acc == nullptr)
     long long *acc;           // out: the Gauss-Newton sums as fixed-point accumulators (see kAcc* below):
                               // every workgroup ADDS its 16 sums and its pair count with integer atomics
+    double acc_scale;         // a power of two (1 normally): the sums are accumulated as fixed-point numbers of
+                              // sum x acc_scale — a frame whose sums leave the range (coordinates of 10^7 m) is
+                              // registered again at 2^-24, 2^-48 (capi.hip); FinParams / LoopParams::acc_unscale undo it
     unsigned long long *counters;  // optional: [2 x waves] running sums of {C_q, pairs evaluated}
     unsigned nwaves;          // waves that own queries: ceil(n / (64 >> lw))
 #ifdef SAGE_ICP_DELAY_PROBE
@@ -104,38 +106,28 @@ int launch_gn(const GnParams &p, hipStream_t s);   // returns the number of part
 // partial (160 B) for k_fin, whose single workgroup then pulled 1,920 (c2) to 7,813 (c4) of them
 // through one CU: 3.6 to 13 us of every iteration.  Integer addition is associative, so the
 // workgroups can add into shared accumulators with fire-and-forget atomics in any order and the
-// result is still bit-reproducible — and exact: each sum is a 120-bit fixed-point number held as
-// three signed digits of 40 bits (weights 2^0, 2^-40, 2^-80) in 64-bit words, which leaves 23 bits
-// of head-room per digit for the carries of up to 2^23 workgroups; nothing is rounded until k_fin
-// converts the totals to fp64 once.  kAccReplicas copies (chosen by workgroup index) keep the
-// atomics of a launch off any single address; k_fin adds the copies (exactly) and clears them.
+// result is still bit-reproducible — and exact: the pair terms of every BLOCK of four consecutive
+// queries are added in fp64 in a fixed order, and each block sum becomes a 120-bit fixed-point number
+// held as three signed digits of 40 bits (weights 2^0, 2^-40, 2^-80) in 64-bit words (kernels.hip,
+// to_digits); from there on everything is integer addition, so the accumulated bits depend on the
+// order of the frame and on nothing else (lanes per query, waves, workgroups, which loop ran, order
+// of arrival).  Nothing is rounded again until k_fin converts the totals to fp64 once.  kAccReplicas
+// copies (chosen by workgroup index) keep the atomics of a launch off any single address; k_fin adds
+// the copies (exactly) and clears them.
 constexpr int kAccReplicas = 32;
 constexpr int kAccWords = 64;              // per replica: (16 sums + pair count) x 3 digits = 51 used
 constexpr int kAccValues = 17;
 struct FinParams {
     IcpState *st;
     const double *partials;
-    long long *acc;           // non-null: the sums come from the fixed-point accumulators (k_icp), not from partials
+    long long *acc;           // non-null: the sums come from the fixed-point accumulators (k_icp), not from partials (k_gn)
+    double acc_unscale;       // 1 / IcpParams::acc_scale
     int nparts;
     int mode;
     int standalone;           // 1: run even when st->done (AlignClouds entry)
     P2pParams p2p;            // mode 3 only
 };
 void launch_fin(const FinParams &p, hipStream_t s);
-
-// Two-stage reduction for big frames: above kRedThreshold partials (what k_fin's one workgroup
-// fetches in a single round of loads) k_red first folds slices of kRedSlice partials into
-// red_rows_for(nparts) rows, and k_fin reduces those.
-constexpr int kRedThreshold = 2448;
-constexpr int kRedSlice = 256;
-struct RedParams {
-    const double *partials;   // [nparts][kNumSums]
-    int nparts;
-    double *out;              // [red_rows_for(nparts)][kNumSums]
-    const int32_t *done;      // the loop's done flag (a finished loop: no-op); nullptr: always run
-};
-int red_rows_for(int nparts);                 // 0: single stage
-void launch_red(const RedParams &p, hipStream_t s);
 
 // ---- k_loop: the whole ICP loop of a frame that fits the machine's LDS in ONE launch -------------
 // (Registration.cpp:127-138.)  The frame is cut into GROUPS of 64 >> lw consecutive queries — what one
@@ -176,6 +168,7 @@ struct LoopParams {
     unsigned long long epoch;      // identifies this call: the solving wave is launched FIRST (it must be resident when the
                                    // grid fills the machine) and waits for LoopShared::go to carry this number
     double T0[7];                  // the initial pose (the solving wave starts before the loop state is uploaded)
+    double acc_unscale;            // 1 / IcpParams::acc_scale
     int shared_loop;               // 1: under a communicator — an overflowing sum or a bad frame point does not end
                                    // this rank's loop on its own (the ranks must keep exchanging in step)
 };

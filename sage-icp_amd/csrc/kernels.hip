@@ -321,59 +321,128 @@ __device__ int g_nn_span_iter;
 #define NN_T(i) do { } while (0)
 #endif
 
-// per-workgroup LDS header (words): ws[4][16] fp64 sums | accepted pairs [4] | arrival counter
-constexpr unsigned kWgSums = 0, kWgPairs = 2u * 16u * kIcpWavesPerBlock, kWgArrive = kWgPairs + kIcpWavesPerBlock;
-constexpr unsigned kWgHeaderWords = (kWgArrive + 1u + 15u) & ~15u;
+// per-workgroup LDS header of k_icp (words): arrival counter | the workgroup's fixed-point accumulators
+// (kWgAccWords 64-bit words)
+constexpr unsigned kWgAccWords = 52;         // (16 sums + pair count) x 3 digits = 51 | [51] overflow flag
+constexpr unsigned kWgArrive = 0, kWgAcc = 2;
+constexpr unsigned kWgHeaderWords = (kWgAcc + 2u * kWgAccWords + 15u) & ~15u;
 __host__ __device__ constexpr unsigned icp_wave_words(int lw) {
     // the rows of the wave's queries (kRowLdsStride words each); reused by the epilogue's
     // transposed reduction, 16 components x (queries + 2) fp64
     return static_cast<unsigned>(kRowLdsStride * (64 >> lw) + 64);
 }
 
-// The sums of a workgroup's waves and its pair count go into shared fixed-point accumulators
-// (kernels.h): one wave, lane l handles digit l % 3 of value l / 3 — converts every WAVE's fp64 sum
-// to that digit, adds the digits as integers, and sends ONE fire-and-forget 64-bit integer atomic.
-// Nothing is rounded after a wave's own fixed-order reduction, so the accumulated bits depend on
-// how the queries are cut into waves (lanes per query) and on nothing else: not on the order of
-// arrival, not on the waves per workgroup, not on which loop (k_icp + k_fin or k_loop) ran.
-// `ws` = [nw][16] fp64 sums of the workgroup's waves, `pairs` = [nw] accepted pairs (LDS); `dst` = the
-// replica this workgroup adds into.
+// ---- the Gauss-Newton sums as exact fixed-point numbers ---------------------------------------------
+// The unit that is rounded is a BLOCK of four consecutive queries of the (sorted) frame: the 16 pair terms
+// of its queries are added as (t0 + t1) + (t2 + t3) in fp64, and that block sum is split exactly into three
+// signed digits of 40 bits (weights 2^0, 2^-40, 2^-80; what lies below 2^-80 is dropped).  From there on
+// everything is integer addition — over the blocks of a wave (DPP), the waves and groups of a workgroup
+// (LDS atomics), the workgroups (global atomics into the shared accumulators, kernels.h) — which is
+// associative: the accumulated bits depend on the order of the frame and on NOTHING else.  Not on the lanes
+// per query (round 4 rounded once per wave: a frame registered with 4 and with 8 lanes per query differed
+// in the last bits), not on how queries are cut into waves, groups and workgroups, not on which loop ran,
+// not on the order of arrival.  (Blocks never straddle waves: a wave holds 4, 8, 16, 32 or 64 queries.)
+//
+// to_digits: v = a + b 2^-40 + c 2^-80 exactly (three integers of at most 40 bits and a sign, each exactly
+// representable), each as int64 through the 2^52 + 2^51 trick (both numbers lie in [2^52, 2^53): their
+// bit patterns differ by exactly the integer).  `ok` is cleared when |a| leaves the range the accumulators
+// have room for: the overflow flag then sends the frame through the fp64 partials (capi.hip).
+__device__ __forceinline__ void to_digits(double v, double limit, long long &d0, long long &d1, long long &d2, bool &ok) {
+    const double a = __builtin_rint(v);
+    const double r1 = (v - a) * 1099511627776.0;             // 2^40, exact
+    const double b = __builtin_rint(r1);
+    const double c2 = __builtin_rint((r1 - b) * 1099511627776.0);
+    ok &= fabs(a) < limit;
+    d0 = __double_as_longlong(a + 6755399441055744.0) - 0x4338000000000000ll;
+    d1 = __double_as_longlong(b + 6755399441055744.0) - 0x4338000000000000ll;
+    d2 = __double_as_longlong(c2 + 6755399441055744.0) - 0x4338000000000000ll;
+}
+// |a| of one block stays below this: 2^46 for k_icp + k_fin (their 32 copies of the accumulators take the
+// blocks of a 16M-point frame), 2^40 for k_loop, whose words also carry a count in their low byte (coordinates
+// of 10^5 m: 4 x (10^5)^2 = 4 10^10 < 2^40 = 1.1 10^12; capi.hip checks the number of blocks per copy)
+constexpr double kDigitLimit = 70368744177664.0, kDigitLimitCounted = 1099511627776.0;
+
+template <int CTRL>
+__device__ __forceinline__ long long dpp_i64(long long v) {
+    int lo = static_cast<int>(v), hi = static_cast<int>(v >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return (static_cast<long long>(hi) << 32) | static_cast<unsigned>(lo);
+}
+// lane i <- lane i + N (the lanes this is used on — the first lanes of queries — always have their partner
+// inside the wave; shifts below 16 stay inside a row of 16 lanes: DPP row_shl, no LDS traffic)
+template <int N>
+__device__ __forceinline__ double lane_shl_f64(double v) {
+    if constexpr (N < 16) return dpp_f64<0x100 + N>(v);
+    else return __shfl_down(v, N, 64);
+}
+
+// A wave's 16 pair terms per query (t[], on the first lane of every query; zeros for a query without a pair)
+// -> block sums -> digits -> added into the workgroup's accumulators `wgacc` (LDS, kWgAccWords 64-bit words).
+// `red` = LDS scratch of this wave, 16 fp64 per block.
+template <int LW>
+__device__ __forceinline__ void wave_terms_to_wgacc(const double (&t)[kCount], unsigned pairs, int lane, double *red,
+                                                    unsigned long long *wgacc, double limit, double scale) {
+    constexpr int W = 1 << LW, QW = 64 >> LW, NBLK = QW / 4;
+    // A. block sums, (t0 + t1) + (t2 + t3), on the first lane of every block;
+    // B. transposed through LDS: the block's first lane parks its 16 sums
+    {
+        const bool first = (lane & (4 * W - 1)) == 0;
+        double *dst = red + (lane / (4 * W)) * kCount;
+#pragma unroll
+        for (int c = 0; c < kCount; ++c) {
+            const double x = t[c] + lane_shl_f64<W>(t[c]);
+            const double y = x + lane_shl_f64<2 * W>(x);
+            if (first) dst[c] = y;
+        }
+    }
+    // (values pass from lane to lane through LDS here: the hardware serves a wave's LDS instructions in order,
+    // but the COMPILER has to be told that the loads below see other lanes' stores)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // C. lane (c, j) = (lane >> 2, lane & 3) converts component c of the blocks j, j + 4, ...
+    const int c = lane >> 2, j = lane & 3;
+    long long d0 = 0, d1 = 0, d2 = 0;
+    bool ok = true;
+#pragma unroll
+    for (int bb = 0; bb < NBLK; bb += 4) {
+        const int blk = bb + j;
+        const double v = blk < NBLK ? red[(blk < NBLK ? blk : 0) * kCount + c] : 0.0;
+        long long e0, e1, e2;
+        to_digits(v * scale, limit, e0, e1, e2, ok);       // (scale: a power of two, 1 normally)
+        d0 += e0; d1 += e1; d2 += e2;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // D. the four lanes of a component meet (integers: any order)
+    d0 += dpp_i64<kDppXor1>(d0); d1 += dpp_i64<kDppXor1>(d1); d2 += dpp_i64<kDppXor1>(d2);
+    d0 += dpp_i64<kDppXor2>(d0); d1 += dpp_i64<kDppXor2>(d1); d2 += dpp_i64<kDppXor2>(d2);
+    // E. ... and add into the workgroup's accumulators
+    if (j == 0) {
+        (void)__hip_atomic_fetch_add(wgacc + 3 * c, static_cast<unsigned long long>(d0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        (void)__hip_atomic_fetch_add(wgacc + 3 * c + 1, static_cast<unsigned long long>(d1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        (void)__hip_atomic_fetch_add(wgacc + 3 * c + 2, static_cast<unsigned long long>(d2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (!ok) (void)__hip_atomic_fetch_or(wgacc + kWgAccWords - 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0)
+        (void)__hip_atomic_fetch_add(wgacc + 3 * kCount, static_cast<unsigned long long>(pairs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// The workgroup's accumulators (LDS) -> the shared ones: lane l sends word l (digit l % 3 of value l / 3) as ONE
+// fire-and-forget 64-bit integer atomic into the copy `dst`, and clears the word for the next iteration.
 // COUNTED (k_loop): every word also counts its contributions — a workgroup adds (digit << 8) + 1, the low
 // byte of a word says how many workgroups are in it — so that whoever reads the accumulators inside the
 // launch knows, word by word, when they are complete, and the workgroup neither waits for its atomics to
 // be acknowledged nor keeps a separate arrival counter.  (The form that did both — s_waitcnt vmcnt(0), then
 // one of eight counters — ran an iteration in the same time, profiles/r04/loop_times_counted_words.txt against
 // loop_times_xcd_stripes_rowshift.txt: this one is kept for having one protocol less and no ordering
-// assumption at all.)  The digits get 8 bits less room for it: a wave's sum has to
-// stay below 2^44 (coordinates of a few 10^5 m); beyond, the overflow flag sends the frame through the fp64
-// partials (capi.hip), as everywhere.
+// assumption at all.)
 template <bool COUNTED = false>
-__device__ __forceinline__ void wg_sums_to_acc(const double *ws, const uint32_t *pairs, int nw, long long *dst,
-                                               long long *overflow) {
+__device__ __forceinline__ void wgacc_flush(unsigned long long *wgacc, long long *dst, long long *overflow) {
     const int lane = static_cast<int>(threadIdx.x & 63u);
-    const int c = min(lane / 3, kAccValues - 1), digit = lane % 3;
-    long long x = 0;
-    bool ok = true;
-    if (c < kCount) {
-        for (int k = 0; k < nw; ++k) {
-            const double v = ws[k * kCount + c];
-            // exact split v = a + b 2^-40 + c2 2^-80 (+ what lies below 2^-80, dropped): three
-            // integers of at most 40 bits and a sign, each exactly representable
-            const double a = __builtin_rint(v);
-            const double r1 = (v - a) * 1099511627776.0;             // 2^40, exact
-            const double b = __builtin_rint(r1);
-            const double c2 = __builtin_rint((r1 - b) * 1099511627776.0);
-            const double d = digit == 0 ? a : (digit == 1 ? b : c2);
-            ok &= fabs(a) < (COUNTED ? 17592186044416.0 : 1125899906842624.0);    // 2^44 / 2^50 (coordinates of 10^6 m stay far below 2^50)
-            // integer of magnitude < 2^51 held in a double -> int64 through the 2^52 + 2^51 trick
-            // (both numbers lie in [2^52, 2^53): their bit patterns differ by exactly d)
-            x += __double_as_longlong(d + 6755399441055744.0) - 0x4338000000000000ll;
-        }
-    } else if (digit == 0) {
-        unsigned n = 0u;
-        for (int k = 0; k < nw; ++k) n += pairs[k];
-        x = static_cast<long long>(n);
-    }
+    const int l = min(lane, static_cast<int>(kWgAccWords) - 1);
+    const long long x = static_cast<long long>(wgacc[l]);
+    const bool ok = wgacc[kWgAccWords - 1] == 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane < static_cast<int>(kWgAccWords)) wgacc[lane] = 0ull;
     if (lane < 3 * kAccValues) {
         if constexpr (COUNTED) {
             (void)__hip_atomic_fetch_add(dst + lane, ok ? x * 256 + 1 : 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -400,9 +469,8 @@ __device__ __forceinline__ void wg_sums_to_acc(const double *ws, const uint32_t 
 struct LoopGroup {
     uint32_t *rows;            // LDS [QW][kRowLdsStride]
     uint32_t *state;           // LDS [QW][kLoopStateWords]
-    double *red;               // LDS: the running wave's scratch for the epilogue's transposed reduction
-    double *ws;                // LDS [16]: where the group's fp64 sums are parked
-    uint32_t *pairs;           // LDS: ... and its accepted pairs
+    double *red;               // LDS: the running wave's scratch for the epilogue's transposed block sums
+    unsigned long long *wgacc; // LDS: the workgroup's fixed-point accumulators (wave_terms_to_wgacc)
     unsigned group;            // index of the group in the frame: queries group * QW ...
 #ifdef SAGE_LOOP_TIMING
     unsigned long long ph[8], tprev;           // probe builds: cycles per phase of the body, summed over the iterations
@@ -418,20 +486,19 @@ constexpr unsigned kLoopStripe = kLoopStripeHost;  // workgroups of k_loop per X
 constexpr int kNoVoxel = 0x7FFFFFFF;        // a home voxel no point has (|index| < 2^20): row not built yet
 constexpr unsigned kStPrev = 16, kStKey = 18;
 // LDS of a k_loop workgroup (words): header { arrival counter | next group | the pose of this iteration
-// (R[9], t[3]) | done } | ws[gpw][16] fp64 sums | accepted pairs [gpw] | the groups { rows, state } |
-// one reduction scratch per wave
+// (R[9], t[3]) | done | the workgroup's fixed-point accumulators } | the groups { rows, state } |
+// one scratch for the transposed block sums per wave
 constexpr unsigned kLpArrive = 0, kLpNext = 1, kLpDone = 2;
 constexpr unsigned kLpPose = 4;                                    // 12 doubles, 16-B aligned
 constexpr unsigned kLpDbg = kLpPose + 24u;                         // probe builds: max points of a query | stale queries | points
-constexpr unsigned kLpHeaderWords = (kLpDbg + 4u + 15u) & ~15u;
-constexpr int kLoopRedRounds = 4;           // the 16 components are reduced four at a time (LDS: 4 x (QW + 2) fp64 per wave)
+constexpr unsigned kLpAcc = kLpDbg + 4u;                           // kWgAccWords 64-bit words
+constexpr unsigned kLpHeaderWords = (kLpAcc + 2u * kWgAccWords + 15u) & ~15u;
 __host__ __device__ constexpr unsigned loop_group_words(int lw) {
     return static_cast<unsigned>((kRowLdsStride + kLoopStateWords) * (64 >> lw));
 }
 __host__ __device__ constexpr unsigned loop_red_words(int lw) {
-    return static_cast<unsigned>(2 * (kCount / kLoopRedRounds) * ((64 >> lw) + 2));
+    return static_cast<unsigned>(2 * kCount * ((64 >> lw) / 4));          // 16 fp64 per block of four queries
 }
-__host__ __device__ constexpr unsigned loop_ws_words(unsigned gpw) { return gpw * 2u * kCount + ((gpw + 7u) & ~7u); }
 
 // PERSIST (k_loop): the body runs on group `G` — rows and per-query state in LDS — with the pose from
 // `pose` (LDS: R[9], t[3]); nothing is read from or written to the global rows / nn_prev arrays;
@@ -510,6 +577,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
     const int wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     if (FUSED && !PERSIST) {
         if (threadIdx.x == 0) smem[kWgArrive] = 0u;
+        if (threadIdx.x < 2u * kWgAccWords) smem[kWgAcc + threadIdx.x] = 0u;
         __syncthreads();
     }
     uint32_t *wl;
@@ -971,9 +1039,22 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
         // of full records, 20.6 -> 22.0 with four of compact ones (profiles/r04/loop_depth.txt) — the
         // slow waves are not waiting for their loads.  Two sets everywhere.)
         constexpr int DEPTH = !PERSIST ? 2 : SAGE_LOOP_DEPTH_OF(FILT);
-        Pair A, B;
+        Pair A;
         bool more = false;
         issue(A, more);
+        if constexpr (DEPTH == 1) {
+            // (probe: one set in flight — 11 registers fewer; the other waves of the SIMD cover the round trips)
+            if (seed) evaluate(*seed, seeded, seed_key);
+            fb = min_f64(fb, best);
+            set_thresholds();
+            for (;;) {
+                consume(A);
+                if (!__ballot(more)) break;
+                issue(A, more);
+            }
+            return;
+        }
+        Pair B;
         if constexpr (DEPTH == 2) {
             // the seed's load is older than A's: waiting for it leaves A's loads in flight
             if (seed) evaluate(*seed, seeded, seed_key);
@@ -1187,38 +1268,10 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
             }
         }
         const unsigned pairs = static_cast<unsigned>(__popcll(__ballot(use)));
-        // Wave reduction in a fixed order (bit-reproducible): the query lanes park their 16 terms
-        // transposed in LDS (k_icp: the rows are no longer needed), four lanes per component add QW / 4
-        // parked values each and finish with two DPP exchanges.
-        constexpr int S = QW + 2;              // fp64 stride of one component
         if constexpr (PERSIST) {
-            // k_loop: the rows stay, the scratch is the running wave's own and holds four components
-            // at a time — the same additions in the same order, component by component
-            double *red = G->red;
-            const int c = lane >> 2, r = lane & 3;
-            double v = 0.0;
-#pragma unroll
-            for (int k = 0; k < kLoopRedRounds; ++k) {
-                constexpr int NC = kCount / kLoopRedRounds;
-                if (ci == 0u) {
-#pragma unroll
-                    for (int cc = 0; cc < NC; ++cc) red[cc * S + qw] = t[NC * k + cc];
-                }
-                // (values pass from lane to lane through LDS here: the hardware serves a wave's LDS
-                // instructions in order, but the COMPILER has to be told that the loads below see other
-                // lanes' stores — without the fences it keeps a non-writing lane's loads of round 0 for all
-                // four rounds, the addresses being the same)
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                double u = 0.0;
-#pragma unroll
-                for (int e = 0; e < QW / 4; ++e) u += red[(c % NC) * S + r + 4 * e];
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                v = (c / NC == k) ? u : v;
-            }
-            v += dpp_f64<kDppXor1>(v);
-            v += dpp_f64<kDppXor2>(v);
-            if (r == 0) G->ws[c] = v;
-            if (lane == 0) *G->pairs = pairs;
+            // k_loop: block sums -> exact digits -> the workgroup's accumulators (the rows stay: the scratch
+            // is the running wave's own)
+            wave_terms_to_wgacc<LW>(t, pairs, lane, G->red, G->wgacc, kDigitLimitCounted, P.acc_scale);
 #ifdef SAGE_LOOP_TIMING
             {
                 unsigned mx = valid ? npairs : 0u, sm = (valid && ci == 0u) ? npairs : 0u, stl = (stale && ci == 0u) ? 1u : 0u;
@@ -1237,54 +1290,21 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
             LP_T(7);
             return;                             // (k_loop closes the workgroup's iteration itself)
         }
-        double *red = reinterpret_cast<double *>(wl);
-        if (ci == 0u) {
-#pragma unroll
-            for (int c = 0; c < kCount; ++c) red[c * S + qw] = t[c];
-        }
         {
-            const int c = lane >> 2, r = lane & 3;
-            double v = 0.0;
-#pragma unroll
-            for (int e = 0; e < QW / 4; ++e) v += red[c * S + r + 4 * e];
-            v += dpp_f64<kDppXor1>(v);
-            v += dpp_f64<kDppXor2>(v);
-            double *ws = reinterpret_cast<double *>(smem + kWgSums) + wv * kCount;
-            if (r == 0) ws[c] = v;
-            if (lane == 0) smem[kWgPairs + wv] = pairs;
-        }
-        // Workgroup partial: the last wave to arrive adds the four rows in wave order.
-        // (what the ticket orders — the waves' sums — lives in LDS, which serves a CU's waves in order: the
-        // ticket is a relaxed LDS atomic between compiler barriers.  An acquire-release one also waits for the
-        // wave's outstanding GLOBAL traffic — the counters' fire-and-forget atomics, the nn_prev store — which
-        // nothing here needs; measured, it made no difference to either loop.)
-        unsigned prior = 0u;
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        if (lane == 0)
-            prior = __hip_atomic_fetch_add(&smem[kWgArrive], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        prior = __builtin_amdgcn_readfirstlane(prior);
-        if (prior == kIcpWavesPerBlock - 1u && P.acc) {
-            wg_sums_to_acc(reinterpret_cast<const double *>(smem + kWgSums), smem + kWgPairs, kIcpWavesPerBlock,
-                           P.acc + static_cast<size_t>(blockIdx.x & (kAccReplicas - 1)) * kAccWords,
-                           P.acc + kAccWords - 1);
-        } else if (prior == kIcpWavesPerBlock - 1u) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const double *ws = reinterpret_cast<const double *>(smem + kWgSums);
-            double *out = P.partials + static_cast<size_t>(blockIdx.x) * kNumSums;
-            if (lane < kCount) {
-                double v = ws[lane];
-#pragma unroll
-                for (int k = 1; k < kIcpWavesPerBlock; ++k) v += ws[k * kCount + lane];
-                out[lane] = v;
-            } else if (lane == kCount) {
-                unsigned n = 0u;
-#pragma unroll
-                for (int k = 0; k < kIcpWavesPerBlock; ++k) n += smem[kWgPairs + k];
-                out[kCount] = static_cast<double>(n);
-            } else if (lane < kNumSums) {
-                out[lane] = 0.0;
-            }
+            // k_icp: the same, into this workgroup's accumulators; the last wave to arrive sends them on
+            // (what the ticket orders lives in LDS, which serves a CU's waves in order: the ticket is a
+            // relaxed LDS atomic between compiler barriers)
+            unsigned long long *wgacc = reinterpret_cast<unsigned long long *>(smem + kWgAcc);
+            wave_terms_to_wgacc<LW>(t, pairs, lane, reinterpret_cast<double *>(wl), wgacc, kDigitLimit, P.acc_scale);
+            unsigned prior = 0u;
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            if (lane == 0)
+                prior = __hip_atomic_fetch_add(&smem[kWgArrive], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            prior = __builtin_amdgcn_readfirstlane(prior);
+            if (prior == kIcpWavesPerBlock - 1u)
+                wgacc_flush(wgacc, P.acc + static_cast<size_t>(blockIdx.x & (kAccReplicas - 1)) * kAccWords,
+                            P.acc + kAccWords - 1);
         }
     }
 #ifdef SAGE_NN_TIMING
@@ -1428,7 +1448,7 @@ __device__ __forceinline__ bool reduce_partials(const double *partials, int npar
 // trip for 16 KB, the replicas added exactly (integers), three digits -> one fp64 per sum, and the
 // accumulators cleared for the next iteration.  Returns false when *done is set (see above).
 __device__ __forceinline__ bool reduce_accumulators(long long *acc, double *S /* LDS [kNumSums] */,
-                                                    const int32_t *done, int32_t *overflow) {
+                                                    const int32_t *done, int32_t *overflow, double unscale) {
     __shared__ long long part[kAccReplicas][kAccWords];
     __shared__ long long part2[8][kAccWords];
     const int t = static_cast<int>(threadIdx.x);
@@ -1467,6 +1487,7 @@ __device__ __forceinline__ bool reduce_accumulators(long long *acc, double *S /*
             const double b = static_cast<double>(part[0][3 * t + 1]);
             const double c = static_cast<double>(part[0][3 * t + 2]);
             r = a + (b * 9.094947017729282e-13 + c * 8.271806125530277e-25);      // 2^-40, 2^-80
+            if (t < kCount) r *= unscale;      // (a power of two; the pair count is not scaled)
         }
         S[t] = r;
         if (t == 0 && part[0][kAccWords - 1] != 0) *overflow = 1;
@@ -1613,20 +1634,6 @@ __device__ __forceinline__ void exchange_sums(IcpState *st, const P2pParams &X) 
     }
 }
 
-// ------------------------------------------------------------------------------------ k_red
-// First stage of the reduction for frames whose partials one workgroup cannot fetch in one round of
-// loads (c4: 7,813 partials = 1.25 MB through ONE CU took 13 us of every iteration): workgroup g
-// reduces slice g (kRedSlice partials, the same fixed order as k_fin's own reduction) into row g of
-// a second, small array of partials, which k_fin then reduces as usual.  Sums are in a fixed order
-// that depends on the number of partials only: bit-reproducible.
-__global__ __launch_bounds__(kFinThreads) void k_red(RedParams P) {
-    __shared__ double S[kNumSums];
-    const int lo = static_cast<int>(blockIdx.x) * kRedSlice;
-    const int cnt = min(kRedSlice, P.nparts - lo);
-    if (!reduce_partials(P.partials + static_cast<size_t>(lo) * kNumSums, cnt, S, P.done)) return;
-    if (threadIdx.x < kNumSums) P.out[static_cast<size_t>(blockIdx.x) * kNumSums + threadIdx.x] = S[threadIdx.x];
-}
-
 // ------------------------------------------------------------------------------------ k_fin
 __global__ __launch_bounds__(kFinThreads) void k_fin(FinParams P) {
     __shared__ double S[kNumSums];
@@ -1639,7 +1646,7 @@ __global__ __launch_bounds__(kFinThreads) void k_fin(FinParams P) {
     if (threadIdx.x < 64) pre = prefetch_state(st);
     if (P.mode != 2) {
         if (P.acc) {
-            if (!reduce_accumulators(P.acc, S, P.standalone ? nullptr : &st->done, &st->acc_overflow)) return;
+            if (!reduce_accumulators(P.acc, S, P.standalone ? nullptr : &st->done, &st->acc_overflow, P.acc_unscale)) return;
         } else if (!reduce_partials(P.partials, P.nparts, S, P.standalone ? nullptr : &st->done)) return;
 #ifdef SAGE_GN_TIMING
         if (threadIdx.x == 0) atomicAdd(&g_gn_phase[8], __builtin_amdgcn_s_memrealtime() - t_start);
@@ -1777,7 +1784,7 @@ __device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, c
     const unsigned long long tag = static_cast<unsigned long long>(it) + 1ull;
 
     // 1. the sums of this iteration's set of accumulators: read (one round trip per pass) until every word
-    // says that all the workgroups adding into it are in (its low byte counts them, wg_sums_to_acc) —
+    // says that all the workgroups adding into it are in (its low byte counts them, wgacc_flush) —
     // the read that finds them complete IS the read of the sums.  The set is then cleared for the
     // iteration after the next (the clears are complete long before that pose is published: the waits
     // of the next iteration's passes cover them).
@@ -1830,6 +1837,7 @@ __device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, c
                 const double b = static_cast<double>(digits[3 * lane + 1]);
                 const double c = static_cast<double>(digits[3 * lane + 2]);
                 r = a + (b * 9.094947017729282e-13 + c * 8.271806125530277e-25);      // 2^-40, 2^-80
+                if (lane < kCount) r *= L.acc_unscale;     // (a power of two; the pair count is not scaled)
             }
             S[lane] = r;
         }
@@ -2007,10 +2015,8 @@ void k_loop(LoopArgs A) {
         g0 = lo + idx * base + min(idx, extra);
         gcnt = min(gpw, base + (idx < extra ? 1u : 0u));
     }
-    uint32_t *ws_base = smem + kLpHeaderWords;
-    double *ws = reinterpret_cast<double *>(ws_base);
-    uint32_t *pairs = ws_base + gpw * 2u * kCount;
-    uint32_t *groups = ws_base + loop_ws_words(gpw);
+    unsigned long long *wgacc = reinterpret_cast<unsigned long long *>(smem + kLpAcc);
+    uint32_t *groups = smem + kLpHeaderWords;
     double *red = reinterpret_cast<double *>(groups + gpw * loop_group_words(LW) + static_cast<unsigned>(wv) * loop_red_words(LW));
 
     // ---- set-up: the initial pose, the state records of the groups' queries --------------------------
@@ -2024,8 +2030,7 @@ void k_loop(LoopArgs A) {
         smem[kLpDbg] = 0u; smem[kLpDbg + 1] = 0u; smem[kLpDbg + 2] = 0u;
 #endif
     }
-    // (a group this workgroup does not have — the tail of the frame, of an XCD's range — adds zeros)
-    for (unsigned i = threadIdx.x; i < loop_ws_words(gpw); i += blockDim.x) ws_base[i] = 0u;
+    for (unsigned i = threadIdx.x; i < 2u * kWgAccWords; i += blockDim.x) smem[kLpAcc + i] = 0u;
     for (unsigned gi = static_cast<unsigned>(wv); gi < gcnt; gi += static_cast<unsigned>(nw)) {
         const unsigned lane = threadIdx.x & 63u;
         const unsigned qw = lane >> LW;
@@ -2072,8 +2077,7 @@ void k_loop(LoopArgs A) {
             G.rows = groups + gi * loop_group_words(LW);
             G.state = G.rows + kRowLdsStride * QW;
             G.red = red;
-            G.ws = ws + gi * kCount;
-            G.pairs = pairs + gi;
+            G.wgacc = wgacc;
             G.group = g0 + gi;
 #ifdef SAGE_LOOP_TIMING
             for (int i = 0; i < 8; ++i) G.ph[i] = 0;
@@ -2102,8 +2106,7 @@ void k_loop(LoopArgs A) {
         const bool last = prior == static_cast<unsigned>(nw) - 1u;
         if (last) {
             // this wave closes the workgroup's iteration
-            wg_sums_to_acc<true>(ws, pairs, static_cast<int>(gpw), &sh->acc[it & 1][blockIdx.x & (kLoopReplicas - 1)][0],
-                                 &sh->acc[it & 1][0][kAccWords - 1]);
+            wgacc_flush<true>(wgacc, &sh->acc[it & 1][blockIdx.x & (kLoopReplicas - 1)][0], &sh->acc[it & 1][0][kAccWords - 1]);
             if (lane == 0) {                   // everybody is in: ready for the next iteration
                 smem[kLpArrive] = 0u;
                 smem[kLpNext] = 0u;
@@ -2412,8 +2415,8 @@ void launch_icp(const IcpParams &p, int lw, bool fused, hipStream_t s) {
 }
 
 size_t loop_lds_bytes(int lw, int nw, int gpw) {
-    return sizeof(uint32_t) * (kLpHeaderWords + loop_ws_words(static_cast<unsigned>(gpw)) +
-                               static_cast<size_t>(gpw) * loop_group_words(lw) + static_cast<size_t>(nw) * loop_red_words(lw));
+    return sizeof(uint32_t) * (kLpHeaderWords + static_cast<size_t>(gpw) * loop_group_words(lw) +
+                               static_cast<size_t>(nw) * loop_red_words(lw));
 }
 // (a workgroup that owns many groups can ask for more than the 64 KB a kernel gets by default)
 template <int LW, bool FILT>
@@ -2477,11 +2480,6 @@ int launch_gn(const GnParams &p, hipStream_t s) {
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_gn, dim3(static_cast<int>(blocks)), dim3(256), 0, s, p);
     return static_cast<int>(blocks);
-}
-
-int red_rows_for(int nparts) { return nparts > kRedThreshold ? (nparts + kRedSlice - 1) / kRedSlice : 0; }
-void launch_red(const RedParams &p, hipStream_t s) {
-    hipLaunchKernelGGL(k_red, dim3(red_rows_for(p.nparts)), dim3(kFinThreads), 0, s, p);
 }
 
 void launch_fin(const FinParams &p, hipStream_t s) {

@@ -772,7 +772,11 @@ def test_direct_exchange_between_two_processes(gpu_sage, tmp_path, chunked):
     assert d2["config"]["iterations_per_frame"] == d1["config"]["iterations_per_frame"]
     assert d2["config"]["converged"] and d2["config"]["pose_error_vs_planted"] == d1["config"]["pose_error_vs_planted"]
     br = d2["config"]["iteration_breakdown"]        # the first real SCALE line explains itself
-    assert br and br["shard_compute_us_per_iteration"] > 1.0 and br["exchange_us_per_iteration"] > 1.0
+    assert br and br["loop_form"]
+    lp = br["launch_per_iteration"]
+    assert lp["shard_compute_us_per_iteration"] > 1.0 and lp["exchange_us_per_iteration"] > 1.0
+    if not chunked:        # (the polled loop: each rank's half of the frame runs in ONE launch, on its half of the CUs)
+        assert "one launch" in br["loop_form"] and br["iteration_us"] > 1.0
 
 
 def test_bench_independent_frames_mode(gpu_sage):
@@ -916,11 +920,11 @@ def test_c5_full_size_properties(gpu_sage, oracle, params):
     assert st.sum_candidates == ost.sum_candidates_total
 
 
-def test_sums_beyond_the_fixed_point_range_fall_back_to_fp64_partials(gpu_sage, oracle, monkeypatch):
-    """|sum over a wave| >= 2^50 (coordinates of millions of metres: georeferenced clouds) does not fit
-    the fixed-point accumulators; the reference has no such limit, so the frame is registered again
-    through the fp64 partials of round 2 instead of failing — the same answer as asking for them"""
-    monkeypatch.setenv("SAGEICP_LW", "1")                    # 32 queries per wave
+def test_sums_beyond_the_fixed_point_range_are_accumulated_at_a_coarser_scale(gpu_sage, oracle, monkeypatch):
+    """|sum over four queries| >= 2^46 (2^40 in the one-launch loop: coordinates of millions of metres,
+    georeferenced clouds) does not fit the fixed-point accumulators; the reference has no such limit, so the
+    frame is registered again with the sums accumulated at 2^-24 of their value instead of failing — the same
+    answer as asking for that scale, in either loop"""
     rng = np.random.default_rng(3)
     off = np.array([8.0e6, -3.0e6, 0.0, 0.0])
     mp = rng.uniform(-60, 60, size=(30000, 4))
@@ -932,7 +936,9 @@ def test_sums_beyond_the_fixed_point_range_fall_back_to_fp64_partials(gpu_sage, 
     frame = np.ascontiguousarray(q + off)
     pose, st = gpu_sage.register_frame(frame, m, gpu_sage.IDENTITY, 6.0, 0.5, 0.4, return_stats=True)
     assert st.iterations >= 1 and np.all(np.isfinite(pose))
-    monkeypatch.setenv("SAGEICP_PARTIALS", "1")
     monkeypatch.setenv("SAGEICP_LOOP", "0")
+    pose0, st0 = gpu_sage.register_frame(frame, m, gpu_sage.IDENTITY, 6.0, 0.5, 0.4, return_stats=True)
+    assert np.array_equal(pose, pose0) and st.iterations == st0.iterations
+    monkeypatch.setenv("SAGEICP_ACC_SHIFT", "1")
     ref, sr = gpu_sage.register_frame(frame, m, gpu_sage.IDENTITY, 6.0, 0.5, 0.4, return_stats=True)
     assert np.array_equal(pose, ref) and st.iterations == sr.iterations
