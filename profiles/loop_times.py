@@ -1,7 +1,7 @@
 """Timeline of the one-launch loop (k_loop) from a build with -DSAGE_LOOP_TIMING: per iteration, when the
 workgroups counted themselves in, when the solving wave saw all counts / had the sums / had the step /
 had published, and when the workgroups held the next pose.  100-MHz ticks -> microseconds.
-    python profiles/loop_times.py [divisor of the c2 frame, default 8] [cold|steady]"""
+    python profiles/loop_times.py [divisor of the frame, default 8] [cold|steady] [workload, default c2]"""
 import ctypes as C
 import os
 import sys
@@ -15,7 +15,8 @@ from sage_icp_amd import synthetic as syn  # noqa: E402
 
 div = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 p = syn.PARAMS[sys.argv[2] if len(sys.argv) > 2 else "cold"]
-w = syn.make_workload("c2", lambda: sage.VoxelHashMap(1.0, 100.0))
+name = sys.argv[3] if len(sys.argv) > 3 else "c2"
+w = syn.make_workload(name, lambda: sage.VoxelHashMap(syn.WORKLOADS[name]["voxel"], 100.0))
 n = len(w["scan"]) // div
 f = sage.Frame(w["map"], w["scan"][:n])
 os.environ["SAGEICP_LOOP"] = "2"

@@ -1396,7 +1396,8 @@ IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, 
 // has to be resident at once: what bounds a frame is the LDS of the machine (232 B per query: ~170k
 // queries on 256 CUs), not its wave slots.
 struct LoopPlan {
-    int lw, nw, gpw, wgs;      // lanes per query (log2), waves per workgroup, groups per workgroup, query workgroups
+    int lw, nw, gpw, wgs;      // lanes per query (log2), waves per workgroup, units of 64 >> lw queries per workgroup
+                               // (at most), query workgroups
     bool filter;
 };
 static int loop_wgs_per_cu(const Scratch &sc, int lw, bool filter, int nw, size_t lds) {
@@ -1497,10 +1498,10 @@ static bool plan_loop(const sageicp_map *m, uint64_t n, double sem_th, LoopPlan 
     if (!ok) ok = multi_pass(lw, out);
     if (dbg) {
         if (ok)
-            std::fprintf(stderr, "sageicp: one-launch loop for %llu queries: %d lanes/query, %d workgroups of %d waves, %d groups each, "
+            std::fprintf(stderr, "sageicp: one-launch loop for %llu queries: %d lanes/query, %d workgroups of %d waves, <= %d units of %d queries each, "
                                  "%zu B of LDS (%d workgroups per CU by the occupancy query, %d CUs)\n",
-                         static_cast<unsigned long long>(n), 1 << out->lw, out->wgs, out->nw, out->gpw,
-                         loop_lds_bytes(out->lw, out->nw, out->gpw),
+                         static_cast<unsigned long long>(n), 1 << out->lw, out->wgs, out->nw,
+                         out->gpw, 64 >> out->lw, loop_lds_bytes(out->lw, out->nw, out->gpw),
                          loop_wgs_per_cu(sc, out->lw, filter, out->nw, loop_lds_bytes(out->lw, out->nw, out->gpw)), sc.num_cus);
         else
             std::fprintf(stderr, "sageicp: %llu queries at %d lanes/query do not fit the one-launch loop (7 waves x 4 workgroups "

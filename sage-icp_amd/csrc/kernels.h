@@ -158,7 +158,7 @@ struct LoopParams {
     LoopShared *sh;
     IcpState *st;                  // in: the initial pose; out: the final loop state (written by the solving wave)
     int nw;                        // waves per workgroup (<= kLoopMaxWaves)
-    int gpw;                       // groups of (64 >> lw) queries a workgroup owns
+    int gpw;                       // units of (64 >> lw) queries a workgroup owns at most (LDS for that many)
     int wgs;                       // query workgroups (a multiple of 8 x kLoopStripe); each accumulator copy counts wgs / 8
     int contiguous;                // 0: XCD x serves stripes x, x + 8, ... of kLoopStripe workgroups; 1: XCD x serves the
                                    // groups [xcd_first[x], xcd_first[x + 1]) of the (spatially sorted) frame

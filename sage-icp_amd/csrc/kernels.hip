@@ -384,43 +384,41 @@ template <int LW>
 __device__ __forceinline__ void wave_terms_to_wgacc(const double (&t)[kCount], unsigned pairs, int lane, double *red,
                                                     unsigned long long *wgacc, double limit, double scale) {
     constexpr int W = 1 << LW, QW = 64 >> LW, NBLK = QW / 4;
-    // A. block sums, (t0 + t1) + (t2 + t3), on the first lane of every block;
-    // B. transposed through LDS: the block's first lane parks its 16 sums
-    {
-        const bool first = (lane & (4 * W - 1)) == 0;
-        double *dst = red + (lane / (4 * W)) * kCount;
+    // A. block sums, (t0 + t1) + (t2 + t3), on the first lane of every block
+    double y[kCount];
 #pragma unroll
-        for (int c = 0; c < kCount; ++c) {
-            const double x = t[c] + lane_shl_f64<W>(t[c]);
-            const double y = x + lane_shl_f64<2 * W>(x);
-            if (first) dst[c] = y;
-        }
+    for (int c = 0; c < kCount; ++c) {
+        const double x = t[c] + lane_shl_f64<W>(t[c]);
+        y[c] = x + lane_shl_f64<2 * W>(x);
     }
-    // (values pass from lane to lane through LDS here: the hardware serves a wave's LDS instructions in order,
-    // but the COMPILER has to be told that the loads below see other lanes' stores)
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    // C. lane (c, j) = (lane >> 2, lane & 3) converts component c of the blocks j, j + 4, ...
+    // B. four blocks at a time (512 B of scratch whatever the lanes per query): the blocks' first lanes park
+    // their 16 sums, C. lane (c, j) = (lane >> 2, lane & 3) converts component c of block j
     const int c = lane >> 2, j = lane & 3;
     long long d0 = 0, d1 = 0, d2 = 0;
     bool ok = true;
+    const int blk = lane / (4 * W);
+    const bool first = (lane & (4 * W - 1)) == 0;
 #pragma unroll
-    for (int bb = 0; bb < NBLK; bb += 4) {
-        const int blk = bb + j;
-        const double v = blk < NBLK ? red[(blk < NBLK ? blk : 0) * kCount + c] : 0.0;
+    for (int r = 0; r < NBLK; r += 4) {
+        if (first && blk >= r && blk < r + 4) {
+            double *dst = red + (blk - r) * kCount;
+#pragma unroll
+            for (int cc = 0; cc < kCount; ++cc) dst[cc] = y[cc];
+        }
+        // (values pass from lane to lane through LDS here: the hardware serves a wave's LDS instructions in
+        // order, but the COMPILER has to be told that the loads below see other lanes' stores)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const double v = r + j < NBLK ? red[j * kCount + c] : 0.0;
         long long e0, e1, e2;
         to_digits(v * scale, limit, e0, e1, e2, ok);       // (scale: a power of two, 1 normally)
         d0 += e0; d1 += e1; d2 += e2;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    // D. the four lanes of a component meet (integers: any order)
-    d0 += dpp_i64<kDppXor1>(d0); d1 += dpp_i64<kDppXor1>(d1); d2 += dpp_i64<kDppXor1>(d2);
-    d0 += dpp_i64<kDppXor2>(d0); d1 += dpp_i64<kDppXor2>(d1); d2 += dpp_i64<kDppXor2>(d2);
-    // E. ... and add into the workgroup's accumulators
-    if (j == 0) {
-        (void)__hip_atomic_fetch_add(wgacc + 3 * c, static_cast<unsigned long long>(d0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        (void)__hip_atomic_fetch_add(wgacc + 3 * c + 1, static_cast<unsigned long long>(d1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        (void)__hip_atomic_fetch_add(wgacc + 3 * c + 2, static_cast<unsigned long long>(d2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
+    // D. every lane adds its digits into the workgroup's accumulators (integers: any order; three
+    // fire-and-forget LDS atomics — reducing the four lanes of a component first costs 24 more instructions)
+    (void)__hip_atomic_fetch_add(wgacc + 3 * c, static_cast<unsigned long long>(d0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    (void)__hip_atomic_fetch_add(wgacc + 3 * c + 1, static_cast<unsigned long long>(d1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    (void)__hip_atomic_fetch_add(wgacc + 3 * c + 2, static_cast<unsigned long long>(d2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (!ok) (void)__hip_atomic_fetch_or(wgacc + kWgAccWords - 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (lane == 0)
         (void)__hip_atomic_fetch_add(wgacc + 3 * kCount, static_cast<unsigned long long>(pairs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -471,7 +469,8 @@ struct LoopGroup {
     uint32_t *state;           // LDS [QW][kLoopStateWords]
     double *red;               // LDS: the running wave's scratch for the epilogue's transposed block sums
     unsigned long long *wgacc; // LDS: the workgroup's fixed-point accumulators (wave_terms_to_wgacc)
-    unsigned group;            // index of the group in the frame: queries group * QW ...
+    unsigned q_first;          // the group's first query (a multiple of four)
+    unsigned slot;             // its slot in the per-wave counters (IcpParams::counters)
 #ifdef SAGE_LOOP_TIMING
     unsigned long long ph[8], tprev;           // probe builds: cycles per phase of the body, summed over the iterations
 #endif
@@ -496,9 +495,7 @@ constexpr unsigned kLpHeaderWords = (kLpAcc + 2u * kWgAccWords + 15u) & ~15u;
 __host__ __device__ constexpr unsigned loop_group_words(int lw) {
     return static_cast<unsigned>((kRowLdsStride + kLoopStateWords) * (64 >> lw));
 }
-__host__ __device__ constexpr unsigned loop_red_words(int lw) {
-    return static_cast<unsigned>(2 * kCount * ((64 >> lw) / 4));          // 16 fp64 per block of four queries
-}
+__host__ __device__ constexpr unsigned loop_red_words() { return 2u * kCount * 4u; }    // 16 fp64 for each of four blocks of queries
 
 // PERSIST (k_loop): the body runs on group `G` — rows and per-query state in LDS — with the pose from
 // `pose` (LDS: R[9], t[3]); nothing is read from or written to the global rows / nn_prev arrays;
@@ -593,7 +590,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
     constexpr unsigned kStripe = SAGE_ICP_STRIPE;
     unsigned wave_id;                                                               // wave-uniform
     if constexpr (PERSIST) {
-        wave_id = G->group;                    // (k_loop maps its workgroups to groups itself)
+        wave_id = G->slot;                     // (k_loop maps its workgroups to groups of queries itself)
     } else {
         const unsigned xcd = blockIdx.x & 7u, jb = blockIdx.x >> 3;
         const unsigned wg = ((jb / kStripe) * 8u + xcd) * kStripe + (jb % kStripe);
@@ -602,7 +599,9 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
 
     const int qw = lane >> LW;                 // this lane's query within the wave
     const unsigned ci = static_cast<unsigned>(lane) & (W - 1u);
-    const unsigned q = wave_id * QW + static_cast<unsigned>(qw);
+    unsigned q;
+    if constexpr (PERSIST) q = G->q_first + static_cast<unsigned>(qw);
+    else q = wave_id * QW + static_cast<unsigned>(qw);
     const bool valid = q < static_cast<unsigned>(P.n);
     const unsigned qc = valid ? q : 0u;        // keeps the loads of idle lanes legal
     uint32_t *lrow = wl + qw * kRowLdsStride;
@@ -1966,6 +1965,10 @@ __global__ __launch_bounds__(64) void k_loop_solve(SolveArgs A) {
 #ifndef SAGE_LOOP_POLL_SLEEP
 #define SAGE_LOOP_POLL_SLEEP 8     // x 64 clocks between two looks of a workgroup at the pose granules
 #endif
+// (Tried and dropped, profiles/r05/mix_ab_*.txt: a workgroup with more units of queries than waves registering
+// PAIRS of units at half the lanes per query, one wave per pair, so that every wave makes one pass — bit-identical,
+// the sums being exact from the blocks of four queries on, and slower: 37.5 against 34.6 us per iteration on c2.  A
+// wave's pass lasts as long as its lanes have points to look at: two units at half the lanes are two passes' worth.)
 template <int LW, bool FILT>
 __global__ __launch_bounds__(64 * kLoopMaxWaves) __attribute__((amdgpu_waves_per_eu(SAGE_LOOP_OCC, 8)))
 void k_loop(LoopArgs A) {
@@ -1987,16 +1990,15 @@ void k_loop(LoopArgs A) {
         if (bad) return;
     }
 
-    // ---- the groups this workgroup owns for the whole call ------------------------------------------
+    // ---- the units (of QW queries) this workgroup owns for the whole call ----------------------------
     // Workgroup b is dispatched to XCD b % 8 (observed; speed only).  Striped: XCD x serves the stripes
     // x, x + 8, ... of kLoopStripe workgroups' worth of the spatially sorted frame (every XCD gets the
     // same mix of dense and sparse regions, every L2 sees the whole map).  Contiguous: XCD x serves the
-    // groups [xcd_first[x], xcd_first[x + 1]) — one compact region of the map per L2, the boundaries
+    // units [xcd_first[x], xcd_first[x + 1]) — one compact region of the map per L2, the boundaries
     // chosen by the host so that the XCDs hold equal work.
-    // Either way the groups are dealt out EVENLY over the workgroups that serve them — floor or ceil of
-    // groups / workgroups each, never more than gpw: a frame of 7,500 groups on 1,760 resident workgroups
-    // of four waves gives 460 of them a fifth group instead of leaving 260 with none (an iteration
-    // ends with the workgroup whose waves have to make a second pass; profiles/r05).
+    // Either way the units are dealt out EVENLY over the workgroups that serve them — floor or ceil of
+    // units / workgroups each, never more than gpw: a frame of 7,500 units on 1,664 resident workgroups
+    // of four waves gives 844 of them a fifth unit instead of leaving 200 with none.
     unsigned g0, gcnt;
     {
         const unsigned xcd = blockIdx.x & 7u, jb = blockIdx.x >> 3;
@@ -2017,7 +2019,7 @@ void k_loop(LoopArgs A) {
     }
     unsigned long long *wgacc = reinterpret_cast<unsigned long long *>(smem + kLpAcc);
     uint32_t *groups = smem + kLpHeaderWords;
-    double *red = reinterpret_cast<double *>(groups + gpw * loop_group_words(LW) + static_cast<unsigned>(wv) * loop_red_words(LW));
+    double *red = reinterpret_cast<double *>(groups + gpw * loop_group_words(LW) + static_cast<unsigned>(wv) * loop_red_words());
 
     // ---- set-up: the initial pose, the state records of the groups' queries --------------------------
     if (threadIdx.x < 9) s_pose[threadIdx.x] = P.st->R[threadIdx.x];
@@ -2032,12 +2034,12 @@ void k_loop(LoopArgs A) {
     }
     for (unsigned i = threadIdx.x; i < 2u * kWgAccWords; i += blockDim.x) smem[kLpAcc + i] = 0u;
     for (unsigned gi = static_cast<unsigned>(wv); gi < gcnt; gi += static_cast<unsigned>(nw)) {
+        // (a unit's LDS: the rows of its QW queries, then their state records)
         const unsigned lane = threadIdx.x & 63u;
-        const unsigned qw = lane >> LW;
-        const unsigned q = (g0 + gi) * QW + qw;
+        const unsigned q = (g0 + gi) * QW + lane;
         const Point4 f = P.frame[q < static_cast<unsigned>(P.n) ? q : 0u];
-        if ((lane & ((1u << LW) - 1u)) == 0u) {
-            uint32_t *lst = groups + gi * loop_group_words(LW) + kRowLdsStride * QW + qw * kLoopStateWords;
+        if (lane < static_cast<unsigned>(QW)) {
+            uint32_t *lst = groups + gi * loop_group_words(LW) + kRowLdsStride * QW + lane * kLoopStateWords;
             *reinterpret_cast<Point4 *>(lst) = f;
             Point4 z;
             z.x = z.y = z.z = z.l = 0.0;
@@ -2078,7 +2080,8 @@ void k_loop(LoopArgs A) {
             G.state = G.rows + kRowLdsStride * QW;
             G.red = red;
             G.wgacc = wgacc;
-            G.group = g0 + gi;
+            G.q_first = (g0 + gi) * QW;
+            G.slot = g0 + gi;
 #ifdef SAGE_LOOP_TIMING
             for (int i = 0; i < 8; ++i) G.ph[i] = 0;
             G.tprev = __builtin_amdgcn_s_memtime();
@@ -2416,56 +2419,37 @@ void launch_icp(const IcpParams &p, int lw, bool fused, hipStream_t s) {
 
 size_t loop_lds_bytes(int lw, int nw, int gpw) {
     return sizeof(uint32_t) * (kLpHeaderWords + static_cast<size_t>(gpw) * loop_group_words(lw) +
-                               static_cast<size_t>(nw) * loop_red_words(lw));
+                               static_cast<size_t>(nw) * loop_red_words());
 }
-// (a workgroup that owns many groups can ask for more than the 64 KB a kernel gets by default)
-template <int LW, bool FILT>
-static bool loop_allow_big_lds() {
-    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_loop<LW, FILT>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-    return ok;
-}
-template <int LW, bool FILT>
-static int loop_blocks_lw(int nw, size_t lds) {
-    int nb = 0;
-    if (lds > 64 * 1024 && !loop_allow_big_lds<LW, FILT>()) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_loop<LW, FILT>, 64 * nw, lds) != hipSuccess) return 0;
-    return nb;
+// the kernel of a shape, as an untyped pointer (what the occupancy query and the launch take)
+static const void *loop_kernel(int lw, bool filter) {
+#define SAGE_LOOP_K(LW_, F_) reinterpret_cast<const void *>(&k_loop<LW_, F_>)
+    switch (lw) {
+        case 1: return filter ? SAGE_LOOP_K(1, true) : SAGE_LOOP_K(1, false);
+        case 2: return filter ? SAGE_LOOP_K(2, true) : SAGE_LOOP_K(2, false);
+        case 3: return filter ? SAGE_LOOP_K(3, true) : SAGE_LOOP_K(3, false);
+        case 4: return filter ? SAGE_LOOP_K(4, true) : SAGE_LOOP_K(4, false);
+        default: return nullptr;
+    }
+#undef SAGE_LOOP_K
 }
 int loop_blocks_per_cu(int lw, bool filter, int nw, size_t lds) {
     if (nw < 1 || nw > kLoopMaxWaves || lds > 160 * 1024) return 0;
-    switch (lw) {
-        case 1: return filter ? loop_blocks_lw<1, true>(nw, lds) : loop_blocks_lw<1, false>(nw, lds);
-        case 2: return filter ? loop_blocks_lw<2, true>(nw, lds) : loop_blocks_lw<2, false>(nw, lds);
-        case 3: return filter ? loop_blocks_lw<3, true>(nw, lds) : loop_blocks_lw<3, false>(nw, lds);
-        case 4: return filter ? loop_blocks_lw<4, true>(nw, lds) : loop_blocks_lw<4, false>(nw, lds);
-        default: return 0;
-    }
+    const void *k = loop_kernel(lw, filter);
+    if (!k) return 0;
+    // (a workgroup that owns many units can ask for more than the 64 KB a kernel gets by default)
+    if (lds > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 0;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64 * nw, lds) != hipSuccess) return 0;
+    return nb;
 }
 void launch_loop(const IcpParams &p, const LoopParams &l, int lw, hipStream_t s) {
-    const dim3 g(l.wgs), b(64 * l.nw);
     const size_t lds = loop_lds_bytes(lw, l.nw, l.gpw);
     LoopArgs a;
     a.P = p;
     a.L = l;
-    switch (lw) {
-        case 1:
-            if (p.filter) hipLaunchKernelGGL((k_loop<1, true>), g, b, lds, s, a);
-            else hipLaunchKernelGGL((k_loop<1, false>), g, b, lds, s, a);
-            break;
-        case 2:
-            if (p.filter) hipLaunchKernelGGL((k_loop<2, true>), g, b, lds, s, a);
-            else hipLaunchKernelGGL((k_loop<2, false>), g, b, lds, s, a);
-            break;
-        case 3:
-            if (p.filter) hipLaunchKernelGGL((k_loop<3, true>), g, b, lds, s, a);
-            else hipLaunchKernelGGL((k_loop<3, false>), g, b, lds, s, a);
-            break;
-        default:
-            if (p.filter) hipLaunchKernelGGL((k_loop<4, true>), g, b, lds, s, a);
-            else hipLaunchKernelGGL((k_loop<4, false>), g, b, lds, s, a);
-            break;
-    }
+    void *args[] = {&a};
+    (void)hipLaunchKernel(loop_kernel(lw, p.filter != 0), dim3(l.wgs), dim3(64 * l.nw), args, lds, s);
 }
 void launch_loop_solve(const LoopParams &l, const P2pParams &x, hipStream_t s) {
     SolveArgs a;

@@ -208,7 +208,7 @@ def test_frame_that_does_not_fit_uses_the_launch_per_iteration_loop(gpu_sage, or
     assert st.single_launch == 0 and st.converged == 1
 
 
-@pytest.mark.parametrize("lw,waves,gpw", [(2, 7, 3), (3, 4, 9), (2, 8, 2), (4, 5, 7), (1, 7, 2)])
+@pytest.mark.parametrize("lw,waves,gpw", [(2, 7, 3), (3, 4, 9), (2, 8, 2), (4, 5, 7), (1, 7, 2), (2, 4, 5), (2, 4, 8), (3, 2, 3), (4, 4, 6)])
 def test_several_groups_per_wave(gpu_sage, oracle, lw, waves, gpw):
     """a workgroup that owns more groups of queries than it has waves: its waves take them one after another from
     an LDS counter (the shape the headline frame runs in) — the same bits as one wave per group"""
