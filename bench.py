@@ -79,13 +79,54 @@ def self_launch(args):
 
 
 def device_source_hash():
-    """sha256 over the sources whose build the profiler counters describe (profiles/collect.py)"""
+    """sha256 over what the profiler counters describe (profiles/collect.py): every source and header of the
+    library and the build recipe with its flags"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("kernels.hip", "kernels.h", "sageicp_types.h", "capi.hip"):
-        with open(os.path.join(ROOT, "sage-icp_amd", "csrc", f), "rb") as fh:
+    csrc = os.path.join(ROOT, "sage-icp_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        with open(os.path.join(csrc, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    for f in (os.path.join(ROOT, "sage-icp_amd", "build.py"), os.path.join(ROOT, "include", "sageicp.h")):
+        with open(f, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
+
+
+def apply_counters(roofline, c, source_hash, one_launch, compulsory, executed_bytes):
+    """`achieved` / `frac` / `traffic` of the roofline object from an entry of profiles/icp_counters.json — only when
+    the entry was collected on exactly this build (`source_hash`) and on the form of the loop that ran; otherwise
+    they stay null and `frac_basis` says why (tests/test_abi_and_host.py feeds a wrong hash)."""
+    want = "k_loop" if one_launch else "k_icp"
+    if not c:
+        return roofline
+    if c.get("source_sha256") != source_hash:
+        roofline["frac_basis"] = ("none: profiles/icp_counters.json was collected on another build of the library "
+                                  "(re-run profiles/run_profiles.sh + profiles/collect.py)")
+        return roofline
+    if c.get("kernel") != want:
+        roofline["frac_basis"] = "none: profiles/icp_counters.json describes %s, this run went through %s" % (c.get("kernel"), want)
+        return roofline
+    if not c.get("hbm_bytes_per_launch"):
+        return roofline
+    kt_us = c["avg_launch_us_kernel_trace"]
+    roofline["counters_fresh"] = True
+    roofline["counters"] = c.get("counters_source")
+    roofline["traffic"] = c["hbm_bytes_per_launch"]
+    roofline["achieved"] = round(roofline["traffic"] / (kt_us * 1e-6) / 1e9, 1)
+    roofline["frac"] = round(roofline["achieved"] / HBM_PEAK_GBS, 4)
+    roofline["frac_basis"] = ("rocprofv3 FETCH_SIZE x 2 per iteration / kernel-trace duration per iteration / 8 TB/s ("
+                              + str(c.get("counters_source", "")).split(" (")[0] + ")")
+    floor_us = roofline["traffic"] / (HBM_ACHIEVABLE_GBS * 1e9) * 1e6
+    roofline["traffic_floor_us"] = round(floor_us, 2)
+    roofline["x_over_traffic_floor"] = round(kt_us / floor_us, 2)
+    roofline["traffic_over_compulsory"] = round(roofline["traffic"] / compulsory, 3)
+    roofline["traffic_over_algorithmic"] = round(roofline["traffic"] / executed_bytes, 3)
+    for key in ("avg_launch_us_kernel_trace", "valu_frac", "useful_inst_frac", "valu_insts_per_launch",
+                "lane_utilization", "l2_hit_rate", "wait_frac"):
+        if key in c:
+            roofline[key] = c[key]
+    return roofline
 
 
 def cpu_quota():
@@ -487,25 +528,31 @@ def main():
         # point) pair the search actually evaluates — counted by the kernel; the exact cell lower
         # bound prunes the rest without loading them — + 32 B per accepted correspondence.
         executed_bytes = 448.0 * n_local + 16.0 * pairs_per_launch + 32.0 * n_corr
-        achieved = executed_bytes / (avg_us * 1e-6) / 1e9          # GB/s
+        executed_gbs = executed_bytes / (avg_us * 1e-6) / 1e9          # GB/s
         # SURVEY 8d's contractual figure charges EVERY candidate of the 27 voxels (what the
         # reference's scan touches): an effective gather rate, not a bound on this kernel
         survey_bytes = 448.0 * n_local + 16.0 * cand_per_launch + 32.0 * n_corr
         compulsory = 16 * (vmap.size() + n_local + 4 * vmap.num_voxels())
-        roofline = {"bound": "hbm", "kernel": "k_icp (correspondence search + Gauss-Newton sums)",
-                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "frac_basis": "executed-bytes model / HIP-event duration (NO fresh rocprofv3 counters for this "
-                                  "build: mostly cache traffic, not an HBM fraction)",
+        one_launch = bool(last.single_launch)
+        # `achieved` / `frac` mean ONE thing: HBM-side bytes per iteration as rocprofv3 counts them (FETCH_SIZE x 2,
+        # the guide's gfx950 correction) / the kernel-trace duration of the same iteration / 8 TB/s — from the
+        # counter passes committed under profiles/, used only when they were collected on exactly this build and
+        # this form of the loop.  Without such counters they are null (never a model under the same name); the
+        # byte MODELS of the executed algorithm are reported under their own names, over the live HIP-event time.
+        roofline = {"bound": "hbm",
+                    "kernel": ("k_loop (the whole ICP loop in one launch: correspondence search + Gauss-Newton sums, "
+                               "per iteration)") if one_launch else "k_icp (correspondence search + Gauss-Newton sums)",
+                    "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                    "counters_fresh": False,
+                    "frac_basis": "none: no rocprofv3 counters collected on this build and loop form "
+                                  "(profiles/run_profiles.sh + profiles/collect.py refresh them)",
                     "traffic": None,
-                    "executed_bytes_gbs": round(achieved, 1),
-                    "executed_bytes_frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "executed_bytes_gbs": round(executed_gbs, 1),
+                    "executed_bytes_frac": round(executed_gbs / HBM_PEAK_GBS, 4),
                     "algorithmic_bytes_per_launch": round(executed_bytes),
                     "algorithmic_bytes_model": "448 B x queries + 16 B x (query, map point) pairs evaluated "
-                                               "(counted by the kernel) + 32 B x correspondences",
-                    "served_from": "L2 / Infinity Cache for the most part where map and per-query streams fit "
-                                   "the 256-MB Infinity Cache (c2: 32 MB + 21 MB): see traffic / hbm_frac "
-                                   "for what crosses the L2s",
+                                               "(counted by the kernel) + 32 B x correspondences, per iteration: "
+                                               "mostly L2 / Infinity-Cache traffic, NOT an HBM fraction",
                     "effective_gather_gbs": round(survey_bytes / (avg_us * 1e-6) / 1e9, 1),
                     "effective_gather_bytes_per_launch": round(survey_bytes),
                     "effective_gather_note": "SURVEY 8d's figure: every candidate of the 27 voxels charged "
@@ -520,13 +567,16 @@ def main():
                     "lanes_per_query": last.lanes_per_query,
                     "scan_form": "compact 16-B records behind an exact fp32 filter" if last.compact_scan
                                  else "full 32-B fp64 records",
-                    "loop_form": "one launch for the whole loop (k_loop): avg_launch_us is the launch / iterations"
-                                 if last.single_launch else "k_icp + k_fin per iteration",
+                    "loop_form": "one launch for the whole loop (k_loop + its solving wave): avg_launch_us is the "
+                                 "launch / its iterations, solve and hand-offs included"
+                                 if one_launch else "k_icp + k_fin per iteration",
                     "candidates_per_query": round(cand_per_launch / max(n_local, 1), 1),
                     "pairs_evaluated_frac": round(pairs / max(cands, 1), 4),
-                    "timing": "mean k_icp duration from HIP events on the launch stream around 1 launch in 8 "
-                              "of the timed region (an event pair also brackets the launch gap: the "
-                              "rocprofv3 kernel-trace mean under profiles/ is ~3 us shorter)"}
+                    "timing": ("HIP events on the launch stream around the k_loop launch of every frame of the timed "
+                               "region / its iterations") if one_launch else
+                              ("mean k_icp duration from HIP events on the launch stream around 1 launch in 8 "
+                               "of the timed region (an event pair also brackets the launch gap: the "
+                               "rocprofv3 kernel-trace mean under profiles/ is ~3 us shorter)")}
         # What bounds the kernel, from the rocprofv3 counter passes of this command
         # (profiles/collect.py -> profiles/icp_counters.json).  They are measurements of a
         # particular build: used only when the device code they were taken on is the code that ran.
@@ -534,31 +584,10 @@ def main():
         if os.path.exists(cpath) and world == 1 and args.scale == 1.0:
             try:
                 c = json.load(open(cpath)).get("%s-%s" % (args.workload, args.params))
-                if c and c.get("source_sha256") != device_source_hash():
-                    roofline["counters"] = "stale: profiles/icp_counters.json was collected on another build " \
-                                           "of kernels.hip / capi.hip (re-run profiles/run_profiles.sh)"
-                elif c:
-                    roofline["counters"] = c.get("counters_source")
-                    roofline["traffic"] = c.get("hbm_bytes_per_launch")
-                    if roofline["traffic"]:
-                        # both from the profiled runs (bytes and duration of the same launches):
-                        # THE roofline figure — what rocprofv3 shows, north_star's wording
-                        kt_us = c.get("avg_launch_us_kernel_trace") or avg_us
-                        roofline["hbm_frac"] = c.get("hbm_frac")
-                        roofline["achieved"] = round(roofline["traffic"] / (kt_us * 1e-6) / 1e9, 1)
-                        roofline["frac"] = round(roofline["achieved"] / HBM_PEAK_GBS, 4)
-                        roofline["frac_basis"] = ("rocprofv3 FETCH_SIZE x 2 per executed launch / kernel-trace mean "
-                                                  "duration / 8 TB/s (" + str(c.get("counters_source", "")).split(" (")[0] + ")")
-                        floor_us = roofline["traffic"] / (HBM_ACHIEVABLE_GBS * 1e9) * 1e6
-                        roofline["traffic_floor_us"] = round(floor_us, 2)
-                        roofline["x_over_traffic_floor"] = round(kt_us / floor_us, 2)
-                        roofline["traffic_over_algorithmic"] = round(roofline["traffic"] / executed_bytes, 3)
-                    for key in ("avg_launch_us_kernel_trace", "valu_frac", "useful_inst_frac",
-                                "lane_utilization", "l2_hit_rate"):
-                        if key in c:
-                            roofline[key] = c[key]
             except Exception as e:      # noqa
-                roofline["counters"] = "unreadable: %s" % e
+                c = None
+                roofline["frac_basis"] = "none: profiles/icp_counters.json unreadable: %s" % e
+            apply_counters(roofline, c, device_source_hash(), one_launch, compulsory, executed_bytes)
 
     fps = args.steps / elapsed * (world if args.independent else 1)
     cpu = parity = None

@@ -35,6 +35,14 @@ with open(os.path.join(dst, "kernel_stats_executed.csv"), "w") as f:
     f.write('"Name","Launches","NoOpLaunches","AverageNs","MinNs","MaxNs","TotalDurationNs"\n')
     for k, v in sorted(ex.items(), key=lambda kv: -kv[1][5]):
         f.write('"%s",%d,%d,%.1f,%.0f,%.0f,%.0f\n' % (k, v[1], v[0] - v[1], v[2], v[3], v[4], v[5]))
+bench = json.load(open(os.path.join(src, "bench_default.json")))
+rf = bench["roofline"]
+iters = int(bench["config"]["iterations_per_frame"])
+# which kernel is the loop made of in this workload?  k_loop: one launch = one frame = `iters` iterations
+# (its counters come from the counter-collection twin, profiles/run_profiles.sh); k_icp: one launch = one iteration
+loop = [k for k in ex if "k_loop<" in k]
+kname = "k_loop" if loop else "k_icp"
+per = float(iters) if loop else 1.0
 mean = {}
 for sub in ("pmc_fetch", "pmc_tcc", "pmc_sq", "pmc_sq2", "pmc_mem"):
     p = os.path.join(src, sub, "pmc_counter_collection.csv")
@@ -45,23 +53,21 @@ for sub in ("pmc_fetch", "pmc_tcc", "pmc_sq", "pmc_sq2", "pmc_mem"):
     acc = collections.defaultdict(list)
     dur = []
     for r in csv.DictReader(open(p)):
-        if "k_icp" not in r["Kernel_Name"]:
+        if kname + "<" not in r["Kernel_Name"]:
             continue
         t = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
         if t < S.noop_limit(r["Kernel_Name"]):
             continue
-        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-        dur.append(t)
+        acc[r["Counter_Name"]].append(float(r["Counter_Value"]) / per)
+        dur.append(t / per)
     for k, v in acc.items():
         mean[k] = sum(v) / len(v)
         mean["_launches_" + k] = len(v)
     if dur:
         mean["_us_" + sub] = sum(dur) / len(dur) / 1e3
-icp = [v for k, v in ex.items() if "k_icp" in k][0]
+icp = [v for k, v in ex.items() if kname + "<" in k][0]
 fin = [v for k, v in ex.items() if "k_fin" in k]
-avg_us = icp[2] / 1e3
-bench = json.load(open(os.path.join(src, "bench_default.json")))
-rf = bench["roofline"]
+avg_us = icp[2] / 1e3 / per              # per iteration
 pairs_per_launch = rf["pairs_evaluated_frac"] * rf["candidates_per_query"] * rf["queries_per_launch"]
 # VALU busy: every VALU wave-instruction holds its SIMD for >= 4 cycles (fp64 and DPP forms; the
 # 2-cycle fp32 forms are a minority here); 256 CUs x 4 SIMDs; cycles = kernel duration x clock
@@ -71,19 +77,24 @@ hbm_bytes = int(round(mean["FETCH_SIZE"] * 1024 * 2)) if "FETCH_SIZE" in mean el
 # bytes and duration of the SAME (counter-pass) launches; the kernel-trace duration beside it
 fetch_us = mean.get("_us_pmc_fetch", avg_us)
 entry = {
-    "kernel": "k_icp",
+    "kernel": kname,
     "workload": key,
+    "iterations_per_launch": int(per),
     "source_sha256": device_source_hash(),
-    "counters_source": "profiles/%s/%s/pmc_*.csv.gz (rocprofv3 --pmc, separate passes, means per executed launch "
-                       "over %d launches; no-op launches of a finished loop excluded)"
-                       % (tag, key, int(mean.get("_launches_SQ_INSTS_VALU", mean.get("_launches_FETCH_SIZE", 0)))),
+    "counters_source": "profiles/%s/%s/pmc_*.csv.gz (rocprofv3 --pmc, separate passes, means per iteration "
+                       "over %d launches%s)"
+                       % (tag, key, int(mean.get("_launches_SQ_INSTS_VALU", mean.get("_launches_FETCH_SIZE", 0))),
+                          "; k_loop: counters of the counter-collection twin of the library (solving wave inside the grid: "
+                          "--pmc runs one kernel at a time), divided by the launch's %d iterations; the duration is the "
+                          "PRODUCT's, from --kernel-trace" % iters if loop else
+                          "; no-op launches of a finished loop excluded"),
     "avg_launch_us_kernel_trace": round(avg_us, 2),
-    "k_fin_avg_us_kernel_trace": round(fin[0][2] / 1e3, 2) if fin else None,
+    "k_fin_avg_us_kernel_trace": round(fin[0][2] / 1e3, 2) if fin and not loop else None,
     "avg_launch_us_fetch_pass": round(fetch_us, 2),
     "fetch_size_kb": mean.get("FETCH_SIZE"),
     "hbm_bytes_per_launch": hbm_bytes,
     "hbm_frac": round(hbm_bytes / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if hbm_bytes else None,
-    "hbm_frac_definition": "FETCH_SIZE x 2 / kernel-trace duration of the executed launches / %.0f GB/s" % HBM_PEAK_GBS,
+    "hbm_frac_definition": "FETCH_SIZE x 2 per iteration / kernel-trace duration per iteration / %.0f GB/s" % HBM_PEAK_GBS,
     "traffic_floor_us": round(hbm_bytes / 6.3e12 * 1e6, 2) if hbm_bytes else None,
     "x_over_traffic_floor": round(avg_us / (hbm_bytes / 6.3e12 * 1e6), 2) if hbm_bytes else None,
     "hbm_correction": "x2: on gfx950 FETCH_SIZE reports half the bytes of 16-B/lane reads (MI355X_MICROARCH.md, HBM); "
@@ -91,6 +102,7 @@ entry = {
     "valu_insts_per_launch": valu,
     "salu_insts_per_launch": mean.get("SQ_INSTS_SALU"),
     "valu_frac": round(valu * 4.0 / (1024.0 * cycles), 4) if valu else None,
+    "wait_frac": round(mean["SQ_WAIT_INST_ANY"] / mean["SQ_WAVE_CYCLES"], 4) if mean.get("SQ_WAVE_CYCLES") and "SQ_WAIT_INST_ANY" in mean else None,
     "lane_utilization": round(mean["SQ_THREAD_CYCLES_VALU"] / (mean["SQ_ACTIVE_INST_VALU"] * 64.0), 4)
                         if "SQ_THREAD_CYCLES_VALU" in mean and mean.get("SQ_ACTIVE_INST_VALU") else None,
     # the VALU instructions spent on one scanned (query, map point) pair — 12 in the fp32 filter of

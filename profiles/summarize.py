@@ -64,7 +64,8 @@ if __name__ == "__main__":
         for r in csv.DictReader(open(p)):
             print("| %s | %s | %.2f | %.3f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
                                                      float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
-    print("\n## PMC passes (mean per executed launch of each kernel)\n\n| pass | kernel | counter | mean/launch | launches |\n|---|---|---|---|---|")
+    print("\n## PMC passes (mean per executed launch of each kernel; k_loop: one launch = one frame = all its iterations,\n"
+          "collected on the counter-collection twin of the library, solving wave inside the grid)\n\n| pass | kernel | counter | mean/launch | launches |\n|---|---|---|---|---|")
     for sub in sorted(os.listdir(d)):
         p = os.path.join(d, sub, "pmc_counter_collection.csv")
         if not os.path.exists(p):

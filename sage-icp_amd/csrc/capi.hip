@@ -1622,9 +1622,11 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         for (int i = 0; i < 7; ++i) L.T0[i] = init[i];
         L.acc_unscale = 1.0 / ip.acc_scale;
         L.shared_loop = comm ? 1 : 0;
+#ifndef SAGE_LOOP_INGRID          // (the counter-collection twin keeps the solving wave inside the grid: kernels.hip)
         launch_loop_solve(L, xp, sc.stream2);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(sc.ev_solve, sc.stream2));
+#endif
     }
 
     // Spatial ordering of the frame: the loop runs on a copy sorted by map-frame voxel under the
@@ -1652,7 +1654,9 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         if (prof) HIPCHK(hipEventRecord(sc.events[1], s));
         launch_loop(lp, L, plan.lw, s);
         if (prof) HIPCHK(hipEventRecord(sc.events[2], s));
+#ifndef SAGE_LOOP_INGRID
         HIPCHK(hipStreamWaitEvent(s, sc.ev_solve, 0));             // the solving wave writes the final state
+#endif
         if (stats) launch_sum_counters(sc.d_cand, static_cast<int>(lp.nwaves), sc.d_state, s);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(sc.h_state, sc.d_state, sizeof(IcpState), hipMemcpyDeviceToHost, s));

@@ -1990,6 +1990,25 @@ void k_loop(LoopArgs A) {
         if (bad) return;
     }
 
+#ifdef SAGE_LOOP_INGRID
+    // Counter-collection twin (profiles/run_profiles.sh builds it as a variant library): rocprofv3 --pmc runs one
+    // kernel at a time, which the grid and its solving wave — two kernels that talk to each other — do not survive.
+    // Here the solving wave is one more workgroup of THIS grid (its path spills under the search's register budget:
+    // the twin is for bytes and instruction counts, not for time).
+    if (blockIdx.x == gridDim.x - 1u) {
+        if (threadIdx.x >= 64u) return;
+        SolveLds &m = *reinterpret_cast<SolveLds *>(smem);
+        const int lane = static_cast<int>(threadIdx.x & 63u);
+        if (lane < 14) m.T[lane] = lane < 7 ? L.T0[lane] : (lane == 10 ? 1.0 : 0.0);
+        __builtin_amdgcn_wave_barrier();
+        P2pParams X{};
+        X.nranks = 1;
+        unsigned long long xg = 0ull;
+        for (int it = 0;; ++it)
+            if (loop_finish_iteration(L, X, m, it, xg)) return;
+    }
+#endif
+
     // ---- the units (of QW queries) this workgroup owns for the whole call ----------------------------
     // Workgroup b is dispatched to XCD b % 8 (observed; speed only).  Striped: XCD x serves the stripes
     // x, x + 8, ... of kLoopStripe workgroups' worth of the spatially sorted frame (every XCD gets the
@@ -2008,10 +2027,10 @@ void k_loop(LoopArgs A) {
             lo = L.xcd_first[xcd];
             cnt = L.xcd_first[xcd + 1u] - lo;
             idx = jb;
-            nwg = gridDim.x >> 3;
+            nwg = static_cast<unsigned>(L.wgs) >> 3;
         } else {
             idx = ((jb / kLoopStripe) * 8u + xcd) * kLoopStripe + (jb % kLoopStripe);
-            nwg = gridDim.x;
+            nwg = static_cast<unsigned>(L.wgs);
         }
         const unsigned base = cnt / nwg, extra = cnt - base * nwg;      // `extra` workgroups serve base + 1 groups
         g0 = lo + idx * base + min(idx, extra);
@@ -2449,7 +2468,11 @@ void launch_loop(const IcpParams &p, const LoopParams &l, int lw, hipStream_t s)
     a.P = p;
     a.L = l;
     void *args[] = {&a};
+#ifdef SAGE_LOOP_INGRID
+    (void)hipLaunchKernel(loop_kernel(lw, p.filter != 0), dim3(l.wgs + 1), dim3(64 * l.nw), args, lds, s);
+#else
     (void)hipLaunchKernel(loop_kernel(lw, p.filter != 0), dim3(l.wgs), dim3(64 * l.nw), args, lds, s);
+#endif
 }
 void launch_loop_solve(const LoopParams &l, const P2pParams &x, hipStream_t s) {
     SolveArgs a;

@@ -303,3 +303,29 @@ def test_round3_entries_on_the_host_side(sage):
     p.prefetch(np.zeros((5, 4)))
     p.prefetch_cancel()                                    # nothing started yet: a no-op that must not hang
     assert L.sageicp_pipeline_prefetch_cancel(None) == sage.ERR_INVALID
+
+
+def test_roofline_frac_is_null_without_counters_of_this_build():
+    """bench.py: `roofline.frac` is what rocprofv3 measured on exactly this build and loop form, or null — never
+    a model under the same name"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    h = bench.device_source_hash()
+    entry = {"kernel": "k_loop", "source_sha256": h, "hbm_bytes_per_launch": 40_000_000, "avg_launch_us_kernel_trace": 32.0,
+             "counters_source": "profiles/rXX/c2-cold/pmc_*.csv.gz (test)", "l2_hit_rate": 0.5}
+
+    def fresh():
+        return {"achieved": None, "frac": None, "traffic": None, "counters_fresh": False, "frac_basis": "none"}
+
+    r = bench.apply_counters(fresh(), entry, h, True, 23.3e6, 127.7e6)
+    assert r["counters_fresh"] and r["traffic"] == 40_000_000
+    assert abs(r["achieved"] - 1250.0) < 1e-6 and abs(r["frac"] - 1250.0 / 8000.0) < 1e-4 and r["l2_hit_rate"] == 0.5
+    stale = bench.apply_counters(fresh(), dict(entry, source_sha256="0" * 64), h, True, 23.3e6, 127.7e6)
+    assert stale["frac"] is None and stale["achieved"] is None and stale["traffic"] is None and not stale["counters_fresh"]
+    assert "another build" in stale["frac_basis"]
+    other = bench.apply_counters(fresh(), entry, h, False, 23.3e6, 127.7e6)          # counters of k_loop, the run went through k_icp
+    assert other["frac"] is None and not other["counters_fresh"] and "k_loop" in other["frac_basis"]
+    assert bench.apply_counters(fresh(), None, h, True, 1.0, 1.0)["frac"] is None
