@@ -15,6 +15,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # 3-term squared norms (sage_oracle.cpp; default 2 = Eigen 3.4's reductions, derived per call site);
 # the product's loader follows the same variable
 SQNORM3_ORDER = 0 if os.environ.get("SAGE_SQNORM3_ORDER", "2") == "0" else 2
+if os.environ.get("SAGE_SQNORM3_ORDER", "2") not in ("0", "2"):
+    import warnings
+    warnings.warn("SAGE_SQNORM3_ORDER=%r: only the builds 0 and 2 exist — using 2" % os.environ["SAGE_SQNORM3_ORDER"])
 _LIB_NAME = "libsage_oracle.v0.so" if SQNORM3_ORDER == 0 else "libsage_oracle.so"
 _LIB_PATH = os.path.join(_HERE, _LIB_NAME)
 

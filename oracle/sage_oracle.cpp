@@ -80,9 +80,11 @@
 //     a fixed-size-3 double expression WITH packet access (plain Vector3d, their difference, head<3>()
 //     of a Vector4d object) reduces as predux(packet(e0, e1)) + e2 = (x^2 + y^2) + z^2
 //       NN VoxelHashMap.cpp:87, RESID Registration.cpp:79, FAR VoxelHashMap.cpp:178, CROP Preprocessing.cpp:176;
-//     a Block of an EXPRESSION, (closest - point).head<3>(), has no packet access and goes through the
-//     scalar unroller, which splits 3 terms as 1 + 2: x^2 + (y^2 + z^2)
-//       ACCEPT VoxelHashMap.cpp:111;
+//     (closest - point).head<3>() (ACCEPT, VoxelHashMap.cpp:111) is a Block of an EXPRESSION: no direct access,
+//     inner stride unknown at compile time — but evaluator<Block> masks the packet bit with
+//     (InnerStrideAtCompileTime == 1 || HasSameStorageOrderAsArgType), and a column segment of a column
+//     expression has the same storage order: it keeps packet access and reduces like the others,
+//     (x^2 + y^2) + z^2 (round 4 had derived x^2 + (y^2 + z^2) here from the stride alone);
 //     the 6-vector of estimation.log().norm() (Registration.cpp:137) reduces as three packets
 //     p0 + (p1 + p2), then the two lanes: (e0 + (e2 + e4)) + (e1 + (e3 + e5)).
 //   0: x^2 + (y^2 + z^2) everywhere (the default of rounds 1-3), 1: (x^2 + y^2) + z^2 everywhere; both
@@ -108,7 +110,7 @@
 #define SAGE_SQNORM3_NN SAGE_SQNORM3_B
 #define SAGE_SQNORM3_RESID SAGE_SQNORM3_B
 #define SAGE_SQNORM3_FAR SAGE_SQNORM3_B
-#define SAGE_SQNORM3_ACCEPT SAGE_SQNORM3_A
+#define SAGE_SQNORM3_ACCEPT SAGE_SQNORM3_B
 #define SAGE_SQNORM3_CROP SAGE_SQNORM3_B
 #endif
 #if SAGE_SQNORM3_ORDER == 2

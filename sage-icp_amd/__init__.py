@@ -24,6 +24,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # squared norms (csrc/sageicp_types.h; default 2 = what Eigen 3.4's reductions evaluate, per call site):
 # libsageicp_hip.v0.so, built by build.py next to the default
 SQNORM3_ORDER = 0 if os.environ.get("SAGE_SQNORM3_ORDER", "2") == "0" else 2
+if os.environ.get("SAGE_SQNORM3_ORDER", "2") not in ("0", "2"):
+    import warnings
+    warnings.warn("SAGE_SQNORM3_ORDER=%r: only the builds 0 and 2 exist — using 2" % os.environ["SAGE_SQNORM3_ORDER"])
 LIB_PATH = os.path.join(_HERE, "libsageicp_hip.v0.so" if SQNORM3_ORDER == 0 else "libsageicp_hip.so")
 if os.environ.get("SAGEICP_VARIANT_LIB"):      # measurement only: a variant build of the same library (profiles/)
     LIB_PATH = os.path.abspath(os.environ["SAGEICP_VARIANT_LIB"])

@@ -2292,11 +2292,12 @@ int sageicp_map_add_points(sageicp_map *m, const double *xyzl, uint64_t n) {
     // point before it.
     {
         const double vs = m->host.voxel_size;
-        constexpr int32_t kLim = 1 << 20;
+        // (the range is tested on the quotient in double: casting a value beyond int32 is the undefined
+        // behaviour D5 refuses to rely on; truncation toward zero keeps |index| < 2^20 exactly when |q| < 2^20)
+        constexpr double kLim = 1048576.0;
         for (uint64_t i = 0; i < n; ++i) {
-            const int32_t vx = static_cast<int32_t>(xyzl[4 * i] / vs), vy = static_cast<int32_t>(xyzl[4 * i + 1] / vs),
-                          vz = static_cast<int32_t>(xyzl[4 * i + 2] / vs);
-            if (vx <= -kLim || vx >= kLim || vy <= -kLim || vy >= kLim || vz <= -kLim || vz >= kLim)
+            const double qx = xyzl[4 * i] / vs, qy = xyzl[4 * i + 1] / vs, qz = xyzl[4 * i + 2] / vs;
+            if (!(std::fabs(qx) < kLim && std::fabs(qy) < kLim && std::fabs(qz) < kLim))
                 return fail(SAGEICP_ERR_CAPACITY, "AddPoints: voxel index beyond +-2^20 at point " + std::to_string(i) +
                                                       "; nothing was inserted");
         }

@@ -21,9 +21,10 @@
 //       FAR    (pt - origin).squaredNorm()                   VoxelHashMap.cpp:178   (x^2 + y^2) + z^2
 //              — fixed-size-3 double expressions with packet access: linear vectorised reduction,
 //              predux(packet(e0, e1)) first, then + e2 (redux_impl<LinearVectorizedTraversal, CompleteUnrolling>);
-//       ACCEPT (closest - point).head<3>().norm()            VoxelHashMap.cpp:111   x^2 + (y^2 + z^2)
-//              — a Block of an expression has no packet access: scalar unrolled reduction, which splits
-//              3 terms as 1 + 2 (redux_novec_unroller: HalfLength = 3 / 2 = 1)
+//       ACCEPT (closest - point).head<3>().norm()            VoxelHashMap.cpp:111   (x^2 + y^2) + z^2
+//              — a Block of an expression: no direct access, but evaluator<Block> keeps the packet bit when
+//              the block has the storage order of its argument (a column segment of a column expression
+//              does), so it reduces like the others (round 4 had x^2 + (y^2 + z^2) here)
 //   0  x^2 + (y^2 + z^2) everywhere (the default of rounds 1-3)      1  (x^2 + y^2) + z^2 everywhere
 // build.py's build_sqnorm3_variant() builds order 0 as libsageicp_hip.v0.so; SAGE_SQNORM3_ORDER=0 in the
 // environment makes the loader and the test-suite use it against the checker built the same way.
@@ -48,7 +49,7 @@
 #define SAGE_SQNORM3_NN SAGE_SQNORM3_B
 #define SAGE_SQNORM3_RESID SAGE_SQNORM3_B
 #define SAGE_SQNORM3_FAR SAGE_SQNORM3_B
-#define SAGE_SQNORM3_ACCEPT SAGE_SQNORM3_A
+#define SAGE_SQNORM3_ACCEPT SAGE_SQNORM3_B
 #define SAGE_SQNORM3_CROP SAGE_SQNORM3_B
 #endif
 // point.head<3>().norm() of the range crop (Preprocessing.cpp:176): CROP, packet access -> (x^2 + y^2) + z^2.

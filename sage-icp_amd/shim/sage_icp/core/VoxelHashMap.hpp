@@ -40,6 +40,21 @@ struct VoxelHashMap {
                                   critical_points_per_voxel_, basic_parts_labels_.data(),
                                   static_cast<int>(basic_parts_labels_.size()), Device())) {
         if (!map_) throw std::runtime_error(std::string("sageicp_map_create: ") + sageicp_last_error());
+#ifndef SAGE_ICP_SHIM_FAST_MAP
+        // The drop-in node keeps the voxels the reference keeps: RemovePointsFarFromLocation erases while it
+        // iterates its robin_map (VoxelHashMap.cpp:176-184), so the entry a deletion shifts into the bucket just
+        // erased survives until a later frame, and Pointcloud() lists bucket order (:132-142).  A map in
+        // reference-order mode reproduces both exactly (include/sageicp.h, sageicp_map_set_reference_order) at
+        // ~3 ms of host work per streamed frame; -DSAGE_ICP_SHIM_FAST_MAP keeps the map on the GPU instead
+        // (0.3 ms; every out-of-range voxel is removed at once, block-pool order) — poses are the same on every
+        // stream measured.
+        if (sageicp_map_set_reference_order(map_, 1) != 0) {
+            const std::string why = sageicp_last_error();
+            sageicp_map_destroy(map_);
+            map_ = nullptr;
+            throw std::runtime_error("sageicp_map_set_reference_order: " + why);
+        }
+#endif
     }
 
     VoxelHashMap(const VoxelHashMap &o)
