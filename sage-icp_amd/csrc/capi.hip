@@ -1492,6 +1492,11 @@ static bool plan_loop(const sageicp_map *m, uint64_t n, double sem_th, LoopPlan 
         const uint64_t few = 15 * cus;                 // (3,840 waves on 256 CUs: where round 4 measured it)
         if (lw < 3 && groups_at(3) <= few) lw = 3;
         if (lw == 3 && !sparse && groups_at(4) <= few) lw = 4;
+        // ... and fewer once the units outnumber the waves the machine holds (7 per SIMD less the residency margin):
+        // a second pass of some waves costs more than a longer chain in everybody's first — 60k queries against
+        // dense voxels: 24.5 us per iteration with four lanes, 26.0 with eight; 30k: 21.7 / 19.6 (profiles/r05)
+        const uint64_t resident_waves = 4ull * SAGE_LOOP_OCC * cus * 15 / 16;
+        while (lw > 2 && groups_at(lw) > resident_waves) --lw;
     }
     const bool dbg = env_int("SAGEICP_LOOP_DEBUG", 0) != 0;
     bool ok = !env_gpw && one_pass(lw, env_nw ? env_nw : 4, out);
