@@ -35,6 +35,7 @@ def timed(frame, m, p, K, **env):
 
 
 LWS = tuple(int(x) for x in os.environ.get("SWEEP_LW", "2,3,1,4").split(","))
+CONTIG = tuple(int(x) for x in os.environ.get("SWEEP_CONTIG", "0,1").split(","))
 NWS = tuple(int(x) for x in os.environ.get("SWEEP_NW", "0,4,8,7").split(","))
 
 
@@ -59,7 +60,7 @@ def main():
     print("  library default: %s, %d lanes %31s %8.3f ms/frame %4d it %6.2f us/it" % ("one launch" if st.single_launch else "launch per iteration", st.lanes_per_query, "", 1e3 * dt, st.iterations, 1e6 * dt / max(1, st.iterations)), flush=True)
     for lw in LWS:
         for nw in NWS:
-            for contig in (0, 1):
+            for contig in CONTIG:
                 for gpw in ((0,) if nw else (0,)):
                     env = dict(SAGEICP_LOOP=2, SAGEICP_LW=lw, SAGEICP_LOOP_CONTIGUOUS=contig)
                     if nw:

@@ -1625,7 +1625,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
             // (an XCD's workgroups must be able to hold its range)
             const uint64_t nwg = static_cast<uint64_t>(plan.wgs / 8);
             for (int x = 0; x < 8; ++x)
-                if ((L.xcd_first[x + 1] - L.xcd_first[x] + nwg - 1) / nwg > static_cast<uint64_t>(plan.gpw)) L.contiguous = 0;
+                if (L.contiguous == 1 && (L.xcd_first[x + 1] - L.xcd_first[x] + nwg - 1) / nwg > static_cast<uint64_t>(plan.gpw)) L.contiguous = 0;
         }
         // a wait inside the launch normally takes microseconds; 50 ms of it means the grid is not
         // resident as a whole (SAGEICP_LOOP_TIMEOUT_MS overrides, e.g. under a debugger)

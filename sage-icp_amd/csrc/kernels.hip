@@ -465,12 +465,15 @@ __device__ __forceinline__ void wgacc_flush(unsigned long long *wgacc, long long
 // copy per LANE in 22 registers: the search now compiles at k_icp's budget (7 waves per SIMD) and a
 // wave is no longer tied to one group — the waves of a workgroup take its groups from an LDS counter.
 struct LoopGroup {
-    uint32_t *rows;            // LDS [QW][kRowLdsStride]
-    uint32_t *state;           // LDS [QW][kLoopStateWords]
+    uint32_t *rows;            // LDS: the rows of ALL the workgroup's queries, [slot][kRowLdsStride]
+    uint32_t *state;           // LDS: ... and their state records, [slot][kLoopStateWords]
+    const uint32_t *perm;      // LDS: the workgroup's blocks of four queries in the order of this iteration (heaviest first)
+    uint32_t *work;            // LDS: per block, the most points one of its queries was handed this iteration
+    unsigned unit;             // which (64 >> LW) / 4 blocks of `perm` this pass takes
     double *red;               // LDS: the running wave's scratch for the epilogue's transposed block sums
     unsigned long long *wgacc; // LDS: the workgroup's fixed-point accumulators (wave_terms_to_wgacc)
-    unsigned q_first;          // the group's first query (a multiple of four)
-    unsigned slot;             // its slot in the per-wave counters (IcpParams::counters)
+    unsigned q_first;          // the workgroup's first query (slot 0; a multiple of four)
+    unsigned slot;             // this pass's slot in the per-wave counters (IcpParams::counters)
 #ifdef SAGE_LOOP_TIMING
     unsigned long long ph[8], tprev;           // probe builds: cycles per phase of the body, summed over the iterations
 #endif
@@ -496,6 +499,7 @@ __host__ __device__ constexpr unsigned loop_group_words(int lw) {
     return static_cast<unsigned>((kRowLdsStride + kLoopStateWords) * (64 >> lw));
 }
 __host__ __device__ constexpr unsigned loop_red_words() { return 2u * kCount * 4u; }    // 16 fp64 for each of four blocks of queries
+__host__ __device__ constexpr unsigned loop_perm_words(unsigned nblk) { return 2u * ((nblk + 7u) & ~7u); }   // perm | work, 32-B aligned
 
 // PERSIST (k_loop): the body runs on group `G` — rows and per-query state in LDS — with the pose from
 // `pose` (LDS: R[9], t[3]); nothing is read from or written to the global rows / nn_prev arrays;
@@ -599,12 +603,21 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
 
     const int qw = lane >> LW;                 // this lane's query within the wave
     const unsigned ci = static_cast<unsigned>(lane) & (W - 1u);
-    unsigned q;
-    if constexpr (PERSIST) q = G->q_first + static_cast<unsigned>(qw);
-    else q = wave_id * QW + static_cast<unsigned>(qw);
+    // k_loop: a pass takes QW / 4 BLOCKS of four consecutive queries — not necessarily neighbours: the workgroup's
+    // blocks are re-ordered every iteration by the work they were (a wave's pass lasts as long as its heaviest
+    // query: blocks of like work share a wave).  The four queries of a block stay together, in order, on one
+    // aligned group of lanes, which is all the exact block sums ask for (wave_terms_to_wgacc).
+    unsigned q, qslot = 0u, bslot = 0u;
+    if constexpr (PERSIST) {
+        bslot = G->perm[G->unit * (QW / 4) + static_cast<unsigned>(qw >> 2)];
+        qslot = bslot * 4u + (static_cast<unsigned>(qw) & 3u);
+        q = G->q_first + qslot;
+    } else {
+        q = wave_id * QW + static_cast<unsigned>(qw);
+    }
     const bool valid = q < static_cast<unsigned>(P.n);
     const unsigned qc = valid ? q : 0u;        // keeps the loads of idle lanes legal
-    uint32_t *lrow = wl + qw * kRowLdsStride;
+    uint32_t *lrow = wl + (PERSIST ? qslot : static_cast<unsigned>(qw)) * kRowLdsStride;
     const uint32_t *grow = P.rows + static_cast<size_t>(qc) * kRowWords;
 
     // raw buffer resource over the point array (bounds-checked, 32-bit byte offsets)
@@ -628,7 +641,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
     uint32_t *lst = nullptr;                   // k_loop: this query's state record (LDS)
     if constexpr (PERSIST) {
         // k_loop: everything is already here, in LDS — the state record and the row
-        lst = G->state + qw * kLoopStateWords;
+        lst = G->state + qslot * kLoopStateWords;
         const uint4 fa = *reinterpret_cast<const uint4 *>(lst), fb = *reinterpret_cast<const uint4 *>(lst + 4);
         const uint4 pk = *reinterpret_cast<const uint4 *>(lst + kStPrev);
         const uint2 ko = *reinterpret_cast<const uint2 *>(lst + kStPrev + 4);
@@ -906,7 +919,9 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
     };
     auto passes = [&](const uint4 &c, bool on) {
         const float dx = __uint_as_float(c.x) - qx, dy = __uint_as_float(c.y) - qy, dz = __uint_as_float(c.z) - qz;
-        const float d = SAGE_SQNORM3_NN(dx * dx, dy * dy, dz * dz);   // (any association: the filter's bound covers it)
+        // (any association, and fused: the filter's bound assumes four roundings of relative size u — two fused
+        // multiply-adds round twice; the library is built with -ffp-contract=off for the fp64 comparisons that decide)
+        const float d = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
         const float lab = __uint_as_float(c.w);
         const bool same = (lab == plab) | (lab == 0.0f) | q_zero;
         return on & !(d > (same ? Ts : Td));
@@ -1174,6 +1189,12 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
     LP_T(3);
     scan((merged ? (need | (1u << kHome)) : (need & ~(1u << kHome))) & occ, nullptr, false, 0u);
     LP_T(4);
+    if constexpr (PERSIST) {
+        // what this block cost: the most points one of its queries was handed (a rebuilt row counts as a few more) —
+        // next iteration's order of the workgroup's blocks (k_loop)
+        if (valid && ci == 0u)
+            (void)__hip_atomic_fetch_max(G->work + bslot, npairs + (stale ? 48u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
 
     // argmin over the W lanes of the query: first the minimum distance (never NaN: a NaN distance
     // fails every comparison), then the smallest key among the lanes that hold it; the winner's
@@ -2023,7 +2044,7 @@ void k_loop(LoopArgs A) {
         const unsigned xcd = blockIdx.x & 7u, jb = blockIdx.x >> 3;
         const unsigned ngroups = (static_cast<unsigned>(P.n) + QW - 1u) / QW;
         unsigned lo = 0u, cnt = ngroups, idx, nwg;
-        if (L.contiguous) {
+        if (L.contiguous == 1) {
             lo = L.xcd_first[xcd];
             cnt = L.xcd_first[xcd + 1u] - lo;
             idx = jb;
@@ -2037,8 +2058,15 @@ void k_loop(LoopArgs A) {
         gcnt = min(gpw, base + (idx < extra ? 1u : 0u));
     }
     unsigned long long *wgacc = reinterpret_cast<unsigned long long *>(smem + kLpAcc);
-    uint32_t *groups = smem + kLpHeaderWords;
-    double *red = reinterpret_cast<double *>(groups + gpw * loop_group_words(LW) + static_cast<unsigned>(wv) * loop_red_words());
+    // LDS after the header: perm[gpw * QW / 4] | work[gpw * QW / 4] | rows of the workgroup's queries | their state
+    // records | one scratch for the transposed block sums per wave
+    constexpr unsigned BPW = QW / 4;                                  // blocks of four queries per pass
+    const unsigned nblk_max = gpw * BPW, nblk = gcnt * BPW;
+    uint32_t *perm = smem + kLpHeaderWords;
+    uint32_t *work = perm + loop_perm_words(nblk_max) / 2u;
+    uint32_t *rows = perm + loop_perm_words(nblk_max);
+    uint32_t *state = rows + gpw * QW * kRowLdsStride;
+    double *red = reinterpret_cast<double *>(state + gpw * QW * kLoopStateWords + static_cast<unsigned>(wv) * loop_red_words());
 
     // ---- set-up: the initial pose, the state records of the groups' queries --------------------------
     if (threadIdx.x < 9) s_pose[threadIdx.x] = P.st->R[threadIdx.x];
@@ -2052,13 +2080,15 @@ void k_loop(LoopArgs A) {
 #endif
     }
     for (unsigned i = threadIdx.x; i < 2u * kWgAccWords; i += blockDim.x) smem[kLpAcc + i] = 0u;
-    for (unsigned gi = static_cast<unsigned>(wv); gi < gcnt; gi += static_cast<unsigned>(nw)) {
-        // (a unit's LDS: the rows of its QW queries, then their state records)
-        const unsigned lane = threadIdx.x & 63u;
-        const unsigned q = (g0 + gi) * QW + lane;
+    for (unsigned i = threadIdx.x; i < nblk_max; i += blockDim.x) {
+        perm[i] = i;                           // the order of the frame, until the blocks' work is known
+        work[i] = 0u;
+    }
+    for (unsigned sl = threadIdx.x; sl < gcnt * QW; sl += blockDim.x) {
+        const unsigned q = g0 * QW + sl;       // slot sl of this workgroup
         const Point4 f = P.frame[q < static_cast<unsigned>(P.n) ? q : 0u];
-        if (lane < static_cast<unsigned>(QW)) {
-            uint32_t *lst = groups + gi * loop_group_words(LW) + kRowLdsStride * QW + lane * kLoopStateWords;
+        {
+            uint32_t *lst = state + sl * kLoopStateWords;
             *reinterpret_cast<Point4 *>(lst) = f;
             Point4 z;
             z.x = z.y = z.z = z.l = 0.0;
@@ -2095,11 +2125,14 @@ void k_loop(LoopArgs A) {
             gi = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(gi)));
             if (gi >= gcnt) break;
             LoopGroup G;
-            G.rows = groups + gi * loop_group_words(LW);
-            G.state = G.rows + kRowLdsStride * QW;
+            G.rows = rows;
+            G.state = state;
+            G.perm = perm;
+            G.work = work;
+            G.unit = gi;
             G.red = red;
             G.wgacc = wgacc;
-            G.q_first = (g0 + gi) * QW;
+            G.q_first = g0 * QW;
             G.slot = g0 + gi;
 #ifdef SAGE_LOOP_TIMING
             for (int i = 0; i < 8; ++i) G.ph[i] = 0;
@@ -2132,6 +2165,25 @@ void k_loop(LoopArgs A) {
             if (lane == 0) {                   // everybody is in: ready for the next iteration
                 smem[kLpArrive] = 0u;
                 smem[kLpNext] = 0u;
+            }
+            // The next iteration's order of the workgroup's blocks: heaviest first, by what they cost in this one (a
+            // rank sort on one wave: lane i counts the blocks that go before block i).  Blocks of like work then
+            // share a wave — whose pass lasts as long as its heaviest query — and the heaviest waves start first.
+            // (Which blocks share a wave does not reach the sums: they are exact from the block on.)
+            if (nblk <= 64u && nblk > BPW) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const unsigned i = static_cast<unsigned>(lane);
+                const unsigned wi = i < nblk ? work[i] : 0u;
+                unsigned rank = 0u;
+                for (unsigned j = 0; j < nblk; ++j) {
+                    const unsigned wj = work[j];
+                    rank += (wj > wi || (wj == wi && j < i)) ? 1u : 0u;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (i < nblk) {
+                    perm[rank] = i;
+                    work[i] = 0u;
+                }
             }
 #ifdef SAGE_LOOP_TIMING
             if (lane == 0 && it < kLoopTimedIters && blockIdx.x < kLoopTimedWgs) {
@@ -2437,8 +2489,8 @@ void launch_icp(const IcpParams &p, int lw, bool fused, hipStream_t s) {
 }
 
 size_t loop_lds_bytes(int lw, int nw, int gpw) {
-    return sizeof(uint32_t) * (kLpHeaderWords + static_cast<size_t>(gpw) * loop_group_words(lw) +
-                               static_cast<size_t>(nw) * loop_red_words());
+    return sizeof(uint32_t) * (kLpHeaderWords + loop_perm_words(static_cast<unsigned>(gpw) * ((64u >> lw) / 4u)) +
+                               static_cast<size_t>(gpw) * loop_group_words(lw) + static_cast<size_t>(nw) * loop_red_words());
 }
 // the kernel of a shape, as an untyped pointer (what the occupancy query and the launch take)
 static const void *loop_kernel(int lw, bool filter) {
