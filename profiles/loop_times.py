@@ -23,7 +23,7 @@ os.environ["SAGEICP_LOOP"] = "2"
 for _ in range(3):
     pose, st = sage.register_frame(f, w["map"], sage.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"], return_stats=True)
 assert st.single_launch == 1
-IT, WG = 32, 1024
+IT, WG = 32, 2048
 wg = np.zeros((IT, WG, 2), dtype=np.uint64)
 sv = np.zeros((IT, 4), dtype=np.uint64)
 sage.lib().sageicp_debug_loop_times(wg.ctypes.data_as(C.c_void_p), sv.ctypes.data_as(C.c_void_p))
@@ -72,6 +72,11 @@ if hasattr(sage.lib(), "sageicp_debug_loop_info"):
               + " | points " + " ".join("%.0f" % sm[xcc == x].sum() for x in range(8) if (xcc == x).any()))
         order = np.argsort(-dur)[:8]
         print("   slowest: " + "; ".join("%.1f us (xcd %d se %d cu %d, max %d pts, %d stale, %d pts)" % (dur[o], xcc[o], se[o], cu[o], mx[o], stl[o], sm[o]) for o in order))
+        cukey = (xcc.astype(np.int64) << 16) | (se.astype(np.int64) << 8) | cu.astype(np.int64)
+        keys, inv, pop = np.unique(cukey, return_inverse=True, return_counts=True)
+        print("   %d CUs hold the %d workgroups: " % (len(keys), used.sum()) + "; ".join(
+            "%d CUs with %d workgroups: search time mean %.2f, last %.2f" % ((pop == k).sum(), k, dur[pop[inv] == k].mean(), dur[pop[inv] == k].max())
+            for k in sorted(set(pop))))
         for lo_, hi_ in ((0, 0), (1, 1), (2, 3), (4, 7), (8, 15), (16, 10 ** 6)):
             sel = (stl >= lo_) & (stl <= hi_)
             if sel.any():
