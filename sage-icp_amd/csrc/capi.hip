@@ -1356,6 +1356,7 @@ IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, 
     ip.check_done = 0;
     ip.apply_pose = 0;
     ip.voxel_size = m->host.voxel_size;
+    ip.inv_voxel_size = env_int("SAGEICP_EXACT_DIVIDE", 0) ? 0.0 : 1.0 / m->host.voxel_size;
     ip.rows = sc.d_rows;
     ip.table = m->d_table;
     ip.mask = static_cast<uint32_t>(m->d_table_cap - 1);
@@ -1609,6 +1610,20 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
             xp.timeout_ticks = static_cast<unsigned long long>(ticks);
     }
     LoopParams L{};
+    // The solving wave is launched well before its grid; should this call leave in between (an allocation or a launch
+    // failing), it must not sit there waiting for a grid that never comes (and write its abort into the state of a
+    // later call): the guard sends it home with the word the grid would have sent for a frame it refuses.
+    struct SolverGuard {
+        Scratch *sc = nullptr;
+        unsigned long long epoch = 0;
+        ~SolverGuard() {
+            if (!sc) return;
+            const unsigned long long word = epoch | 0x8000000000000000ull;
+            (void)hipMemcpyAsync(&sc->d_loop->go[0], &word, sizeof(word), hipMemcpyHostToDevice, sc->stream);
+            (void)hipStreamSynchronize(sc->stream);
+            (void)hipStreamSynchronize(sc->stream2);
+        }
+    } solver_guard;
     if (use_loop && (rc = sc.loop_streams())) return rc;
     if (use_loop) {
         // ---- the whole loop in one launch (kernels.hip, k_loop): first its solving wave, on its own stream —
@@ -1640,6 +1655,8 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
 #ifndef SAGE_LOOP_INGRID          // (the counter-collection twin keeps the solving wave inside the grid: kernels.hip)
         launch_loop_solve(L, xp, sc.stream2);
         HIPCHK(hipGetLastError());
+        solver_guard.sc = &sc;
+        solver_guard.epoch = L.epoch;
         HIPCHK(hipEventRecord(sc.ev_solve, sc.stream2));
 #endif
     }
@@ -1668,6 +1685,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         HIPCHK(hipMemsetAsync(sc.d_loop, 0, sizeof(LoopShared), s));
         if (prof) HIPCHK(hipEventRecord(sc.events[1], s));
         launch_loop(lp, L, plan.lw, s);
+        if (hipPeekAtLastError() == hipSuccess) solver_guard.sc = nullptr;      // the grid is on its way: it will say go
         if (prof) HIPCHK(hipEventRecord(sc.events[2], s));
 #ifndef SAGE_LOOP_INGRID
         HIPCHK(hipStreamWaitEvent(s, sc.ev_solve, 0));             // the solving wave writes the final state

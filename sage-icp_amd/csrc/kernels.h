@@ -28,6 +28,7 @@ struct IcpParams {
     int check_done;           // 1 inside the ICP loop: later launches of a finished loop are no-ops
     int apply_pose;
     double voxel_size;
+    double inv_voxel_size;    // fl(1 / voxel_size): the fast path of the voxel index (kernels.hip, voxel_index); 0: always divide
     uint32_t *rows;           // [n][kRowWords] cached neighbourhood rows
     const Slot *table;        // the open-addressed voxel hash; a slot word — and a row word — is
                               // (first unit (4 points) of the voxel's region << 8) | count (host_map.hpp)

@@ -256,9 +256,20 @@ struct Query {
 // all hold the same point: lane a < 3 of a quad then divides axis a only (an fp64 divide is ~15
 // instructions) and the three voxel indices are handed round by quad broadcasts — the same
 // divisions, a third of them per lane.
+// The voxel index is trunc(fl(x / voxel_size)) — the reference's fp64 divide, to the bit.  An fp64 division is ~35
+// instructions; x * fl(1 / voxel_size) is one, and differs from the quotient by a few ulps at most: wherever it lies
+// farther than 1e-9 (1 + |q|) from an integer its truncation IS the quotient's, and only a wave that holds a lane
+// closer than that to a cell face (one pass in thousands) pays for the division (`inv_vs` = 0: always divide).
+__device__ __forceinline__ int voxel_index(double x, double voxel_size, double inv_vs) {
+    const double q = x * inv_vs;
+    const bool unsure = !(fabs(q - __builtin_rint(q)) > 1e-9 * (1.0 + fabs(q))) || inv_vs == 0.0;
+    int k = static_cast<int>(q);
+    if (__ballot(unsure)) k = static_cast<int>(x / voxel_size);
+    return k;
+}
 template <bool QUAD = false>
 __device__ __forceinline__ Query make_query(const Point4 &f, const double *R, const double *t, int apply_pose,
-                                            double voxel_size) {
+                                            double voxel_size, double inv_vs = 0.0) {
     Query q;
     q.x = f.x; q.y = f.y; q.z = f.z; q.l = f.l;
     if (apply_pose) {
@@ -269,14 +280,14 @@ __device__ __forceinline__ Query make_query(const Point4 &f, const double *R, co
     if constexpr (QUAD) {
         const unsigned a = threadIdx.x & 3u;
         const double num = a == 0u ? q.x : (a == 1u ? q.y : q.z);
-        const unsigned k = static_cast<unsigned>(static_cast<int>(num / voxel_size));
+        const unsigned k = static_cast<unsigned>(voxel_index(num, voxel_size, inv_vs));
         q.kx = static_cast<int>(dpp_u32<0x00>(k));       // quad_perm [0,0,0,0]
         q.ky = static_cast<int>(dpp_u32<0x55>(k));       // quad_perm [1,1,1,1]
         q.kz = static_cast<int>(dpp_u32<0xAA>(k));       // quad_perm [2,2,2,2]
     } else {
-        q.kx = static_cast<int>(q.x / voxel_size);
-        q.ky = static_cast<int>(q.y / voxel_size);
-        q.kz = static_cast<int>(q.z / voxel_size);
+        q.kx = voxel_index(q.x, voxel_size, inv_vs);
+        q.ky = voxel_index(q.y, voxel_size, inv_vs);
+        q.kz = voxel_index(q.z, voxel_size, inv_vs);
     }
     return q;
 }
@@ -676,8 +687,8 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
         __builtin_amdgcn_sched_barrier(0);
     }
 #endif
-    const Query s = PERSIST ? make_query<(W >= 4)>(f, pose, pose + 9, 1, P.voxel_size)
-                            : make_query<(W >= 4)>(f, P.st->R, P.st->T + 4, P.apply_pose, P.voxel_size);
+    const Query s = PERSIST ? make_query<(W >= 4)>(f, pose, pose + 9, 1, P.voxel_size, P.inv_voxel_size)
+                            : make_query<(W >= 4)>(f, P.st->R, P.st->T + 4, P.apply_pose, P.voxel_size, P.inv_voxel_size);
     const bool stale = valid && (static_cast<uint32_t>(s.kx) != rk.x || static_cast<uint32_t>(s.ky) != rk.y ||
                                  static_cast<uint32_t>(s.kz) != rk.z);
     unsigned occ = rk.w;
