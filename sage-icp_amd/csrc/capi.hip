@@ -1647,6 +1647,10 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         L.timeout_ticks = 100000ull * static_cast<unsigned long long>(std::max(1, env_int("SAGEICP_LOOP_TIMEOUT_MS", 50)));
         if (const int ticks = env_int("SAGEICP_LOOP_TIMEOUT_TICKS", 0))      // tests: provoke a timeout
             L.timeout_ticks = static_cast<unsigned long long>(ticks);
+        // (under a communicator the workgroups wait for a pose that waits for the peers' sums: their patience has
+        // to outlast the exchange's — a peer's first launches of a process can take a second)
+        if (comm && env_int("SAGEICP_LOOP_TIMEOUT_TICKS", 0) == 0)
+            L.timeout_ticks = std::max(L.timeout_ticks, xp.timeout_ticks + 100000000ull);
         L.max_iterations = max_it;
         L.epoch = ++sc.loop_epoch;
         for (int i = 0; i < 7; ++i) L.T0[i] = init[i];
