@@ -18,7 +18,8 @@
 // HBM-bound integer/byte work; per frame ~30-50k points: 32 B in, 32 B out, a 12-B sort record,
 // one 16-B probe and one 32-B block write per point — tens of microseconds, not milliseconds.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+
 #include <rocprim/rocprim.hpp>
 
 #include "map_update.h"

@@ -16,7 +16,9 @@
 // id), which is the insertion order the host pipeline used; the reference itself emits
 // tsl::robin_map bucket order (deviation D3).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
 
 #include "kernels.h"
 
@@ -146,7 +148,7 @@ void launch_vds_permute(const Point4 *in, const uint32_t *perm, uint32_t n, Poin
 size_t vds_sort_temp_bytes(int n) {
     size_t bytes = 0;
     uint32_t *k = nullptr;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k, k, k, k, n, 0, 4);
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, k, k, static_cast<unsigned>(n), 0, 4);
     return bytes;
 }
 
@@ -164,8 +166,8 @@ hipError_t voxel_downsample_device(const VdsParams &P, void *sort_temp, size_t s
     const int grid = (P.n + 255) / 256;
     hipLaunchKernelGGL(k_vds_insert, dim3(grid), dim3(256), 0, s, P);
     hipLaunchKernelGGL(k_vds_flag, dim3(grid), dim3(256), 0, s, P);
-    e = hipcub::DeviceRadixSort::SortPairs(sort_temp, sort_temp_bytes, P.sort_key, P.sort_key + P.n,
-                                           P.sort_val, P.sort_val + P.n, P.n, 0, 4, s);
+    e = rocprim::radix_sort_pairs(sort_temp, sort_temp_bytes, P.sort_key, P.sort_key + P.n, P.sort_val, P.sort_val + P.n,
+                                  static_cast<unsigned>(P.n), 0, 4, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_vds_count, dim3(grid), dim3(256), 0, s, P.sort_key + P.n, P.n, d_n_kept);
     hipLaunchKernelGGL(k_vds_gather, dim3(grid), dim3(256), 0, s, P.tmp, P.sort_val + P.n, d_n_kept, out,

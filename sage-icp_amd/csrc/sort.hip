@@ -13,7 +13,9 @@
 // A stable sort keeps the result — and therefore the fp64 summation order of the Gauss-Newton
 // sums — bit-reproducible from run to run.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
 
 #include "kernels.h"
 
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256) void k_gather(const Point4 *in, const uint32_t
 size_t sort_temp_bytes(int n) {
     size_t bytes = 0;
     uint32_t *k = nullptr;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k, k, k, k, n, 0, 30);
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, k, k, static_cast<unsigned>(n), 0, 30);
     return bytes;
 }
 
@@ -90,8 +92,8 @@ hipError_t sort_frame(const Point4 *d_in, Point4 *d_out, int n, IcpState *st, bo
     else
         hipLaunchKernelGGL(k_morton_keys<false>, dim3(grid), dim3(256), 0, s, d_in, n, st, stop_on_bad ? 1 : 0,
                            voxel_size, keys, vals);
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys + n, vals,
-                                                      vals + n, n, 0, 30, s);
+    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys + n, vals, vals + n,
+                                             static_cast<unsigned>(n), 0, 30, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), 0, s, d_in, vals + n, n, d_out);
     return hipGetLastError();
