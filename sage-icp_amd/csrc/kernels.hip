@@ -90,12 +90,15 @@ namespace sageicp {
 // ---------------------------------------------------------------------------- cross-lane helpers
 // DPP moves run on the VALU (no LDS traffic, no scalar instructions); the patterns used are
 // involutions (quad swaps, half-row and row mirrors), so each step is an exchange and every lane
-// of a segment ends with the segment's result.
+// of a segment ends with the segment's result.  (bound_ctrl with no `old` operand: a lane without a
+// source — only the row shifts of the block sums have such lanes, and nobody reads them — gets zero, and
+// the move is ONE instruction per dword; with old = the value itself the compiler first copied the value
+// into the destination: 4 instructions per fp64 exchange instead of 2, 64 of them in every pass's sums.)
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 constexpr int kDppXor1 = 0xB1;          // quad_perm [1,0,3,2]
@@ -130,7 +133,7 @@ SAGE_MIN_U32_DPP(min_u32_mirror, "row_mirror")
 template <int CTRL>
 __device__ __forceinline__ unsigned dpp_u32(unsigned v) {
     return static_cast<unsigned>(
-        __builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), CTRL, 0xF, 0xF, false));
+        __builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, 0xF, 0xF, true));
 }
 template <int W>
 __device__ __forceinline__ unsigned seg_or_u32(unsigned m) {   // over segments of W <= 16 lanes
@@ -376,8 +379,8 @@ constexpr double kDigitLimit = 70368744177664.0, kDigitLimitCounted = 1099511627
 template <int CTRL>
 __device__ __forceinline__ long long dpp_i64(long long v) {
     int lo = static_cast<int>(v), hi = static_cast<int>(v >> 32);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
     return (static_cast<long long>(hi) << 32) | static_cast<unsigned>(lo);
 }
 // lane i <- lane i + N (the lanes this is used on — the first lanes of queries — always have their partner
