@@ -267,7 +267,10 @@ __device__ __forceinline__ int voxel_index(double x, double voxel_size, double i
     const double q = x * inv_vs;
     const bool unsure = !(fabs(q - __builtin_rint(q)) > 1e-9 * (1.0 + fabs(q))) || inv_vs == 0.0;
     int k = static_cast<int>(q);
-    if (__ballot(unsure)) k = static_cast<int>(x / voxel_size);
+    if (__ballot(unsure)) {
+        asm volatile("" ::: "memory");         // (keeps this a branch: if-converted, the division ran in every pass)
+        k = static_cast<int>(x / voxel_size);
+    }
     return k;
 }
 template <bool QUAD = false>
@@ -1275,31 +1278,34 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
 #ifdef SAGE_NN_TIMING
         if (valid && ci == 0u && P.work) P.work[q] = npairs;
 #endif
+        // Branch-free: every lane computes the terms of "its" pair from operands that are zeroed unless it is the
+        // first lane of a query with an accepted answer (the products are then exact zeros of either sign, which
+        // the block sums and their digits do not tell apart) — clearing sixteen fp64 registers twice around two
+        // nested branches cost more than the selects.
         double t[kCount];
-#pragma unroll
-        for (int c = 0; c < kCount; ++c) t[c] = 0.0;
-        bool use = false;
-        if (found && ci == 0u) {
-            if constexpr (!PERSIST) g = load_point(pts, woff);
-            const double rx = s.x - g.x, ry = s.y - g.y, rz = s.z - g.z;
-            // (closest_neighboor - point).head<3>().norm() < max_correspondance_distance (VoxelHashMap.cpp:111)
-            use = SAGE_SQNORM3_ACCEPT(rx * rx, ry * ry, rz * rz) <= P.accept_r2;
+        const bool cand = found && ci == 0u;
+        if constexpr (!PERSIST) g = load_point(pts, cand ? woff : 0u);      // (the other lanes re-read record 0: no branch)
+        const double rx0 = s.x - g.x, ry0 = s.y - g.y, rz0 = s.z - g.z;
+        // (closest_neighboor - point).head<3>().norm() < max_correspondance_distance (VoxelHashMap.cpp:111)
+        const bool use = cand && SAGE_SQNORM3_ACCEPT(rx0 * rx0, ry0 * ry0, rz0 * rz0) <= P.accept_r2;
+        {
             // residual.squaredNorm() (Registration.cpp:79): its own reduction (sageicp_types.h)
-            const double r2 = SAGE_SQNORM3_RESID(rx * rx, ry * ry, rz * rz);
-            if (use) {
-                const double k = P.kernel;
-                const double den = k + r2;
-                const double w = (k * k) / (den * den);   // square(th) / square(th + residual2)
-                const double wsx = w * s.x, wsy = w * s.y, wsz = w * s.z;
-                t[kW] = w;
-                t[kWsx] = wsx; t[kWsy] = wsy; t[kWsz] = wsz;
-                t[kWxx] = wsx * s.x; t[kWxy] = wsx * s.y; t[kWxz] = wsx * s.z;
-                t[kWyy] = wsy * s.y; t[kWyz] = wsy * s.z; t[kWzz] = wsz * s.z;
-                t[kWrx] = w * rx; t[kWry] = w * ry; t[kWrz] = w * rz;
-                t[kWcx] = w * (s.y * rz - s.z * ry);
-                t[kWcy] = w * (s.z * rx - s.x * rz);
-                t[kWcz] = w * (s.x * ry - s.y * rx);
-            }
+            const double r2 = SAGE_SQNORM3_RESID(rx0 * rx0, ry0 * ry0, rz0 * rz0);
+            const double k = P.kernel;
+            const double den = k + r2;
+            const double wq = (k * k) / (den * den);   // square(th) / square(th + residual2)
+            const double w = use ? wq : 0.0;
+            const double sx = use ? s.x : 0.0, sy = use ? s.y : 0.0, sz = use ? s.z : 0.0;
+            const double rx = use ? rx0 : 0.0, ry = use ? ry0 : 0.0, rz = use ? rz0 : 0.0;
+            const double wsx = w * sx, wsy = w * sy, wsz = w * sz;
+            t[kW] = w;
+            t[kWsx] = wsx; t[kWsy] = wsy; t[kWsz] = wsz;
+            t[kWxx] = wsx * sx; t[kWxy] = wsx * sy; t[kWxz] = wsx * sz;
+            t[kWyy] = wsy * sy; t[kWyz] = wsy * sz; t[kWzz] = wsz * sz;
+            t[kWrx] = w * rx; t[kWry] = w * ry; t[kWrz] = w * rz;
+            t[kWcx] = w * (sy * rz - sz * ry);
+            t[kWcy] = w * (sz * rx - sx * rz);
+            t[kWcz] = w * (sx * ry - sy * rx);
         }
         const unsigned pairs = static_cast<unsigned>(__popcll(__ballot(use)));
         if constexpr (PERSIST) {
