@@ -422,6 +422,9 @@ def main():
     def timed():
         """EXACTLY args.steps steps between two fences; None if a step failed on this rank"""
         sage.set_profiling(0 if args.no_profile_events else 1)
+        # the per-wave counters behind sum_candidates / pairs_evaluated (the bytes models of the line) are
+        # instrumentation the C++ shim's calls never pay for: off in the timed region, one counted frame after it
+        sage.set_counting(False)
         fence()
         t0 = time.perf_counter()
         stats, pose, good = [], None, True
@@ -435,6 +438,7 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
         sage.set_profiling(0)
+        sage.set_counting(True)
         return (elapsed, stats, pose) if good else None
 
     res = timed()
@@ -459,6 +463,15 @@ def main():
     # Where an iteration of the sharded loop goes (not in the timed region: bracketing every kernel
     # costs stream time): one more frame on every rank with HIP events around each launch — the
     # search of this rank's shard, and the finish (reduction, exchange with the peers, solve).
+    # the same frame once more with the counters on: C_q and the pairs evaluated, per iteration (every rank:
+    # under a communicator the call is collective)
+    fence()
+    try:
+        _, counted = step()
+    except sage.SageIcpError as e:
+        raise SystemExit("the counted frame after the timed region failed: %s" % e)
+    fence()
+
     breakdown = None
     if use_dist and not args.independent:
         loop_env = os.environ.get("SAGEICP_LOOP")
@@ -515,14 +528,14 @@ def main():
     us_nn = sum(s.us_nn for s in stats)             # the timed sample of k_icp launches
     launches = sum(s.nn_launches for s in stats)
     all_launches = sum(s.iterations for s in stats)  # every k_icp launch of the timed region
-    cands = sum(s.sum_candidates for s in stats)     # sum of C_q over ALL launches (counted by the kernel)
-    pairs = sum(s.pairs_evaluated for s in stats)
+    cands = counted.sum_candidates                   # sum of C_q over the launches of the counted frame (by the kernel)
+    pairs = counted.pairs_evaluated
     roofline = None
     if launches:
         n_corr = 0.5 * (last.n_corr_first + last.n_corr_last) * n_local / max(len(scan), 1)
         avg_us = us_nn / launches
-        cand_per_launch = cands / all_launches
-        pairs_per_launch = pairs / all_launches
+        cand_per_launch = cands / max(counted.iterations, 1)
+        pairs_per_launch = pairs / max(counted.iterations, 1)
         # Bytes the EXECUTED algorithm needs per launch, in SURVEY 8d's compact representation
         # (fused form): 448 B per query (16 query + 27 x 16 hash slots) + 16 B per (query, map
         # point) pair the search actually evaluates — counted by the kernel; the exact cell lower
@@ -572,6 +585,8 @@ def main():
                                  if one_launch else "k_icp + k_fin per iteration",
                     "candidates_per_query": round(cand_per_launch / max(n_local, 1), 1),
                     "pairs_evaluated_frac": round(pairs / max(cands, 1), 4),
+                    "pair_counts": "the library's per-wave counters (C_q, pairs evaluated) are off in the timed region — "
+                                   "as for the C++ shim's calls, which pass no statistics — and on for one frame after it",
                     "timing": ("HIP events on the launch stream around the k_loop launch of every frame of the timed "
                                "region / its iterations") if one_launch else
                               ("mean k_icp duration from HIP events on the launch stream around 1 launch in 8 "
@@ -592,7 +607,7 @@ def main():
     fps = args.steps / elapsed * (world if args.independent else 1)
     cpu = parity = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu, parity = cpu_baseline(args, w, wl, prm, scan, iters, fps, pose, last)
+        cpu, parity = cpu_baseline(args, w, wl, prm, scan, iters, fps, pose, counted)
 
     err = None
     try:

@@ -92,6 +92,10 @@ const char *sageicp_last_error(void);
 int sageicp_device_count(void);               /* number of visible HIP devices (0: none) */
 void sageicp_set_profiling(int level);        /* 0 off; 1 HIP events around k_icp in one iteration
                                                * out of 8; 2 around every kernel of every iteration */
+void sageicp_set_counting(int on);            /* 1 (default): a call given a sageicp_stats counts C_q and the pairs it
+                                               * evaluates (sum_candidates, pairs_evaluated: ~3 % of the search);
+                                               * 0: those two fields stay zero, the others are filled as before.
+                                               * A call without stats (the C++ shim's) never counts. */
 
 /* ---- map: sage_icp::VoxelHashMap (core/VoxelHashMap.hpp:35-107) ------------------------ */
 /* ctor, VoxelHashMap.hpp:79-88.  device: HIP device ordinal that will hold the mirror. */

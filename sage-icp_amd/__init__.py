@@ -131,6 +131,7 @@ _SIGNATURES = [
     ("sageicp_last_error", C.c_char_p, []),
     ("sageicp_device_count", C.c_int, []),
     ("sageicp_set_profiling", None, [C.c_int]),
+    ("sageicp_set_counting", None, [C.c_int]),
     ("sageicp_set_downsample_order", None, [C.c_int]),
     ("sageicp_robin_iteration_order", C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
     ("sageicp_map_create", C.c_void_p,
@@ -245,6 +246,12 @@ def set_profiling(level):
     """0 off; 1 (or True) HIP events around k_icp in one iteration out of 8 (what bench.py times
     with); 2 around every kernel of every iteration"""
     lib().sageicp_set_profiling(int(level))
+
+
+def set_counting(on):
+    """True (default): calls that return statistics count candidates and evaluated pairs (sum_candidates,
+    pairs_evaluated); False: those two stay zero and the search runs as it does for a caller without statistics"""
+    lib().sageicp_set_counting(1 if on else 0)
 
 
 class Frame:

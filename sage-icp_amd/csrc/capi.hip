@@ -49,6 +49,7 @@ namespace sageicp {
 // ---- errors --------------------------------------------------------------------------
 static thread_local std::string g_err;
 static int g_profiling = 0;
+static int g_counting = 1;                // sageicp_set_counting: the per-wave candidate / pair counters behind sageicp_stats
 // VoxelDownsample emits its survivors in the reference's order (the bucket order of its
 // tsl::robin_map, replayed on the host: robin_order.hpp) unless switched to arrival order
 static int g_reference_order = 1;
@@ -1590,8 +1591,11 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     ip.apply_pose = 1;
     ip.kernel = kernel;
     ip.accept_r2 = accept_threshold(max_dist);
-    ip.counters = stats ? sc.d_cand : nullptr;
-    if (stats) HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * 2 * (std::max(ip.nwaves, loop_waves) + 1), s));
+    // (the counters behind sum_candidates / pairs_evaluated cost ~45 vector instructions per pass, a memset and a
+    // launch per frame: a caller that wants the other statistics only — bench.py's timed region — switches them off)
+    const bool counting = stats && g_counting != 0;
+    ip.counters = counting ? sc.d_cand : nullptr;
+    if (counting) HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * 2 * (std::max(ip.nwaves, loop_waves) + 1), s));
 
     // direct exchange of the sums with the peer GPUs (k_fin mode 3, or the solving wave of the one-launch loop)
     P2pParams xp{};
@@ -1694,7 +1698,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
 #ifndef SAGE_LOOP_INGRID
         HIPCHK(hipStreamWaitEvent(s, sc.ev_solve, 0));             // the solving wave writes the final state
 #endif
-        if (stats) launch_sum_counters(sc.d_cand, static_cast<int>(lp.nwaves), sc.d_state, s);
+        if (counting) launch_sum_counters(sc.d_cand, static_cast<int>(lp.nwaves), sc.d_state, s);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(sc.h_state, sc.d_state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -1721,7 +1725,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
                 sc.h_state->progress = sc.d_prog;
             }
             HIPCHK(hipMemcpyAsync(sc.d_state, sc.h_state, sizeof(IcpState), hipMemcpyHostToDevice, s));
-            if (stats) HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * 2 * (ip.nwaves + 1), s));
+            if (counting) HIPCHK(hipMemsetAsync(sc.d_cand, 0, sizeof(unsigned long long) * 2 * (ip.nwaves + 1), s));
             use_loop = false;
         } else {
             looped = true;
@@ -1811,7 +1815,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
                     break;     // everything ran and nothing flagged the end: read the state below
             }
         }
-        if (stats) launch_sum_counters(sc.d_cand, static_cast<int>(ip.nwaves), sc.d_state, s);
+        if (counting) launch_sum_counters(sc.d_cand, static_cast<int>(ip.nwaves), sc.d_state, s);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(sc.h_state, sc.d_state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -1825,7 +1829,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
             const int todo = std::min(chunk, kMaxIterations - launched);
             for (int k = 0; k < todo; ++k)
                 if ((rc = enqueue_iteration(k, launched + k))) return rc;
-            if (stats) launch_sum_counters(sc.d_cand, static_cast<int>(ip.nwaves), sc.d_state, s);
+            if (counting) launch_sum_counters(sc.d_cand, static_cast<int>(ip.nwaves), sc.d_state, s);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(sc.h_state, sc.d_state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
@@ -2092,6 +2096,7 @@ int sageicp_device_count(void) {
     return c;
 }
 void sageicp_set_profiling(int level) { g_profiling = level; }
+void sageicp_set_counting(int on) { g_counting = on ? 1 : 0; }
 void sageicp_set_downsample_order(int reference_order) { g_reference_order = reference_order ? 1 : 0; }
 int sageicp_robin_iteration_order(const int32_t *vox_xyz, uint64_t n, uint32_t *order_out) {
     if (n && (!vox_xyz || !order_out)) return fail(SAGEICP_ERR_INVALID, "null argument");

@@ -942,3 +942,26 @@ def test_sums_beyond_the_fixed_point_range_are_accumulated_at_a_coarser_scale(gp
     monkeypatch.setenv("SAGEICP_ACC_SHIFT", "1")
     ref, sr = gpu_sage.register_frame(frame, m, gpu_sage.IDENTITY, 6.0, 0.5, 0.4, return_stats=True)
     assert np.array_equal(pose, ref) and st.iterations == sr.iterations
+
+
+def test_counters_can_be_switched_off(gpu_sage, oracle):
+    """sageicp_set_counting(0): a call that returns statistics no longer counts candidates and pairs (what bench.py's
+    timed region does: the C++ shim's calls never count) — same pose to the bit, the other statistics unchanged"""
+    from sage_icp_amd import synthetic as syn
+    w = syn.make_workload("c2", lambda: gpu_sage.VoxelHashMap(syn.WORKLOADS["c2"]["voxel"], 100.0), scale=0.1)
+    p = syn.PARAMS["cold"]
+    for loop in (0, 2):
+        os.environ["SAGEICP_LOOP"] = str(loop)
+        try:
+            a, sa = gpu_sage.register_frame(w["scan"], w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"],
+                                            return_stats=True)
+            gpu_sage.set_counting(False)
+            b, sb = gpu_sage.register_frame(w["scan"], w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"],
+                                            return_stats=True)
+        finally:
+            gpu_sage.set_counting(True)
+            os.environ.pop("SAGEICP_LOOP", None)
+        assert np.array_equal(a, b)
+        assert sa.sum_candidates > 0 and sa.pairs_evaluated > 0
+        assert sb.sum_candidates == 0 and sb.pairs_evaluated == 0
+        assert (sa.iterations, sa.converged, sa.n_corr_first, sa.n_corr_last) == (sb.iterations, sb.converged, sb.n_corr_first, sb.n_corr_last)
