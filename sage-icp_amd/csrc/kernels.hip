@@ -2244,6 +2244,9 @@ void k_loop(LoopArgs A) {
                 // cache lines: a pass every ~0.3 us each leaves the L2 channel that serves them — and the
                 // accumulators the solving wave is reading — alone)
                 __builtin_amdgcn_s_sleep(SAGE_LOOP_POLL_SLEEP);
+                // (a big grid backs off twice as long: c2's 1,664 workgroups 30.7 -> 30.3 us per iteration, flat from there
+                // to six times as long; c1's 640 prefer the short one — same-box A/B, profiles/r05/poll_sleep.txt)
+                if (L.wgs > 1024) __builtin_amdgcn_s_sleep(SAGE_LOOP_POLL_SLEEP);
             }
             if (aborted) {
                 if (lane == 0) smem[kLpDone] = 2u;
