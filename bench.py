@@ -266,7 +266,7 @@ def main():
     local_dev = int(os.environ.get("SAGEICP_BENCH_DEVICE", local_rank))
     backend = os.environ.get("SAGEICP_BENCH_BACKEND", "nccl")
     if "SAGEICP_BENCH_DEVICE" in os.environ and world > 1:
-        # the ranks share ONE GPU: each runs on its own part of the CUs (CU-masked streams, capi.hip), so that the
+        # the ranks share ONE GPU: each runs on its own part of the CUs (CU-masked streams, capi_internal.h), so that the
         # persistent grids of their one-launch loops are resident side by side instead of waiting for each other
         os.environ.setdefault("SAGEICP_CU_SHARE", "%d/%d" % (rank, world))
     torch.cuda.set_device(local_dev)

@@ -10,8 +10,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["csrc/kernels.hip", "csrc/sort.hip", "csrc/preprocess.hip", "csrc/map_update.hip",
-           "csrc/capi.hip"]
-HEADERS = ["csrc/kernels.h", "csrc/sageicp_types.h", "csrc/se3_math.h", "csrc/host_map.hpp", "csrc/pipeline.hpp", "csrc/map_update.h", "csrc/metrics.hpp", "csrc/robin_order.hpp",
+           "csrc/capi_mirror.hip", "csrc/capi_run.hip", "csrc/capi.hip"]
+HEADERS = ["csrc/kernels.h", "csrc/sageicp_types.h", "csrc/se3_math.h", "csrc/host_map.hpp", "csrc/pipeline.hpp", "csrc/map_update.h", "csrc/metrics.hpp", "csrc/robin_order.hpp", "csrc/capi_internal.h",
            "../include/sageicp.h"]
 OUT = os.path.join(HERE, "libsageicp_hip.so")
 OBJ_DIR = os.path.join(HERE, "build")

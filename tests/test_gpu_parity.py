@@ -394,7 +394,7 @@ def test_register_frame_pose_parity_c2_scaled(gpu_sage, oracle, params, scan_for
 @pytest.mark.parametrize("lw,flat", [(0, 0), (1, 0), (1, 1), (2, 0), (2, 1), (3, 1), (4, 1)])
 def test_every_lanes_per_query_variant(gpu_sage, oracle, scan_form, lw, flat, monkeypatch):
     """k_icp is compiled for 1, 2, 4, 8 and 16 lanes per query and the library picks by frame size
-    and voxel density (capi.hip::icp_lw), so a given workload only ever reaches one or two of the
+    and voxel density (capi_internal.h::icp_lw), so a given workload only ever reaches one or two of the
     variants: each is forced in turn (SAGEICP_LW) in both scan forms and, with 2 and 4 lanes, in both orders
     the lanes take a query's points in (SAGEICP_FLAT; 8 and 16 lanes: always flat) — index-exact search, the
     same registration as the oracle's, the same exact candidate count."""
