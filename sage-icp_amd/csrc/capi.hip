@@ -14,9 +14,9 @@
 
 namespace sageicp {
 thread_local std::string g_err;
-int g_profiling = 0;
-int g_counting = 1;
-int g_reference_order = 1;
+std::atomic<int> g_profiling{0};
+std::atomic<int> g_counting{1};
+std::atomic<int> g_reference_order{1};
 }  // namespace sageicp
 
 

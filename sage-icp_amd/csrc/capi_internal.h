@@ -40,11 +40,12 @@ namespace sageicp {
 
 // ---- errors --------------------------------------------------------------------------
 extern thread_local std::string g_err;
-extern int g_profiling;
-extern int g_counting;                // sageicp_set_counting: the per-wave candidate / pair counters behind sageicp_stats
+// (switches set through the C ABI, read by every call: several host threads may be inside the library)
+extern std::atomic<int> g_profiling;
+extern std::atomic<int> g_counting;                // sageicp_set_counting: the per-wave candidate / pair counters behind sageicp_stats
 // VoxelDownsample emits its survivors in the reference's order (the bucket order of its
 // tsl::robin_map, replayed on the host: robin_order.hpp) unless switched to arrival order
-extern int g_reference_order;
+extern std::atomic<int> g_reference_order;
 
 // tuning knobs (defaults chosen by measurement on MI355X; the environment overrides are for
 // experiments only)

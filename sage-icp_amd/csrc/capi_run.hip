@@ -328,10 +328,8 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         use_loop = false;
     }
     const unsigned loop_waves = use_loop ? static_cast<unsigned>((n + (64u >> plan.lw) - 1) / (64u >> plan.lw)) : 0u;
-    const int blocks = n ? icp_blocks_for(static_cast<int>(n), lw) : 1;
     if ((rc = ensure_cand(m, wants_filter(m, n, sem_th)))) return rc;
     if ((rc = sc.reserve_sort(n))) return rc;
-    if ((rc = sc.reserve_partials(static_cast<size_t>(blocks)))) return rc;
     IcpParams ip = icp_params(m, sc.d_sorted, n, sem_th, lw);
     ip.check_done = 1;
     ip.apply_pose = 1;
@@ -769,10 +767,8 @@ int register_sharded(const sageicp_map *m, const double *h_frame, const Point4 *
             if (r) return r;
             Scratch &sc = mk->sc;
             if ((r = sc.reserve_frame(cnt))) return r;
-            const int lw = icp_lw(cnt, sparse_voxels(mk));
             if ((r = ensure_cand(mk, wants_filter(mk, cnt, sem_th)))) return r;
             if ((r = sc.reserve_sort(cnt))) return r;
-            if ((r = sc.reserve_partials(static_cast<size_t>(cnt ? icp_blocks_for(static_cast<int>(cnt), lw) : 1)))) return r;
             mine = sc.d_frame;
             if (cnt) {
                 if (h_frame)
