@@ -12,7 +12,7 @@ cases = []
 w1 = syn.make_workload("c1", lambda: sage.VoxelHashMap(0.8, 100.0))
 cases.append(("c1 cold", w1, w1["scan"], syn.PARAMS["cold"]))
 w2 = syn.make_workload("c2", lambda: sage.VoxelHashMap(1.0, 100.0))
-for div, prm in ((8, "cold"), (5, "steady"), (2, "cold")):
+for div, prm in ((8, "cold"), (5, "steady"), (2, "cold"), (1, "cold")):       # (1: the headline frame, two passes per workgroup)
     cases.append(("c2/%d %s" % (div, prm), w2, w2["scan"][: len(w2["scan"]) // div], syn.PARAMS[prm]))
 for name, w, scan, p in cases:
     f = sage.Frame(w["map"], scan)
