@@ -187,10 +187,11 @@ def cpu_baseline(args, w, wl, prm, scan, iters, fps, gpu_pose, gpu_stats):
     cpu_fps = 1.0 / (per_iter * iters)
     # parity of the headline workload itself: the oracle registers the whole frame once (every
     # iteration, to convergence) and is compared with what the timed region returned
-    if per_iter * iters > 60.0:     # c4: minutes of oracle time; tests/test_gpu_parity.py covers it scaled
-        skipped = {"skipped": "the oracle needs ~%.0f s for this frame; parity of this workload is "
-                              "checked in tests/test_gpu_parity.py" % (per_iter * iters)}
-        return _cpu_dict(locals(), None), skipped
+    if per_iter * iters > 60.0:
+        # c4: minutes of oracle time.  The oracle's full registration of exactly this frame was run once in the
+        # build container (tests/golden/make_c4_golden.py -> tests/golden/c4_full.npz: data only); the timed
+        # region's pose and counts are compared with that fixture instead.
+        return _cpu_dict(locals(), None), parity_from_fixture(args, w, scan, gpu_pose, gpu_stats, per_iter * iters)
     t = time.perf_counter()
     opose, ofull = om.register_frame(scan, oracle.IDENTITY, prm["max_dist"], prm["kernel"], prm["sem_th"],
                                      nthreads=threads)
@@ -212,6 +213,40 @@ def cpu_baseline(args, w, wl, prm, scan, iters, fps, gpu_pose, gpu_stats):
               "ok": bool(np.linalg.norm(e[:3]) < 1e-4 and np.linalg.norm(e[3:]) < 1e-4 and
                          gpu_stats.iterations == ofull.iterations)}
     return _cpu_dict(locals(), 1.0 / t_full), parity
+
+
+def parity_from_fixture(args, w, scan, gpu_pose, gpu_stats, oracle_seconds_estimate):
+    import numpy as np
+    import oracle
+    path = os.path.join(ROOT, "tests", "golden", "c4_full.npz")
+    params = args.params or "steady"
+    why = None
+    if args.workload != "c4" or args.scale != 1.0 or not os.path.exists(path):
+        why = "no committed fixture for this workload"
+    else:
+        g = np.load(path)
+        same = (params + "_pose" in g and [int(x) for x in g["map_size"]][0] == w["map"].size() and
+                np.array_equal(g["scan_checksum"], [float(np.sum(scan[:, :3])), float(np.sum(scan[:, 3]))]))
+        if not same:
+            why = "the committed fixture is not of this frame"
+    if why:
+        return {"skipped": "the oracle needs ~%.0f s for this frame and %s; parity of this workload is checked in "
+                           "tests/test_gpu_parity.py" % (oracle_seconds_estimate, why)}
+    iters, conv, nc_first, nc_last, sum_cq, _ = [int(x) for x in g[params + "_counts"]]
+    e = oracle.se3_log(oracle.se3_mul(oracle.se3_inv(g[params + "_pose"]), np.asarray(gpu_pose, dtype=np.float64)))
+    return {"against": "tests/golden/c4_full.npz: the oracle's full registration of this frame, run once in the build "
+                       "container (make_c4_golden.py; the oracle: CPU restatement of the reference path, parity unpinned "
+                       "by the reference, DESIGN.md section 5)",
+            "pose_delta_m": float("%.3e" % np.linalg.norm(e[:3])),
+            "pose_delta_rad": float("%.3e" % np.linalg.norm(e[3:])),
+            "tolerance": {"m": 1e-4, "rad": 1e-4},
+            "iterations": [int(gpu_stats.iterations), iters],
+            "iterations_equal": bool(gpu_stats.iterations == iters),
+            "n_corr_first_last": [[int(gpu_stats.n_corr_first), int(gpu_stats.n_corr_last)], [nc_first, nc_last]],
+            "n_corr_equal": bool(gpu_stats.n_corr_first == nc_first and gpu_stats.n_corr_last == nc_last),
+            "candidates_equal": bool(gpu_stats.sum_candidates == sum_cq),
+            "oracle_seconds": None,
+            "ok": bool(np.linalg.norm(e[:3]) < 1e-4 and np.linalg.norm(e[3:]) < 1e-4 and gpu_stats.iterations == iters)}
 
 
 def _cpu_dict(v, cpu_fps_full):

@@ -443,7 +443,7 @@ int sageicp_get_correspondences(const sageicp_map *m, const double *q, uint64_t 
                                 int64_t *query_idx_out) {
     if (!m || !n_out || (n && (!q || !src_out || !tgt_out)))
         return fail(SAGEICP_ERR_INVALID, "null argument");
-    if (n > kMaxQueries) return fail(SAGEICP_ERR_INVALID, "too many queries (2^26 max)");
+    if (n > kMaxQueries) return fail(SAGEICP_ERR_INVALID, "too many queries (2^26 - 4 max)");
     *n_out = 0;
     if (!all_finite(q, n))
         return fail(SAGEICP_ERR_INVALID, "GetCorrespondences: a coordinate or label of a query is not finite (NaN / Inf)");

@@ -503,7 +503,7 @@ struct Prep {
             std::vector<std::vector<double>> &out, bool download = true) {
         kept_levels[0] = kept_levels[1] = 0;
         us_order = 0;
-        if (n > kMaxQueries) return fail(SAGEICP_ERR_INVALID, "frame too large (2^26 points max)");
+        if (n > kMaxQueries) return fail(SAGEICP_ERR_INVALID, "frame too large (2^26 - 4 points max)");
         if (n_groups > 8) return fail(SAGEICP_ERR_INVALID, "at most 8 label groups");
         size_t nlabels = 0;
         for (int g = 0; g < n_groups; ++g) nlabels += static_cast<size_t>(gcounts[g]);

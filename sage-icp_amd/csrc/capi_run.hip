@@ -138,6 +138,13 @@ IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, 
     ip.nn_prev = sc.d_prev;
     ip.work = sc.d_work;
     ip.acc_scale = std::ldexp(1.0, -24 * std::max(g_acc_shift, std::min(2, std::max(0, env_int("SAGEICP_ACC_SHIFT", 0)))));
+    {
+        // k_fin adds the accumulator copies in 64-bit integers: blocks x limit < 2^62 (kernels.hip, kDigitLimitCounted)
+        const uint64_t blocks = std::max<uint64_t>(1, (n + 3) / 4);
+        int bits = 0;
+        while ((1ull << bits) < blocks) ++bits;              // ceil(log2(blocks)) <= 24
+        ip.digit_limit = std::ldexp(1.0, std::min(46, 62 - bits));
+    }
     ip.counters = nullptr;
     const uint64_t qw = 64u >> lw;
     ip.nwaves = static_cast<unsigned>((n + qw - 1) / qw);
@@ -287,7 +294,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
             sageicp_stats *stats, double us_upload, double t_begin) {
     Scratch &sc = m->sc;
     hipStream_t s = sc.stream;
-    if (n > kMaxQueries) return fail(SAGEICP_ERR_INVALID, "frame too large (2^26 points max)");
+    if (n > kMaxQueries) return fail(SAGEICP_ERR_INVALID, "frame too large (2^26 - 4 points max)");
     int rc;
     const bool prof = g_profiling != 0;
     const bool prof2 = g_profiling >= 2;
@@ -404,6 +411,8 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         for (int i = 0; i < 7; ++i) L.T0[i] = init[i];
         L.acc_unscale = 1.0 / ip.acc_scale;
         L.shared_loop = comm ? 1 : 0;
+        L.prio = std::min(3, std::max(0, env_int("SAGEICP_LOOP_PRIO", 3)));
+        L.deal = env_int("SAGEICP_LOOP_DEAL", 1) ? 1 : 0;
 #ifndef SAGE_LOOP_INGRID          // (the counter-collection twin keeps the solving wave inside the grid: kernels.hip)
         launch_loop_solve(L, xp, sc.stream2);
         HIPCHK(hipGetLastError());
@@ -591,7 +600,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     if (st.bad_input)
         return fail(SAGEICP_ERR_INVALID, "the frame holds a coordinate or label that is not finite (NaN / Inf)");
     if (st.acc_overflow && !comm && g_acc_shift < 2) {
-        // |sum over four queries| >= 2^46 (2^40 in the one-launch loop): georeferenced coordinates (UTM: ~3e6 m,
+        // |sum over four queries| >= 2^46 or 2^62 / blocks of the frame (2^40 in the one-launch loop): georeferenced coordinates (UTM: ~3e6 m,
         // 4 s^2 = 4e13; 10^7 m beyond) do that.  The reference has no such limit: the frame is registered again
         // with the sums accumulated at 2^-24, then 2^-48 of their value — the same exact integer arithmetic on
         // digits of weight 2^24, 2^-16, 2^-56 (what is dropped lies 2^80 below the limit either way).

@@ -63,6 +63,8 @@ struct IcpParams {
     uint32_t *work;           // instrumented builds only: [n] map points handed to each query
     long long *acc;           // out: the Gauss-Newton sums as fixed-point accumulators (see kAcc* below):
                               // every workgroup ADDS its 16 sums and its pair count with integer atomics
+    double digit_limit;       // k_icp + k_fin: the leading digit of one block of four queries stays below this — a power of two
+                              // chosen by the host so that the sum over ALL the frame's blocks stays inside 63 bits (icp_params)
     double acc_scale;         // a power of two (1 normally): the sums are accumulated as fixed-point numbers of
                               // sum x acc_scale — a frame whose sums leave the range (coordinates of 10^7 m) is
                               // registered again at 2^-24, 2^-48 (capi.hip); FinParams / LoopParams::acc_unscale undo it
@@ -149,7 +151,7 @@ constexpr int kLoopReplicas = 8;           // accumulator copies (workgroup b ad
 constexpr int kLoopPoseGranules = 25;      // R[9], t[3] as 24 x {tag, 32 bits} + {tag, done}
 struct LoopShared {
     long long acc[2][kLoopReplicas][kAccWords];         // as FinParams::acc, one set per iteration parity, every word
-                                                        // (digit << 8) | workgroups in it; word 63 of copy 0: overflow flag
+                                                        // (digit << 8) | workgroups in it; word 51: (workgroups whose sums overflowed << 8) | workgroups
     unsigned long long pose[32];                        // granules (tag << 32) | payload, tag = iteration + 1
     unsigned long long abort_word[16];                  // [0] != 0: a wait timed out somewhere — everybody leaves
     unsigned long long go[16];                          // [0]: the call's epoch, stored by k_loop's first workgroup when the
@@ -172,6 +174,10 @@ struct LoopParams {
     double acc_unscale;            // 1 / IcpParams::acc_scale
     int shared_loop;               // 1: under a communicator — an overflowing sum or a bad frame point does not end
                                    // this rank's loop on its own (the ranks must keep exchanging in step)
+    int prio;                      // wave priorities by the work of a wave's unit (kernels.hip, k_loop): 0 off | 1..3: on, the
+                                   // priority of a unit beyond one per wave
+    int deal;                      // 1: a wave's FIRST unit of an iteration is fixed by where the wave sits — unit (SIMD +
+                                   // the workgroup's slot on the CU) mod waves — instead of first come first served (k_loop)
 };
 struct LoopArgs {                  // k_loop's one argument: its passes re-read it from the kernel-argument segment
     IcpParams P;
@@ -191,7 +197,8 @@ void launch_loop(const IcpParams &p, const LoopParams &l, int lw, hipStream_t s)
 void launch_loop_solve(const LoopParams &l, const P2pParams &x, hipStream_t s);
 
 constexpr int kMaxPartials = 1 << 16;
-constexpr uint64_t kMaxQueries = (1ull << 26) - 1;
+// (2^24 - 1 blocks of four: the lower digits of a block are below 2^39 in magnitude, their sum over the frame inside 63 bits)
+constexpr uint64_t kMaxQueries = (1ull << 26) - 4;
 
 void launch_tf(Point4 *pts, int n, const IcpState *st, hipStream_t s);
 void launch_scatter_points(const uint32_t *idx, const Point4 *vals, uint32_t n, Point4 *pts,

@@ -374,10 +374,14 @@ __device__ __forceinline__ void to_digits(double v, double limit, long long &d0,
     d1 = __double_as_longlong(b + 6755399441055744.0) - 0x4338000000000000ll;
     d2 = __double_as_longlong(c2 + 6755399441055744.0) - 0x4338000000000000ll;
 }
-// |a| of one block stays below this: 2^46 for k_icp + k_fin (their 32 copies of the accumulators take the
-// blocks of a 16M-point frame), 2^40 for k_loop, whose words also carry a count in their low byte (coordinates
-// of 10^5 m: 4 x (10^5)^2 = 4 10^10 < 2^40 = 1.1 10^12; capi.hip checks the number of blocks per copy)
-constexpr double kDigitLimit = 70368744177664.0, kDigitLimitCounted = 1099511627776.0;
+// |a| of one block stays below a limit.  k_icp + k_fin: IcpParams::digit_limit — k_fin adds the 32 copies of the
+// accumulators in plain 64-bit integers, so what has to stay inside 63 bits is the sum over ALL the blocks of the
+// frame: the host passes 2^62 / blocks rounded down to a power of two, at most 2^46 (capi_run.hip, icp_params; a
+// frame of 500k points: 2^45 — coordinates of 3 10^6 m; ADVICE r05: a fixed 2^46 let a frame of 1M+ points at UTM
+// coordinates wrap silently).  k_loop: 2^40, its words also carry a count in their low byte (coordinates of 10^5 m:
+// 4 x (10^5)^2 = 4 10^10 < 2^40 = 1.1 10^12; plan_loop checks the number of blocks per copy).  The lower digits
+// are below 2^39 in magnitude: 2^24 - 1 blocks at most (kMaxQueries).
+constexpr double kDigitLimitCounted = 1099511627776.0;
 
 template <int CTRL>
 __device__ __forceinline__ long long dpp_i64(long long v) {
@@ -458,11 +462,16 @@ __device__ __forceinline__ void wgacc_flush(unsigned long long *wgacc, long long
     const bool ok = wgacc[kWgAccWords - 1] == 0ull;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (lane < static_cast<int>(kWgAccWords)) wgacc[lane] = 0ull;
-    if (lane < 3 * kAccValues) {
-        if constexpr (COUNTED) {
-            (void)__hip_atomic_fetch_add(dst + lane, ok ? x * 256 + 1 : 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!ok) (void)__hip_atomic_fetch_or(overflow, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
+    if constexpr (COUNTED) {
+        // (the overflow travels IN the counted words: word 3 kAccValues of the copy counts its workgroups like the
+        // others and carries, as its "digit", how many of them overflowed — whoever finds the counts complete has
+        // the flags of exactly those workgroups; a flag at another address could land after the counts)
+        (void)overflow;
+        if (lane <= 3 * kAccValues)
+            (void)__hip_atomic_fetch_add(dst + lane, lane == 3 * kAccValues ? (ok ? 1ll : 257ll) : (ok ? x * 256 + 1 : 1ll),
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (lane < 3 * kAccValues) {
+        {
             if (ok) (void)__hip_atomic_fetch_add(dst + lane, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else (void)__hip_atomic_fetch_or(overflow, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -510,7 +519,8 @@ constexpr unsigned kStPrev = 16, kStKey = 18;
 constexpr unsigned kLpArrive = 0, kLpNext = 1, kLpDone = 2;
 constexpr unsigned kLpPose = 4;                                    // 12 doubles, 16-B aligned
 constexpr unsigned kLpDbg = kLpPose + 24u;                         // probe builds: max points of a query | stale queries | points
-constexpr unsigned kLpAcc = kLpDbg + 4u;                           // kWgAccWords 64-bit words
+constexpr unsigned kLpFirst = kLpDbg + 4u;                         // per wave: the unit it takes first in every iteration (LoopParams::deal)
+constexpr unsigned kLpAcc = kLpFirst + 8u;                         // kWgAccWords 64-bit words
 constexpr unsigned kLpHeaderWords = (kLpAcc + 2u * kWgAccWords + 15u) & ~15u;
 __host__ __device__ constexpr unsigned loop_group_words(int lw) {
     return static_cast<unsigned>((kRowLdsStride + kLoopStateWords) * (64 >> lw));
@@ -746,10 +756,12 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
                                        s.kz + v % 3 - 1));
             };
             if constexpr (kShift) {
-                const int dx = s.kx - static_cast<int>(rk.x), dy = s.ky - static_cast<int>(rk.y),
-                          dz = s.kz - static_cast<int>(rk.z);
-                const bool nearv = static_cast<unsigned>(dx + 1) <= 2u && static_cast<unsigned>(dy + 1) <= 2u &&
-                                   static_cast<unsigned>(dz + 1) <= 2u;
+                // (unsigned differences: a row not built yet carries kNoVoxel = 0x7FFFFFFF, and a signed difference from
+                // a negative index would overflow)
+                const unsigned dxu = static_cast<unsigned>(s.kx) - rk.x, dyu = static_cast<unsigned>(s.ky) - rk.y,
+                               dzu = static_cast<unsigned>(s.kz) - rk.z;
+                const bool nearv = dxu + 1u <= 2u && dyu + 1u <= 2u && dzu + 1u <= 2u;
+                const int dx = static_cast<int>(dxu), dy = static_cast<int>(dyu), dz = static_cast<int>(dzu);
                 // the old words of this lane's voxels (LDS is in order within a wave: every read here
                 // precedes the writes below, also those of the query's other lanes)
                 uint32_t ow[NV];
@@ -757,10 +769,10 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
 #pragma unroll
                 for (int j = 0; j < NV; ++j) {
                     const int v = static_cast<int>(ci) + W * j;
-                    const int a = v / 9 + dx, b = (v / 3) % 3 + dy, c = v % 3 + dz;
-                    reuse[j] = nearv && v < 27 && static_cast<unsigned>(a) <= 2u && static_cast<unsigned>(b) <= 2u &&
-                               static_cast<unsigned>(c) <= 2u;
-                    ow[j] = lrow[reuse[j] ? a * 9 + b * 3 + c : 0];
+                    const unsigned a = static_cast<unsigned>(v / 9) + dxu, b = static_cast<unsigned>((v / 3) % 3) + dyu,
+                                   c = static_cast<unsigned>(v % 3) + dzu;
+                    reuse[j] = nearv && v < 27 && a <= 2u && b <= 2u && c <= 2u;
+                    ow[j] = lrow[reuse[j] ? a * 9u + b * 3u + c : 0u];
                 }
                 uint32_t sl[NV];
                 int4 e[NV];
@@ -1335,7 +1347,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
             // (what the ticket orders lives in LDS, which serves a CU's waves in order: the ticket is a
             // relaxed LDS atomic between compiler barriers)
             unsigned long long *wgacc = reinterpret_cast<unsigned long long *>(smem + kWgAcc);
-            wave_terms_to_wgacc<LW>(t, pairs, lane, reinterpret_cast<double *>(wl), wgacc, kDigitLimit, P.acc_scale);
+            wave_terms_to_wgacc<LW>(t, pairs, lane, reinterpret_cast<double *>(wl), wgacc, P.digit_limit, P.acc_scale);
             unsigned prior = 0u;
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
             if (lane == 0)
@@ -1731,10 +1743,11 @@ __global__ __launch_bounds__(kFinThreads) void k_fin(FinParams P) {
 // probe builds: 100-MHz stamps of the first kLoopTimedIters iterations — per workgroup when it counted
 // itself in and when it had the next pose; for the solving wave when all counts were in, the sums
 // read, the step solved, the pose published
-constexpr int kLoopTimedIters = 32, kLoopTimedWgs = 1024;
-__device__ unsigned long long g_loop_wg[kLoopTimedIters][kLoopTimedWgs][2];
+constexpr int kLoopTimedIters = 32, kLoopTimedWgs = 2048;
+__device__ unsigned long long g_loop_wg[kLoopTimedIters][kLoopTimedWgs][4];     // counted in | pose held | a wave took a unit beyond one per wave | ... finished it
 __device__ unsigned g_loop_wginfo[kLoopTimedIters][kLoopTimedWgs][4];     // HW_ID | max points of a query | stale queries | points
 __device__ unsigned long long g_loop_solver[kLoopTimedIters][4];
+__device__ unsigned long long g_loop_wave[kLoopTimedIters][kLoopTimedWgs][8][2];      // per wave: its FIRST unit of the iteration: end stamp | start stamp (low 32) << 32 ... see LOOP_STAMP_WAVE
 __device__ unsigned long long g_loop_phase[16];     // [0..7] cycles per body phase, [8] wait for the pose, [9] closing a workgroup, [10] group passes
 #define LOOP_STAMP_SOLVER(it, k) do { if ((it) < kLoopTimedIters && (threadIdx.x & 63u) == 0u) g_loop_solver[it][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define LOOP_STAMP_WG(it, k) do { if ((it) < kLoopTimedIters && blockIdx.x < kLoopTimedWgs && (threadIdx.x & 63u) == 0u) g_loop_wg[it][blockIdx.x][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -1745,11 +1758,14 @@ extern "C" void sageicp_debug_loop_phases(unsigned long long *out, int reset) {
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_loop_phase), z, sizeof(z));
     }
 }
+extern "C" void sageicp_debug_loop_waves(unsigned long long *out) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_loop_wave), sizeof(unsigned long long) * kLoopTimedIters * kLoopTimedWgs * 8 * 2);
+}
 extern "C" void sageicp_debug_loop_info(unsigned *info) {
     (void)hipMemcpyFromSymbol(info, HIP_SYMBOL(g_loop_wginfo), sizeof(unsigned) * kLoopTimedIters * kLoopTimedWgs * 4);
 }
 extern "C" void sageicp_debug_loop_times(unsigned long long *wg, unsigned long long *solver) {
-    (void)hipMemcpyFromSymbol(wg, HIP_SYMBOL(g_loop_wg), sizeof(unsigned long long) * kLoopTimedIters * kLoopTimedWgs * 2);
+    (void)hipMemcpyFromSymbol(wg, HIP_SYMBOL(g_loop_wg), sizeof(unsigned long long) * kLoopTimedIters * kLoopTimedWgs * 4);
     (void)hipMemcpyFromSymbol(solver, HIP_SYMBOL(g_loop_solver), sizeof(unsigned long long) * kLoopTimedIters * 4);
 }
 #else
@@ -1838,7 +1854,7 @@ __device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, c
             for (int r = 0; r < kLoopReplicas; ++r)
                 v[r] = __hip_atomic_load(&acc[r][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             bool ok = true;
-            if (lane < 3 * kAccValues) {
+            if (lane <= 3 * kAccValues) {          // (word 3 kAccValues: the overflow count, counted like the sums)
 #pragma unroll
                 for (int r = 0; r < kLoopReplicas; ++r) ok &= (v[r] & 255ll) == per;
             }
@@ -1858,12 +1874,9 @@ __device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, c
         }
         LOOP_STAMP_SOLVER(it, 0);
         long long d = 0;
-        if (lane < 3 * kAccValues) {
+        if (lane <= 3 * kAccValues) {
 #pragma unroll
             for (int r = 0; r < kLoopReplicas; ++r) d += (v[r] - per) >> 8;       // (exact: the low byte is the count)
-        } else {
-#pragma unroll
-            for (int r = 0; r < kLoopReplicas; ++r) d += v[r];                    // (word 63: the overflow flag)
         }
 #pragma unroll
         for (int r = 0; r < kLoopReplicas; ++r)
@@ -1883,7 +1896,7 @@ __device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, c
         }
         __builtin_amdgcn_wave_barrier();
     }
-    const bool overflow = digits[kAccWords - 1] != 0;
+    const bool overflow = digits[3 * kAccValues] != 0;       // workgroups whose sums left the range (wgacc_flush)
     LOOP_STAMP_SOLVER(it, 1);
 
     // 2. multi-GPU: this rank's sums -> the sums over all ranks (direct exchange over xGMI, P2pBlock)
@@ -1970,6 +1983,7 @@ struct SolveArgs {
 };
 __global__ __launch_bounds__(64) void k_loop_solve(SolveArgs A) {
     __shared__ SolveLds m;
+    __builtin_amdgcn_s_setprio(3);             // (the grid waits for this wave: its SIMD's other waves can)
     {
         // Launched before the frame is even sorted, so that this wave holds its registers when the grid
         // of k_loop fills the machine; it waits here until the grid's first workgroup says that the
@@ -2099,6 +2113,15 @@ void k_loop(LoopArgs A) {
         smem[kLpDbg] = 0u; smem[kLpDbg + 1] = 0u; smem[kLpDbg + 2] = 0u;
 #endif
     }
+    if (L.deal && (threadIdx.x & 63u) == 0u) {
+        // The heaviest unit of a workgroup (its blocks are ordered by work) should not meet the heaviest units of the
+        // other workgroups of its CU on one SIMD: a workgroup's four waves sit on the four SIMDs, one wave of every
+        // workgroup of the CU per SIMD, and a SIMD's issue slots are what its waves share.  Workgroup r of the CU
+        // (its waves' slot number) hands unit (s + r) mod waves to its wave on SIMD s: every SIMD gets the same mix.
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        smem[kLpFirst + static_cast<unsigned>(wv)] = (((hw >> 4) & 3u) + (hw & 15u)) % static_cast<unsigned>(nw);
+    }
     for (unsigned i = threadIdx.x; i < 2u * kWgAccWords; i += blockDim.x) smem[kLpAcc + i] = 0u;
     for (unsigned i = threadIdx.x; i < nblk_max; i += blockDim.x) {
         perm[i] = i;                           // the order of the frame, until the blocks' work is known
@@ -2119,6 +2142,28 @@ void k_loop(LoopArgs A) {
         }
     }
     __syncthreads();
+    if (L.deal) {
+        // (two waves of a workgroup on one SIMD would ask for the same unit: the first keeps it, the others take what is
+        // left — every wave derives the same table, wave 0 stores it)
+        unsigned claimed = 0u, kept = 0u, table[kLoopMaxWaves];
+        for (int w2 = 0; w2 < nw; ++w2) {
+            const unsigned pr = smem[kLpFirst + static_cast<unsigned>(w2)];
+            table[w2] = pr;
+            if (!((claimed >> pr) & 1u)) { claimed |= 1u << pr; kept |= 1u << w2; }
+        }
+        for (int w2 = 0; w2 < nw; ++w2)
+            if (!((kept >> w2) & 1u)) {
+                const unsigned pr = static_cast<unsigned>(__builtin_ctz(~claimed));
+                table[w2] = pr;
+                claimed |= 1u << pr;
+            }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w2 = 0; w2 < nw; ++w2) smem[kLpFirst + static_cast<unsigned>(w2)] = table[w2];
+            smem[kLpNext] = static_cast<unsigned>(nw);
+        }
+        __syncthreads();
+    }
 #ifdef SAGE_LOOP_TIMING
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_wait = 0, t_close = 0, n_pass = 0;
@@ -2138,12 +2183,39 @@ void k_loop(LoopArgs A) {
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_u));
         const int lane = static_cast<int>(lane_u);
         // the workgroup's groups, first come first served: a wave held up by a heavy query takes fewer
+        bool dealt = L.deal != 0;
         for (;;) {
             unsigned gi = 0u;
-            if (lane == 0)
-                gi = __hip_atomic_fetch_add(&smem[kLpNext], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            gi = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(gi)));
-            if (gi >= gcnt) break;
+            if (dealt) {
+                // (this wave's first unit is fixed by where it sits; the units beyond one per wave go first come first served)
+                dealt = false;
+                gi = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(smem[kLpFirst + static_cast<unsigned>(wv)])));
+                if (gi >= gcnt) continue;
+            } else {
+                if (lane == 0)
+                    gi = __hip_atomic_fetch_add(&smem[kLpNext], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                gi = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(gi)));
+                if (gi >= gcnt) break;
+            }
+            if (L.prio) {
+                // A SIMD's issue slots go to its waves by priority: the wave with the heaviest unit of its workgroup (the
+                // units are ordered by last iteration's work) runs at the highest, the lightest at the lowest, a unit beyond
+                // one per wave — it starts late — at `prio` (3 by default).  The work of a SIMD does not change with the order, but
+                // its END does: the long chains run while there is other work to fill their stalls with, and what
+                // is left to run alone at the end of an iteration are the short ones (c2: 31.2 -> 28.2 us per iteration,
+                // profiles/r06/deal_ab.txt).
+                const unsigned rk = gi >= static_cast<unsigned>(nw) ? static_cast<unsigned>(L.prio) : 3u - min(gi, 3u);
+                switch (rk) {
+                    case 0: __builtin_amdgcn_s_setprio(0); break;
+                    case 1: __builtin_amdgcn_s_setprio(1); break;
+                    case 2: __builtin_amdgcn_s_setprio(2); break;
+                    default: __builtin_amdgcn_s_setprio(3); break;
+                }
+            }
+#ifdef SAGE_LOOP_TIMING
+            if (gi >= static_cast<unsigned>(nw)) LOOP_STAMP_WG(it, 2);
+            const unsigned long long t_unit = __builtin_amdgcn_s_memrealtime();
+#endif
             LoopGroup G;
             G.rows = rows;
             G.state = state;
@@ -2165,6 +2237,15 @@ void k_loop(LoopArgs A) {
                 icp_body<LW, true, FILT, true>(((const LoopArgs *)(kb))->P, smem, &G, s_pose);
             }
 #ifdef SAGE_LOOP_TIMING
+            if (gi >= static_cast<unsigned>(nw)) LOOP_STAMP_WG(it, 3);
+            if (it < kLoopTimedIters && blockIdx.x < kLoopTimedWgs && lane == 0 && wv < 8 && gi < static_cast<unsigned>(nw)) {
+                unsigned hw;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+                g_loop_wave[it][blockIdx.x][wv][0] = __builtin_amdgcn_s_memrealtime();
+                g_loop_wave[it][blockIdx.x][wv][1] = (t_unit << 24) | (static_cast<unsigned long long>(gi & 0xFFu) << 16) | (hw & 0xFFFFu);
+            }
+#endif
+#ifdef SAGE_LOOP_TIMING
             for (int i = 0; i < 8; ++i) ph[i] += G.ph[i];
 #endif
         }
@@ -2184,7 +2265,7 @@ void k_loop(LoopArgs A) {
             wgacc_flush<true>(wgacc, &sh->acc[it & 1][blockIdx.x & (kLoopReplicas - 1)][0], &sh->acc[it & 1][0][kAccWords - 1]);
             if (lane == 0) {                   // everybody is in: ready for the next iteration
                 smem[kLpArrive] = 0u;
-                smem[kLpNext] = 0u;
+                smem[kLpNext] = L.deal ? static_cast<unsigned>(nw) : 0u;
             }
             // The next iteration's order of the workgroup's blocks: heaviest first, by what they cost in this one (a
             // rank sort on one wave: lane i counts the blocks that go before block i).  Blocks of like work then

@@ -490,17 +490,31 @@ def test_register_frame_pose_parity_c4_scaled(gpu_sage, oracle, scan_form):
 
 
 def test_c4_full_size_properties(gpu_sage, oracle):
-    """c4 at full size (500k scan vs 10M map, the multi-GPU configuration) on one GPU through
-    size-independent properties: convergence near the planted pose, idempotence, and index-exact
-    correspondences against the oracle's search at the converged pose (the oracle's full
-    registration of this frame takes minutes and is not repeated here)."""
+    """c4 at full size (500k scan vs 10M map, the multi-GPU configuration) on one GPU: the oracle's FULL
+    registration of this frame (minutes of CPU: run once in the build container by
+    tests/golden/make_c4_golden.py, committed as tests/golden/c4_full.npz — pose, iteration count,
+    correspondence counts, the exact sum of C_q; steady and cold parameters), then size-independent
+    properties: convergence near the planted pose, idempotence, and index-exact correspondences against
+    the oracle's search at the converged pose."""
     from sage_icp_amd import synthetic as syn
     w, om = _workload(gpu_sage, oracle, "c4", 1.0)
     assert w["map"].size() == 10_000_000 and len(w["scan"]) == 500_000
-    p = syn.PARAMS["steady"]
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "c4_full.npz"))
+    assert [int(x) for x in gold["map_size"]] == [w["map"].size(), om.num_voxels()]           # the same workload
+    assert np.array_equal(gold["scan_checksum"], [float(np.sum(w["scan"][:, :3])), float(np.sum(w["scan"][:, 3]))])
     f = gpu_sage.Frame(w["map"], w["scan"])
-    pose, st = gpu_sage.register_frame(f, w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"],
-                                       p["sem_th"], return_stats=True)
+    for params in ("cold", "steady"):
+        p = syn.PARAMS[params]
+        assert np.array_equal(gold[params + "_params"], [p["max_dist"], p["kernel"], p["sem_th"]])
+        pose, st = gpu_sage.register_frame(f, w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"],
+                                           p["sem_th"], return_stats=True)
+        iters, conv, nc_first, nc_last, sum_cq, _ = [int(x) for x in gold[params + "_counts"]]
+        dt, dr = pose_error(oracle, gold[params + "_pose"], pose)
+        assert dt < 1e-7 and dr < 1e-7, (params, dt, dr)
+        assert (st.iterations, st.converged) == (iters, conv) and conv == 1
+        assert (st.n_corr_first, st.n_corr_last) == (nc_first, nc_last)
+        assert st.sum_candidates == sum_cq                                   # exact C_q accounting at 500k x 10M
+    p = syn.PARAMS["steady"]
     assert st.converged == 1 and 0 < st.pairs_evaluated < st.sum_candidates
     dt, dr = pose_error(oracle, w["T_gt"], pose)
     assert dt < 0.05 and dr < 2e-3
@@ -942,6 +956,32 @@ def test_sums_beyond_the_fixed_point_range_are_accumulated_at_a_coarser_scale(gp
     monkeypatch.setenv("SAGEICP_ACC_SHIFT", "1")
     ref, sr = gpu_sage.register_frame(frame, m, gpu_sage.IDENTITY, 6.0, 0.5, 0.4, return_stats=True)
     assert np.array_equal(pose, ref) and st.iterations == sr.iterations
+
+
+def test_big_frame_at_utm_coordinates_does_not_wrap_the_accumulators(gpu_sage, oracle, monkeypatch):
+    """k_fin adds the 32 copies of k_icp's accumulators in 64-bit integers, so what must fit is the sum
+    over ALL the blocks of the frame, not one block: 1.05M points at y = 4e6 m (UTM northing) keep every block of
+    four under the old fixed limit (4 x 1.6e13 < 2^46) while sum(w y^2) ~ 1.7e19 passes 2^63.  The limit of a block
+    now follows from the size of the frame (2^62 / blocks), the frame is registered at the coarser scale, and the
+    answer is that of asking for the coarser scale by name."""
+    rng = np.random.default_rng(5)
+    off = np.array([5.0e5, 4.0e6, 0.0, 0.0])
+    mp = rng.uniform(-60, 60, size=(30000, 4))
+    mp[:, 2] = rng.uniform(-2, 2, 30000)
+    mp[:, 3] = rng.choice([0, 40, 50], 30000)
+    plant = np.array([0.3, -0.2, 0.05, 0.0])
+    q = mp[rng.integers(0, 30000, 1_050_000)] + plant
+    m = gpu_sage.VoxelHashMap(4.0, 1e9)
+    m.AddPoints(mp + off)
+    frame = np.ascontiguousarray(q + off)
+    pose, st = gpu_sage.register_frame(frame, m, gpu_sage.IDENTITY, 6.0, 0.5, 0.4, return_stats=True)
+    assert st.single_launch == 0 and st.converged == 1 and np.all(np.isfinite(pose))
+    monkeypatch.setenv("SAGEICP_ACC_SHIFT", "1")
+    ref, sr = gpu_sage.register_frame(frame, m, gpu_sage.IDENTITY, 6.0, 0.5, 0.4, return_stats=True)
+    assert np.array_equal(pose, ref) and st.iterations == sr.iterations
+    # the planted shift is found (the frame is the map's own points moved by `plant`)
+    moved = oracle.transform_points(pose, frame[:2000])
+    assert np.abs(moved[:, :3] - (frame[:2000, :3] - plant[:3])).max() < 1e-3
 
 
 def test_counters_can_be_switched_off(gpu_sage, oracle):
