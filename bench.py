@@ -460,20 +460,22 @@ def main():
         # the per-wave counters behind sum_candidates / pairs_evaluated (the bytes models of the line) are
         # instrumentation the C++ shim's calls never pay for: off in the timed region, one counted frame after it
         sage.set_counting(False)
-        fence()
-        t0 = time.perf_counter()
-        stats, pose, good = [], None, True
         try:
-            for _ in range(args.steps):
-                pose, st = step()
-                stats.append(st)
-        except sage.SageIcpError as e:
-            sys.stderr.write("rank %d: timed step failed: %s\n" % (rank, e))
-            good = False
-        fence()
-        elapsed = time.perf_counter() - t0
-        sage.set_profiling(0)
-        sage.set_counting(True)
+            fence()
+            t0 = time.perf_counter()
+            stats, pose, good = [], None, True
+            try:
+                for _ in range(args.steps):
+                    pose, st = step()
+                    stats.append(st)
+            except sage.SageIcpError as e:
+                sys.stderr.write("rank %d: timed step failed: %s\n" % (rank, e))
+                good = False
+            fence()
+            elapsed = time.perf_counter() - t0
+        finally:                               # (whatever happens in there: the process-wide switches go back)
+            sage.set_profiling(0)
+            sage.set_counting(True)
         return (elapsed, stats, pose) if good else None
 
     res = timed()
@@ -679,6 +681,14 @@ def main():
                                   else "query-sharded x%d, map replicated, %s" % (world, exchange)
                                   if use_dist else "single GPU",
                    "ranks": world,
+                   # which entry `value` times (the contract: inputs resident in HBM when the timed region starts; the
+                   # PCIe-inclusive rate of the host-buffer entry the C++ shim calls is `ms_per_step_host_entry`, never `value`)
+                   "entry": "sageicp_register_frame_resident (frame and map in HBM); the host-buffer entry "
+                            "sageicp_register_frame, which sage_icp::RegisterFrame() of the shim calls, is timed in the same run "
+                            "as ms_per_step_host_entry",
+                   "counters_in_timed_region": "off (sageicp_set_counting(0)): the per-wave candidate / pair counters are "
+                                               "instrumentation the shim's calls never pay for; one counted frame follows "
+                                               "the timed region — frames/s are not comparable with BENCH files before round 5",
                    # what ran, without reading stderr: the exchange form of the timed region, the ranks
                    # RCCL itself reports for the communicator (ncclCommCount; None: no communicator),
                    # and the pose of one frame registered through both forms before the timed region

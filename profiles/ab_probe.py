@@ -21,7 +21,7 @@ for _ in range(K): pose, st = run()
 dt = (time.perf_counter() - t) / K
 print("%-30s %s %s: %8.3f ms/frame %4d it %6.2f us/it" % (os.path.basename(os.environ.get("SAGEICP_VARIANT_LIB", "product")), name, params, 1e3 * dt, st.iterations, 1e6 * dt / max(1, st.iterations)), flush=True)
 '''
-for wl in (("c2", "cold", "20"), ("c1", "cold", "100"), ("c4", "steady", "6")):
+for wl in [tuple(x.split(":")) for x in os.environ.get("AB_WORKLOADS", "c2:cold:20 c1:cold:100 c4:steady:6").split()]:
     for rep in range(3):
         for lib in sys.argv[1:]:
             env = dict(os.environ)

@@ -191,9 +191,10 @@ __device__ __forceinline__ Point4 load_point(__amdgpu_buffer_rsrc_t pts, uint32_
     return q;
 }
 
-// One compact candidate record (16 B): fp32 x, y, z, label.  `off` is its byte offset.
-__device__ __forceinline__ uint4 load_cand(__amdgpu_buffer_rsrc_t cands, uint32_t off) {
-    const v4u a = __builtin_amdgcn_raw_buffer_load_b128(cands, off, 0, 0);
+// One compact candidate record (16 B): fp32 x, y, z, label.  `off` is its byte offset; `imm` (a constant) travels in the
+// instruction's scalar offset: a second record at a fixed distance from the first costs no address arithmetic.
+__device__ __forceinline__ uint4 load_cand(__amdgpu_buffer_rsrc_t cands, uint32_t off, int imm = 0) {
+    const v4u a = __builtin_amdgcn_raw_buffer_load_b128(cands, off, imm, 0);
     return make_uint4(a.x, a.y, a.z, a.w);
 }
 
@@ -932,28 +933,35 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
     unsigned n_consume = 0u, n_exact = 0u, n_exact_lanes = 0u;
 #endif
     double fb = best;                          // what the thresholds were derived from (>= the query's final best)
-    float Ts = 0.0f, Td = 0.0f;
+    float Ts = 0.0f, Td = 0.0f, Tmax = 0.0f;   // Tmax: the looser of the two
     auto round_up = [](double x) {             // the next fp32 above x (an infinity becomes a NaN:
         return __uint_as_float(__float_as_uint(static_cast<float>(x)) + 1u);   // `D32 > NaN` is false, nothing is dropped)
     };
     auto set_thresholds = [&]() {
         if constexpr (!FILT) return;
         float a = round_up(fb * P.filt_inv_same + slack), b = round_up(fb * P.filt_inv_diff + slack);
-        if (unknown) {                         // the looser one; a NaN stands for an infinity
-            float m = a > b ? a : b;
-            if (a != a || b != b) m = __uint_as_float(0x7FC00000u);
-            a = b = m;
-        }
-        Ts = a; Td = b;
+        float m = a > b ? a : b;               // the looser one; a NaN stands for an infinity
+        if (a != a || b != b) m = __uint_as_float(0x7FC00000u);
+        if (unknown) a = b = m;
+        Ts = a; Td = b; Tmax = m;
     };
-    auto passes = [&](const uint4 &c, bool on) {
-        const float dx = __uint_as_float(c.x) - qx, dy = __uint_as_float(c.y) - qy, dz = __uint_as_float(c.z) - qz;
-        // (any association, and fused: the filter's bound assumes four roundings of relative size u — two fused
-        // multiply-adds round twice; the library is built with -ffp-contract=off for the fp64 comparisons that decide)
-        const float d = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
-        const float lab = __uint_as_float(c.w);
-        const bool same = (lab == plab) | (lab == 0.0f) | q_zero;
-        return on & !(d > (same ? Ts : Td));
+    // The filter in two steps.  Every scanned point pays for the fp32 distance and ONE comparison with the looser
+    // threshold (packed arithmetic: x and y in one instruction, z and the label difference in another — six vector
+    // instructions per point); only a step in which some lane holds a point under it looks at the label classes
+    // (`tight`), and only a point under the threshold of ITS class is fetched.  (Any association, and fused: the
+    // filter's bound assumes four roundings of relative size u — this sum rounds three times; the library is built
+    // with -ffp-contract=off for the fp64 comparisons that decide.)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    auto dist32 = [&](const uint4 &c, float &dl) {
+        const f2 u = f2{__uint_as_float(c.x), __uint_as_float(c.y)} - f2{qx, qy};
+        const f2 v = f2{__uint_as_float(c.z), __uint_as_float(c.w)} - f2{qz, plab};
+        const f2 sq = u * u;
+        dl = v.y;                              // label - query label (exact: small integers; a NaN label stays a NaN)
+        return __builtin_fmaf(v.x, v.x, sq.x) + sq.y;
+    };
+    auto tight = [&](const uint4 &c, float d, float dl) {
+        const bool same = (dl == 0.0f) | (__uint_as_float(c.w) == 0.0f) | q_zero;
+        return !(d > (same ? Ts : Td));
     };
 
     // Per-lane state machine over the voxels in `need` (and the one already open).  A step handles
@@ -1028,19 +1036,23 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
             if constexpr (FILT) n.oa = off;
             // issued by every lane (idle lanes re-read record 0): a load behind a branch would make
             // the compiler drain the whole queue before the other set is looked at
-            const unsigned oa = n.ha ? off : 0u, ob = n.hb ? off + (static_cast<unsigned>(W) << SHC) : 0u;
+            const unsigned oa = n.ha ? off : 0u;
             if constexpr (FILT) {
+                // (b lies W records behind a — a constant in the instruction; a lane without a b reads whatever
+                // lies there, under the buffer's bounds check, and its `hb` drops it)
                 n.a = load_cand(cands, oa);
-                n.b = load_cand(cands, ob);
+                n.b = load_cand(cands, oa, W << SHC);
             } else {
+                const unsigned ob = n.hb ? off + (static_cast<unsigned>(W) << SHC) : 0u;
                 n.a = load_point(pts, oa);
                 n.b = load_point(pts, ob);
             }
             // the filtering of the other set stays below these loads (the scheduler would
             // otherwise sink them under the arithmetic it believes is ready)
             __builtin_amdgcn_sched_barrier(0);
-            k += n.ha ? 2u * W : 0u;
-            off += n.ha ? (2u * W) << SHC : 0u;
+            // (a lane past the end of its voxel keeps counting: the next voxel it opens sets k and off afresh)
+            k += 2u * W;
+            off += (2u * W) << SHC;
             more = (k < kend) | (need != 0u);
             }
         };
@@ -1052,10 +1064,14 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
                 evaluate(n.b, n.hb, kb);
             } else {
             // (the candidate already held — the seed met again in its voxel — needs no second look)
-            const bool pa = passes(n.a, n.ha) & (n.ka != bkey), pb = passes(n.b, n.hb) & (kb != bkey);
+            float dla, dlb;
+            const float da = dist32(n.a, dla), db = dist32(n.b, dlb);
+            const bool la = n.ha & !(da > Tmax) & (n.ka != bkey), lb = n.hb & !(db > Tmax) & (kb != bkey);
 #ifdef SAGE_NN_TIMING
             ++n_consume;
 #endif
+            if (__ballot(la | lb)) {
+            const bool pa = la & tight(n.a, da, dla), pb = lb & tight(n.b, db, dlb);
             if (__ballot(pa | pb)) {
                 // rarer and rarer as the registration settles (a fifth of the pair steps at the
                 // start of a cold one, 2 % near convergence): the full records of the candidates
@@ -1073,6 +1089,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
                 evaluate(eb, pb, kb);
                 fb = min_f64(fb, best);
                 set_thresholds();
+            }
             }
             }
         };
