@@ -57,8 +57,8 @@ typedef struct sageicp_comm sageicp_comm;     /* opaque: RCCL communicator for q
  * sageicp_comm_describe, sageicp_map_pointcloud served from the HBM copy, sageicp_map_point_slots
  * (size-classed voxel storage).   3: sageicp_stats names its loop form (single_launch in the slot of
  * reserved0), sageicp_pipeline_prefetch_wait, non-finite input refused (SAGEICP_ERR_INVALID) at every entry
- * that would cast it. */
-#define SAGEICP_ABI_VERSION 3
+ * that would cast it.   4: sageicp_map_loop_status, sageicp_reload_env (additions only). */
+#define SAGEICP_ABI_VERSION 4
 
 /* Filled by sageicp_register_frame*.  Times are microseconds. */
 typedef struct sageicp_stats {
@@ -92,6 +92,9 @@ const char *sageicp_last_error(void);
 int sageicp_device_count(void);               /* number of visible HIP devices (0: none) */
 void sageicp_set_profiling(int level);        /* 0 off; 1 HIP events around k_icp in one iteration
                                                * out of 8; 2 around every kernel of every iteration */
+void sageicp_reload_env(void);                /* the SAGEICP_* tuning knobs are read from the environment once per process (at
+                                               * first use); this makes the next calls read them again.  Not while calls of
+                                               * other threads are in flight. */
 void sageicp_set_counting(int on);            /* 1 (default): a call given a sageicp_stats counts C_q and the pairs it
                                                * evaluates (sum_candidates, pairs_evaluated: ~3 % of the search);
                                                * 0: those two fields stay zero, the others are filled as before.
@@ -206,6 +209,27 @@ int sageicp_register_frame_resident(const sageicp_map *map, const sageicp_frame 
                                     double max_correspondence_distance, double kernel,
                                     double sem_th, sageicp_comm *comm /* optional */,
                                     double pose_out[7], sageicp_stats *stats /* optional */);
+
+/* Which form of the loop the calls of a map handle take, and why.  A frame that fits the machine's LDS runs its whole loop
+ * in ONE launch (Registration.cpp:127-138 without a kernel boundary); that launch needs every workgroup resident at once,
+ * and when a wait inside it times out (another tenant on the GPU, a driver that places fewer workgroups) the frame is
+ * registered through the launch-per-iteration form instead, the handle stays away from the one-launch form for
+ * `cooldown_calls` calls and plans `derate_workgroups` fewer workgroups from then on.  The first such event of a process
+ * also writes one line to stderr.  Poses are the same to the bit in either form. */
+#define SAGEICP_LOOP_FALLBACK_NONE 0
+#define SAGEICP_LOOP_FALLBACK_TIMEOUT 1          /* a wait inside the one launch timed out: the grid was not resident as a whole */
+#define SAGEICP_LOOP_FALLBACK_COOLDOWN 2         /* the call fell into the cool-down after such a time-out */
+#define SAGEICP_LOOP_FALLBACK_DOES_NOT_FIT 3     /* the frame needs more LDS than the machine has (~170k points), or the form is
+                                                  * switched off (SAGEICP_LOOP=0), or the call runs under an RCCL communicator */
+typedef struct sageicp_loop_status {
+    uint64_t calls_single_launch;       /* registrations of this handle that ran in one launch */
+    uint64_t calls_per_iteration;       /* ... through the launch-per-iteration form */
+    uint32_t timeouts;                  /* launches that gave up (each cost its time-out, 50 ms by default, before the fall-back) */
+    uint32_t cooldown_calls;            /* calls that will still stay away from the one-launch form */
+    uint32_t derate_workgroups;         /* workgroups taken off every later plan of this handle (32 per time-out, at most 512) */
+    int32_t last_fallback;              /* SAGEICP_LOOP_FALLBACK_*: why the LAST call did not run in one launch (NONE: it did) */
+} sageicp_loop_status;
+int sageicp_map_loop_status(const sageicp_map *map, sageicp_loop_status *out);
 
 /* ---- query sharding across GPUs (one process per GPU, RCCL over xGMI) -------------------- */
 #define SAGEICP_UNIQUE_ID_BYTES 128

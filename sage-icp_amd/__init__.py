@@ -36,7 +36,7 @@ _u64p = C.POINTER(C.c_uint64)
 _i64p = C.POINTER(C.c_int64)
 _u8p = C.POINTER(C.c_uint8)
 
-ABI_VERSION = 3          # SAGEICP_ABI_VERSION of include/sageicp.h
+ABI_VERSION = 4          # SAGEICP_ABI_VERSION of include/sageicp.h
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_RCCL, ERR_CAPACITY = -1, -2, -3, -4, -5
 UNIQUE_ID_BYTES = 128
 P2P_HANDLE_BYTES = 64
@@ -132,6 +132,8 @@ _SIGNATURES = [
     ("sageicp_device_count", C.c_int, []),
     ("sageicp_set_profiling", None, [C.c_int]),
     ("sageicp_set_counting", None, [C.c_int]),
+    ("sageicp_reload_env", None, []),
+    ("sageicp_map_loop_status", C.c_int, [C.c_void_p, C.c_void_p]),
     ("sageicp_set_downsample_order", None, [C.c_int]),
     ("sageicp_robin_iteration_order", C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
     ("sageicp_map_create", C.c_void_p,
@@ -201,10 +203,38 @@ EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
 
 _lib = None
 
+# The library reads its SAGEICP_* knobs from the environment once (sageicp_reload_env() makes it look again).  Tests and
+# probes flip knobs between calls through os.environ: every change of a SAGEICP_* name marks the cache stale, and the next
+# call through lib() reloads.
+_env_stale = [False]
+_Environ = type(os.environ)
+if not getattr(_Environ, "_sageicp_hooked", False):
+    _set0, _del0 = _Environ.__setitem__, _Environ.__delitem__
+
+    def _set1(self, k, v):
+        _set0(self, k, v)
+        if str(k).startswith("SAGEICP_"):
+            _env_stale[0] = True
+
+    def _del1(self, k):
+        _del0(self, k)
+        if str(k).startswith("SAGEICP_"):
+            _env_stale[0] = True
+
+    _Environ.__setitem__, _Environ.__delitem__, _Environ._sageicp_hooked = _set1, _del1, True
+
+
+class LoopStatus(C.Structure):
+    _fields_ = [("calls_single_launch", C.c_uint64), ("calls_per_iteration", C.c_uint64), ("timeouts", C.c_uint32),
+                ("cooldown_calls", C.c_uint32), ("derate_workgroups", C.c_uint32), ("last_fallback", C.c_int32)]
+
 
 def lib():
     """Load libsageicp_hip.so.  Raises (loudly) if it has not been built — no fallback."""
     global _lib
+    if _lib is not None and _env_stale[0]:
+        _env_stale[0] = False
+        _lib.sageicp_reload_env()
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError(
@@ -429,6 +459,12 @@ class VoxelHashMap:
 
     def sync(self):
         _check(lib().sageicp_map_sync(self._h))
+
+    def loop_status(self):
+        """sageicp_map_loop_status: which form of the ICP loop this handle's calls took, and why"""
+        st = LoopStatus()
+        _check(lib().sageicp_map_loop_status(self._h, C.byref(st)))
+        return st
 
     def GetCorrespondences(self, pts, max_correspondance_distance, th, with_index=False):
         pts, pp = _d(pts)

@@ -16,6 +16,25 @@ namespace sageicp {
 thread_local std::string g_err;
 std::atomic<int> g_profiling{0};
 std::atomic<int> g_counting{1};
+std::atomic<unsigned> g_env_epoch{0};
+const char *env_cached(const char *name) {
+    // (text knobs — SAGEICP_DEVICES, SAGEICP_CU_SHARE — are asked for when a handle or its streams are created, not per call)
+    static std::mutex mu;
+    static unsigned epoch = 0xFFFFFFFFu;
+    static std::map<std::string, std::pair<bool, std::string>> vals;
+    std::lock_guard<std::mutex> lk(mu);
+    const unsigned e = g_env_epoch.load();
+    if (epoch != e) {
+        vals.clear();
+        epoch = e;
+    }
+    auto it = vals.find(name);
+    if (it == vals.end()) {
+        const char *v = std::getenv(name);
+        it = vals.emplace(name, std::make_pair(v != nullptr, std::string(v ? v : ""))).first;
+    }
+    return it->second.first ? it->second.second.c_str() : nullptr;
+}
 std::atomic<int> g_reference_order{1};
 }  // namespace sageicp
 
@@ -32,6 +51,7 @@ int sageicp_device_count(void) {
 }
 void sageicp_set_profiling(int level) { g_profiling = level; }
 void sageicp_set_counting(int on) { g_counting = on ? 1 : 0; }
+void sageicp_reload_env(void) { sageicp::g_env_epoch.fetch_add(1u); }
 void sageicp_set_downsample_order(int reference_order) { g_reference_order = reference_order ? 1 : 0; }
 int sageicp_robin_iteration_order(const int32_t *vox_xyz, uint64_t n, uint32_t *order_out) {
     if (n && (!vox_xyz || !order_out)) return fail(SAGEICP_ERR_INVALID, "null argument");
@@ -63,7 +83,7 @@ sageicp_map *sageicp_map_create(double voxel_size, double max_distance, int basi
     m->device = device;
     // SAGEICP_DEVICES=0,1,2,3: every map of this process spans these devices (the knob for callers
     // that cannot be changed, e.g. the ROS node behind the header shim); the first is rank 0
-    if (const char *list = std::getenv("SAGEICP_DEVICES")) {
+    if (const char *list = env_cached("SAGEICP_DEVICES")) {
         std::vector<int> devs;
         for (const char *q = list; *q;) {
             char *end = nullptr;
@@ -595,6 +615,18 @@ int sageicp_register_frame(const sageicp_map *m, const double *frame, uint64_t n
     const double us_upload = now_us() - t0;
     return run_icp(m, sc.d_frame, n, init, max_dist, kernel, sem_th, nullptr, pose_out, stats,
                    us_upload, t0);
+}
+
+int sageicp_map_loop_status(const sageicp_map *m, sageicp_loop_status *out) {
+    if (!m || !out) return fail(SAGEICP_ERR_INVALID, "null argument");
+    const Scratch &sc = m->sc;
+    out->calls_single_launch = sc.calls_single_launch;
+    out->calls_per_iteration = sc.calls_per_iteration;
+    out->timeouts = sc.loop_timeouts;
+    out->cooldown_calls = static_cast<uint32_t>(std::max(0, sc.loop_cooldown));
+    out->derate_workgroups = 32u * static_cast<uint32_t>(std::max(0, sc.loop_derate));
+    out->last_fallback = sc.last_fallback;
+    return SAGEICP_OK;
 }
 
 sageicp_frame *sageicp_frame_upload(const sageicp_map *m, const double *frame, uint64_t n) {

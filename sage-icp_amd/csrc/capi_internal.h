@@ -49,10 +49,29 @@ extern std::atomic<int> g_reference_order;
 
 // tuning knobs (defaults chosen by measurement on MI355X; the environment overrides are for
 // experiments only)
-inline int env_int(const char *name, int dflt) {
-    const char *v = std::getenv(name);
-    return v ? std::atoi(v) : dflt;
+// The process environment is read ONCE per knob and call site (the first time it is asked for) and again only after
+// sageicp_reload_env(): a registration asks for ~35 knobs, and a ROS node's environment does not change under it.
+// (Tests and probes that flip knobs between calls go through the Python binding, which calls sageicp_reload_env()
+// whenever the SAGEICP_* part of os.environ changed.)
+extern std::atomic<unsigned> g_env_epoch;          // bumped by sageicp_reload_env()
+struct EnvKnob {
+    const char *name;
+    std::atomic<unsigned> epoch{0xFFFFFFFFu};
+    std::atomic<int> has{0}, val{0};
+};
+inline int env_knob(EnvKnob &k, int dflt) {
+    const unsigned e = g_env_epoch.load(std::memory_order_relaxed);
+    if (k.epoch.load(std::memory_order_acquire) != e) {
+        const char *v = std::getenv(k.name);
+        k.val.store(v ? std::atoi(v) : 0, std::memory_order_relaxed);
+        k.has.store(v ? 1 : 0, std::memory_order_relaxed);
+        k.epoch.store(e, std::memory_order_release);
+    }
+    return k.has.load(std::memory_order_relaxed) ? k.val.load(std::memory_order_relaxed) : dflt;
 }
+#define env_int(name, dflt) ([&]() -> int { static ::sageicp::EnvKnob _knob{name}; return ::sageicp::env_knob(_knob, (dflt)); }())
+// a knob that is text: the value at the last (re)load (capi.hip), or nullptr
+const char *env_cached(const char *name);
 // Lanes per query in k_icp (log2).  One lane per query needs the fewest instructions per query
 // but gives a frame of n points only n / 64 waves with long dependent chains; small frames and
 // shards spread each query over more lanes.  Thresholds measured on MI355X (profiles/README.md);
@@ -128,6 +147,10 @@ struct Scratch {
                                    // ranks on ONE GPU — tests, or a small node — each keep a persistent grid resident)
     int loop_cooldown = 0;         // calls that stay away from k_loop after one of its launches timed out
     int loop_derate = 0;           // x 32 workgroups fewer than the residency rule allows: one more after every time-out
+    // what sageicp_map_loop_status reports
+    uint64_t calls_single_launch = 0, calls_per_iteration = 0;
+    uint32_t loop_timeouts = 0;
+    int last_fallback = 0;
     unsigned long long *d_cand = nullptr;      // per-wave counters of k_icp [2 x sort_cap]
     IcpState *d_state = nullptr;
     IcpState *h_state = nullptr;   // pinned
@@ -148,7 +171,7 @@ struct Scratch {
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) num_cus = cus;
         }
         if (cu_share_k <= 1) {
-            if (const char *e = std::getenv("SAGEICP_CU_SHARE")) {
+            if (const char *e = env_cached("SAGEICP_CU_SHARE")) {
                 int i = 0, k = 1;
                 if (std::sscanf(e, "%d/%d", &i, &k) == 2 && k >= 1 && k <= 16 && i >= 0 && i < k) {
                     cu_share_i = i;

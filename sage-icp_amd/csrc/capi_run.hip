@@ -146,6 +146,8 @@ IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, 
         ip.digit_limit = std::ldexp(1.0, std::min(46, 62 - bits));
     }
     ip.counters = nullptr;
+    ip.stripe_work = nullptr;
+    ip.stripe_order = nullptr;
     const uint64_t qw = 64u >> lw;
     ip.nwaves = static_cast<unsigned>((n + qw - 1) / qw);
 #ifdef SAGE_ICP_DELAY_PROBE
@@ -330,9 +332,11 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     // a launch that timed out (its grid was not resident as a whole: the GPU is shared with other work)
     // cost 50 ms before the frame went through the other loop: the next calls do not try again
     bool use_loop = loop_shape;
+    sc.last_fallback = loop_shape ? SAGEICP_LOOP_FALLBACK_NONE : SAGEICP_LOOP_FALLBACK_DOES_NOT_FIT;
     if (use_loop && sc.loop_cooldown > 0) {
         --sc.loop_cooldown;
         use_loop = false;
+        sc.last_fallback = SAGEICP_LOOP_FALLBACK_COOLDOWN;
     }
     const unsigned loop_waves = use_loop ? static_cast<unsigned>((n + (64u >> plan.lw) - 1) / (64u >> plan.lw)) : 0u;
     if ((rc = ensure_cand(m, wants_filter(m, n, sem_th)))) return rc;
@@ -465,6 +469,17 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
             // with the same lanes per query
             sc.loop_cooldown = std::max(0, env_int("SAGEICP_LOOP_COOLDOWN", 256));
             if (env_int("SAGEICP_LOOP_TIMEOUT_TICKS", 0) == 0 && sc.loop_derate < 16) ++sc.loop_derate;
+            ++sc.loop_timeouts;
+            sc.last_fallback = SAGEICP_LOOP_FALLBACK_TIMEOUT;
+            {
+                // (said out loud once per process: the fast path was lost, and what it cost)
+                static std::atomic<int> told{0};
+                if (told.exchange(1) == 0 && env_int("SAGEICP_QUIET", 0) == 0)
+                    std::fprintf(stderr, "sageicp: a wait inside the one-launch ICP loop timed out (the GPU is shared with other work, or "
+                                         "fewer workgroups are resident than planned): this frame goes through the launch-per-iteration "
+                                         "loop, the next %d calls of this map too, later plans take %d workgroups fewer "
+                                         "(sageicp_map_loop_status() reports the state)\n", sc.loop_cooldown, 32 * sc.loop_derate);
+            }
             if (comm) {
                 // (the peers are somewhere inside their loops: there is no starting again in step)
                 comm->p2p = false;
@@ -514,10 +529,25 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     // stream time): the roofline figure is the mean over that sample; level 2: every kernel of
     // every iteration.
     auto sampled = [&](int iteration) { return prof2 || (prof && (iteration & 7) == 4); };
+    // Heaviest first (kernels.h, IcpParams::stripe_order): the stripes of k_icp are dispatched in the order of the work
+    // iterations 0, 3 and 15 measured (a cold registration's first passes are not its later ones; from then on the heavy
+    // regions stay the heavy regions).  The sort's buffers are the frame sort's, free once the frame is in order.
+    const unsigned stripes = (n > 0 && !looped) ? static_cast<unsigned>(icp_stripes_for(static_cast<int>(n), lw)) : 0u;
+    // (three small sorts per frame: worth it from ~40k points on — c1 through this loop: +4.5 % with them)
+    const bool lpt = stripes >= 16 && stripes <= sc.sort_cap && stripe_sort_temp_bytes(stripes) <= sc.sort_temp_bytes_ &&
+                     env_int("SAGEICP_LPT", n >= 40000 ? 1 : 0) != 0;
+    uint32_t *st_work = sc.d_keys, *st_sorted = sc.d_keys + stripes, *st_iota = sc.d_vals, *st_order = sc.d_vals + stripes;
+    if (lpt) stripe_order_init(st_work, st_iota, stripes, s);
+    auto measures = [&](int iteration) { return lpt && (iteration == 0 || iteration == 3 || iteration == 15); };
     auto enqueue_iteration = [&](int slot, int iteration) -> int {
         const bool ev = sampled(iteration);
         if (ev) HIPCHK(hipEventRecord(sc.events[5 * slot + 1], s));
+        ip.stripe_work = measures(iteration) ? st_work : nullptr;
         launch_icp(ip, lw, true, s);
+        if (measures(iteration)) {
+            HIPCHK(stripe_order_sort(st_work, st_sorted, st_iota, st_order, stripes, sc.d_sort_temp, sc.sort_temp_bytes_, s));
+            ip.stripe_order = st_order;
+        }
         if (ev) HIPCHK(hipEventRecord(sc.events[5 * slot + 2], s));
         launch_fin(fp, s);
         if (comm && !p2p) {     // k_fin left the local sums in state->sums
@@ -624,6 +654,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         return fail(SAGEICP_ERR_RCCL, "direct exchange: a peer's sums did not arrive in time");
     }
     for (int i = 0; i < 7; ++i) out[i] = st.T[i];
+    if (looped) ++sc.calls_single_launch; else ++sc.calls_per_iteration;
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         stats->iterations = st.iter;

@@ -68,6 +68,14 @@ struct IcpParams {
     double acc_scale;         // a power of two (1 normally): the sums are accumulated as fixed-point numbers of
                               // sum x acc_scale — a frame whose sums leave the range (coordinates of 10^7 m) is
                               // registered again at 2^-24, 2^-48 (capi.hip); FinParams / LoopParams::acc_unscale undo it
+    // k_icp, heaviest first: the launch-per-iteration form ends with the waves that started last, and with the sorted frame
+    // dealt out in its own order those are as heavy as any — half of a c4 launch is its tail (profiles/r06/icp_tail_c4.txt).
+    // The stripes of kStripe consecutive workgroups (what one XCD takes at a time) are dispatched in the order of the work
+    // an earlier iteration measured, heaviest first, so that what runs last is light and short.  A stripe's work is that of
+    // its heaviest wave: what a launch waits for at its end is single long waves, not busy stripes (the sum of the waves
+    // instead: c4 -3 % against -7 %, profiles/r06/lpt_max_ab.txt; stripes of 4, 2, 1 workgroups: within 1.5 %, lpt_stripe_ab.txt).
+    uint32_t *stripe_work;    // optional, out: [stripes] max over the stripe's waves of the most points one of a wave's queries was handed
+    const uint32_t *stripe_order;  // optional: [stripes] the stripe dispatched at each position (null: the order of the frame)
     unsigned long long *counters;  // optional: [2 x waves] running sums of {C_q, pairs evaluated}
     unsigned nwaves;          // waves that own queries: ceil(n / (64 >> lw))
 #ifdef SAGE_ICP_DELAY_PROBE
@@ -237,6 +245,13 @@ hipError_t voxel_downsample_device(const VdsParams &P, void *sort_temp, size_t s
 
 // sort.hip: re-ordering of a frame along the Morton curve of its map-frame voxels
 size_t sort_temp_bytes(int n);
+// ... and the dispatch order of k_icp's stripes: `order` = the stripes by `work`, heaviest first (stable); `work` is zeroed
+// for the next measurement.  iota: [stripes] 0, 1, 2, ... (stripe_order_init fills it and zeroes `work`).
+size_t stripe_sort_temp_bytes(unsigned stripes);
+void stripe_order_init(uint32_t *work, uint32_t *iota, unsigned stripes, hipStream_t s);
+hipError_t stripe_order_sort(uint32_t *work, uint32_t *work_sorted, const uint32_t *iota, uint32_t *order, unsigned stripes,
+                             void *temp, size_t temp_bytes, hipStream_t s);
+int icp_stripes_for(int n, int lw);        // stripes of the k_icp launch of n queries
 // A frame point with a coordinate or label that is not finite raises st->bad_input (the reference
 // casts such values to int: undefined behaviour); with `stop_on_bad` it also ends the loop before its
 // first iteration (st->done, the progress word) — not under a communicator, where every rank has to

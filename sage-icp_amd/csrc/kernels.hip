@@ -620,12 +620,27 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
     // of the frame per XCD left the XCDs with 57k to 97k points to look at per iteration on a c2 shard,
     // and the iteration ends with the slowest, profiles/r04/loop_times.txt.)
     constexpr unsigned kStripe = SAGE_ICP_STRIPE;
-    unsigned wave_id;                                                               // wave-uniform
+    unsigned wave_id, stripe_id = 0u;                                               // wave-uniform
     if constexpr (PERSIST) {
         wave_id = G->slot;                     // (k_loop maps its workgroups to groups of queries itself)
     } else {
         const unsigned xcd = blockIdx.x & 7u, jb = blockIdx.x >> 3;
-        const unsigned wg = ((jb / kStripe) * 8u + xcd) * kStripe + (jb % kStripe);
+        unsigned stripe = (jb / kStripe) * 8u + xcd;            // the stripe dispatched at this position ...
+        if (P.stripe_order) {
+            // ... in the order of the work an earlier iteration measured, heaviest first (kernels.h): what runs last is
+            // light.  Within a SIMD the waves of the heavier stripes go first as well (s_setprio by the quarter of the
+            // order this stripe lies in: the long chains run while there is other work to cover their stalls).
+            const unsigned nstripes = gridDim.x / kStripe;
+            switch (stripe * 4u / nstripes) {
+                case 0: __builtin_amdgcn_s_setprio(3); break;
+                case 1: __builtin_amdgcn_s_setprio(2); break;
+                case 2: __builtin_amdgcn_s_setprio(1); break;
+                default: break;
+            }
+            stripe = P.stripe_order[stripe];
+        }
+        stripe_id = stripe;
+        const unsigned wg = stripe * kStripe + (jb % kStripe);
         wave_id = wg * static_cast<unsigned>(kIcpWavesPerBlock) + static_cast<unsigned>(wv);
     }
 
@@ -1358,6 +1373,13 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
 #endif
             LP_T(7);
             return;                             // (k_loop closes the workgroup's iteration itself)
+        }
+        if (P.stripe_work) {
+            // (an iteration that measures: the most points one of this wave's queries was handed -> the stripe's heaviest wave)
+            unsigned mx = valid ? npairs : 0u;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) mx = max(mx, static_cast<unsigned>(__shfl_xor(mx, d, 64)));
+            if (lane == 0) (void)__hip_atomic_fetch_max(&P.stripe_work[stripe_id], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         {
             // k_icp: the same, into this workgroup's accumulators; the last wave to arrive sends them on
@@ -2552,6 +2574,7 @@ void launch_scatter_slots(const uint32_t *idx, const Slot *vals, uint32_t n, Slo
     if (n) hipLaunchKernelGGL(k_scatter_slots, dim3((n + 255) / 256), dim3(256), 0, s, idx, vals, n, table);
 }
 
+int icp_stripes_for(int n, int lw) { return icp_blocks_for(n, lw) / SAGE_ICP_STRIPE; }
 int icp_blocks_for(int n, int lw) {
     // one wave per 64 >> lw queries, kIcpWavesPerBlock waves per workgroup, rounded up to whole
     // stripes on all 8 XCDs

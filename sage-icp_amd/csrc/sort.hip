@@ -99,4 +99,28 @@ hipError_t sort_frame(const Point4 *d_in, Point4 *d_out, int n, IcpState *st, bo
     return hipGetLastError();
 }
 
+// ---- the dispatch order of k_icp's stripes (kernels.h) ----------------------------------------------
+__global__ __launch_bounds__(256) void k_stripe_init(uint32_t *work, uint32_t *iota, unsigned n) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    work[i] = 0u;
+    iota[i] = i;
+}
+size_t stripe_sort_temp_bytes(unsigned stripes) {
+    size_t bytes = 0;
+    uint32_t *k = nullptr;
+    (void)rocprim::radix_sort_pairs_desc(nullptr, bytes, k, k, k, k, stripes, 0, 32);
+    return bytes;
+}
+void stripe_order_init(uint32_t *work, uint32_t *iota, unsigned stripes, hipStream_t s) {
+    if (stripes) hipLaunchKernelGGL(k_stripe_init, dim3((stripes + 255u) / 256u), dim3(256), 0, s, work, iota, stripes);
+}
+hipError_t stripe_order_sort(uint32_t *work, uint32_t *work_sorted, const uint32_t *iota, uint32_t *order, unsigned stripes,
+                             void *temp, size_t temp_bytes, hipStream_t s) {
+    if (!stripes) return hipSuccess;
+    hipError_t e = rocprim::radix_sort_pairs_desc(temp, temp_bytes, work, work_sorted, iota, order, stripes, 0, 32, s);
+    if (e != hipSuccess) return e;
+    return hipMemsetAsync(work, 0, sizeof(uint32_t) * stripes, s);
+}
+
 }  // namespace sageicp

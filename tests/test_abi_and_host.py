@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(sage):
     for n in names:
         assert hasattr(L, n), "libsageicp_hip.so does not export %s" % n
     assert sorted(sage.EXPORTED_SYMBOLS) == names, "python binding and header disagree"
-    assert L.sageicp_abi_version() == sage.ABI_VERSION == 3
+    assert L.sageicp_abi_version() == sage.ABI_VERSION == 4
 
 
 def test_stats_struct_layout_matches_header(sage):

@@ -257,12 +257,18 @@ def test_timeout_inside_the_launch_falls_back(gpu_sage, oracle):
         a, sa = gpu_sage.register_frame(w["scan"], w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"],
                                         return_stats=True)
     assert sa.single_launch == 1
+    s0 = w["map"].loop_status()
+    assert (s0.last_fallback, s0.timeouts, s0.cooldown_calls) == (0, 0, 0) and s0.calls_single_launch >= 1
     with Env(SAGEICP_LOOP=2, SAGEICP_LOOP_TIMEOUT_TICKS=1, SAGEICP_LOOP_COOLDOWN=2):
         b, sb = gpu_sage.register_frame(w["scan"], w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"],
                                         p["sem_th"], return_stats=True)
     assert np.array_equal(a, b)
     # (a tick is 10 ns: a wait that long never succeeds on a grid of this size)
     assert sb.single_launch == 0
+    # the handle says what happened (sageicp_map_loop_status): one launch gave up, two calls of cool-down ahead
+    s1 = w["map"].loop_status()
+    assert (s1.last_fallback, s1.timeouts, s1.cooldown_calls) == (1, 1, 2)         # SAGEICP_LOOP_FALLBACK_TIMEOUT
+    assert s1.calls_per_iteration == s0.calls_per_iteration + 1 and s1.calls_single_launch == s0.calls_single_launch
     # a map whose launch timed out stays away from k_loop for a while (here: two calls), then tries again
     with Env(SAGEICP_LOOP=2):
         forms = []
@@ -270,8 +276,8 @@ def test_timeout_inside_the_launch_falls_back(gpu_sage, oracle):
             c, sc = gpu_sage.register_frame(w["scan"], w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"],
                                             p["sem_th"], return_stats=True)
             assert np.array_equal(a, c)
-            forms.append(sc.single_launch)
-    assert forms == [0, 0, 1]
+            forms.append((sc.single_launch, w["map"].loop_status().last_fallback))
+    assert forms == [(0, 2), (0, 2), (1, 0)]                                        # ... _COOLDOWN twice, then _NONE
 
 
 def test_streamed_frames_through_the_pipeline(gpu_sage, oracle):
