@@ -1786,9 +1786,14 @@ constexpr int kLoopTimedIters = 32, kLoopTimedWgs = 2048;
 __device__ unsigned long long g_loop_wg[kLoopTimedIters][kLoopTimedWgs][4];     // counted in | pose held | a wave took a unit beyond one per wave | ... finished it
 __device__ unsigned g_loop_wginfo[kLoopTimedIters][kLoopTimedWgs][4];     // HW_ID | max points of a query | stale queries | points
 __device__ unsigned long long g_loop_solver[kLoopTimedIters][4];
+__device__ unsigned long long g_loop_solver2[kLoopTimedIters][4];      // inside the solve: after the LDL^T | the exponential | the composition | the norm
 __device__ unsigned long long g_loop_wave[kLoopTimedIters][kLoopTimedWgs][8][2];      // per wave: its FIRST unit of the iteration: end stamp | start stamp (low 32) << 32 ... see LOOP_STAMP_WAVE
 __device__ unsigned long long g_loop_phase[16];     // [0..7] cycles per body phase, [8] wait for the pose, [9] closing a workgroup, [10] group passes
 #define LOOP_STAMP_SOLVER(it, k) do { if ((it) < kLoopTimedIters && (threadIdx.x & 63u) == 0u) g_loop_solver[it][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define LOOP_STAMP_SOLVER2(it, k) do { if ((it) < kLoopTimedIters && (threadIdx.x & 63u) == 0u) g_loop_solver2[it][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" void sageicp_debug_loop_solver2(unsigned long long *out) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_loop_solver2), sizeof(unsigned long long) * kLoopTimedIters * 4);
+}
 #define LOOP_STAMP_WG(it, k) do { if ((it) < kLoopTimedIters && blockIdx.x < kLoopTimedWgs && (threadIdx.x & 63u) == 0u) g_loop_wg[it][blockIdx.x][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 extern "C" void sageicp_debug_loop_phases(unsigned long long *out, int reset) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_loop_phase), sizeof(unsigned long long) * 16);
@@ -1809,6 +1814,7 @@ extern "C" void sageicp_debug_loop_times(unsigned long long *wg, unsigned long l
 }
 #else
 #define LOOP_STAMP_SOLVER(it, k) do { } while (0)
+#define LOOP_STAMP_SOLVER2(it, k) do { } while (0)
 #define LOOP_STAMP_WG(it, k) do { } while (0)
 #endif
 
@@ -1952,7 +1958,9 @@ __device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, c
 #pragma unroll
     for (int i = 0; i < 6; ++i) neg[i] = -JTr[i];
     ldlt_solve6_t<WaveLanes>(JTJ, neg, x);
+    LOOP_STAMP_SOLVER2(it, 0);
     se3_exp_t<WaveLanes>(x, est);
+    LOOP_STAMP_SOLVER2(it, 1);
     double rhs[7], Tn[7];
     {
         const double *src = sT + (lane == 1 ? 7 : 0);      // lane 1: T_icp, the other lanes: T
@@ -1968,12 +1976,14 @@ __device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, c
     }
     double Rn[9];
     quat_to_mat(Tn, Rn);
+    LOOP_STAMP_SOLVER2(it, 2);
     double nrm = sqrt(SAGE_SQNORM6(x));
     if (!(x[3] * x[3] + x[4] * x[4] + x[5] * x[5] < 9.0) || fabs(nrm - kEstimationThreshold) < 1e-12) {
         double lg[6];                                      // see solve_and_publish
         se3_log(est, lg);
         nrm = sqrt(SAGE_SQNORM6(lg));
     }
+    LOOP_STAMP_SOLVER2(it, 3);
     const bool converged = nrm < kEstimationThreshold;
     unsigned done = (converged || it + 1 >= L.max_iterations) ? 1u : 0u;
     // (under a communicator an overflow on this rank alone must not end its loop: the peers would wait
