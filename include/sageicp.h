@@ -289,6 +289,13 @@ void sageicp_set_downsample_order(int reference_order);
  * below 40).  Inside sageicp_voxel_downsample / the pipeline such a group is emitted in arrival
  * order and a warning goes to stderr once. */
 int sageicp_robin_iteration_order(const int32_t *vox_xyz, uint64_t n, uint32_t *order_out);
+/* The far-voxel sweep of VoxelHashMap::RemovePointsFarFromLocation (core/VoxelHashMap.cpp:176-184: erase WHILE iterating the
+ * robin_map) on a table filled with the n distinct voxels in arrival order; far[i] != 0: voxel i is out of range.  listed = 0:
+ * the sweep as written (every bucket looked at); 1: the form a map whose points live in HBM uses (only the far voxels are
+ * known to the host) — the two must agree.  erased_out (capacity n): the voxels erased, in the order of their erasure;
+ * order_after (capacity n): the iteration order of what is left. */
+int sageicp_robin_sweep(const int32_t *vox_xyz, uint64_t n, const uint8_t *far, int listed, uint32_t *erased_out,
+                        uint64_t *n_erased, uint32_t *order_after, uint64_t *n_after);
 int sageicp_preprocess(const double *frame_xyzl, uint64_t n, double max_range, double min_range,
                        double label_max_range, double *out_xyzl, uint64_t *n_out, int device);
 int sageicp_voxel_downsample(const double *frame_xyzl, uint64_t n, int n_groups,

@@ -136,6 +136,7 @@ _SIGNATURES = [
     ("sageicp_map_loop_status", C.c_int, [C.c_void_p, C.c_void_p]),
     ("sageicp_set_downsample_order", None, [C.c_int]),
     ("sageicp_robin_iteration_order", C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
+    ("sageicp_robin_sweep", C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p, _u64p, C.c_void_p, _u64p]),
     ("sageicp_map_create", C.c_void_p,
      [C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]),
     ("sageicp_map_destroy", None, [C.c_void_p]),
@@ -265,6 +266,18 @@ def _d(a):
 
 def device_count():
     return int(lib().sageicp_device_count())
+
+
+def robin_sweep(vox, far, listed):
+    """sageicp_robin_sweep: (erased voxels in erasure order, iteration order of the rest)"""
+    v = np.ascontiguousarray(vox, dtype=np.int32).reshape(-1, 3)
+    f = np.ascontiguousarray(far, dtype=np.uint8)
+    n = len(v)
+    er, af = np.zeros(max(n, 1), dtype=np.uint32), np.zeros(max(n, 1), dtype=np.uint32)
+    ne, na = C.c_uint64(0), C.c_uint64(0)
+    _check(lib().sageicp_robin_sweep(v.ctypes.data_as(C.c_void_p), n, f.ctypes.data_as(C.c_void_p), 1 if listed else 0,
+                                     er.ctypes.data_as(C.c_void_p), C.byref(ne), af.ctypes.data_as(C.c_void_p), C.byref(na)))
+    return er[:ne.value].copy(), af[:na.value].copy()
 
 
 def set_downsample_order(reference_order=True):

@@ -70,6 +70,33 @@ int sageicp_robin_iteration_order(const int32_t *vox_xyz, uint64_t n, uint32_t *
 }
 
 // ---- map ----------------------------------------------------------------------------------
+int sageicp_robin_sweep(const int32_t *vox_xyz, uint64_t n, const uint8_t *far, int listed, uint32_t *erased_out,
+                        uint64_t *n_erased, uint32_t *order_after, uint64_t *n_after) {
+    if (n && (!vox_xyz || !far || !erased_out || !order_after)) return fail(SAGEICP_ERR_INVALID, "null argument");
+    if (!n_erased || !n_after) return fail(SAGEICP_ERR_INVALID, "null argument");
+    if (n >= (1ull << 27)) return fail(SAGEICP_ERR_INVALID, "too many voxels (2^27 max)");
+    sageicp::RobinTable t;
+    std::vector<uint32_t> h(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        h[i] = reference_voxel_hash(vox_xyz[3 * i], vox_xyz[3 * i + 1], vox_xyz[3 * i + 2]);
+        t.insert(h[i], static_cast<uint32_t>(i));
+    }
+    uint64_t k = 0;
+    if (listed) {
+        std::vector<std::pair<uint32_t, uint32_t>> lst;
+        for (uint64_t i = n; i-- > 0;)          // (any order: here the reverse of arrival)
+            if (far[i]) lst.emplace_back(h[i], static_cast<uint32_t>(i));
+        t.sweep_erase_listed(std::move(lst), [&](uint32_t v) { erased_out[k++] = v; });
+    } else {
+        t.sweep_erase([&](uint32_t v) { return far[v] != 0; }, [&](uint32_t v) { erased_out[k++] = v; });
+    }
+    *n_erased = k;
+    uint64_t a = 0;
+    t.for_each([&](uint32_t v) { order_after[a++] = v; });
+    *n_after = a;
+    return t.valid() ? SAGEICP_OK : fail(SAGEICP_ERR_CAPACITY, "a probe distance the replay does not model");
+}
+
 sageicp_map *sageicp_map_create(double voxel_size, double max_distance, int basic, int critical,
                                 const int *labels, int n_labels, int device) {
     if (!(voxel_size > 0.0) || basic < 0 || critical < 0 || basic + critical < 1 ||
@@ -171,6 +198,8 @@ void sageicp_map_destroy(sageicp_map *m) {
         for (void *q : aux)
             if (q) (void)hipFree(q);
         if (m->h_ctr) (void)hipHostFree(m->h_ctr);
+        if (m->h_ctr_aux) (void)hipHostFree(m->h_ctr_aux);
+        if (m->h_lists) (void)hipHostFree(m->h_lists);
         if (m->d_pc) (void)hipFree(m->d_pc);
     }
     m->sc.destroy();
@@ -185,6 +214,9 @@ static int clone_on_device(const sageicp_map *src, sageicp_map *m) {
                       static_cast<int>(h.basic_labels.size()));
     m->host.n_classes = h.n_classes;                    // (the source's size classes, whatever the environment says now)
     for (int k = 0; k < kMaxClasses; ++k) m->host.class_points[k] = h.class_points[k];
+    // (a map in reference-order mode: the bucket array lives on the host whoever holds the points — "a copy has the same array")
+    m->host.track_order = h.track_order;
+    m->host.order = h.order;
     int rc = m->sc.init(m->device);
     if (rc) return rc;
     HIPCHK(hipSetDevice(m->device));
@@ -417,8 +449,22 @@ static int pointcloud_from_device(const sageicp_map *m, double *out, uint64_t ca
         m->d_pc_cap = c;
     }
     const DevMap dm = dev_map(m);
-    HIPCHK(map_pointcloud_device(dm, m->ctr.blocks_hi, m->up.far_flag, m->up.far_sel, m->up.temp,
-                                 m->up.temp_bytes, m->d_pc, s));
+    if (m->host.track_order) {
+        // reference-order mode: the voxels in the bucket order of the host's array (VoxelHashMap.cpp:132-142), their points
+        // packed on the device in that order
+        std::vector<uint32_t> list;
+        list.reserve(m->host.order.size());
+        m->host.order.for_each([&](uint32_t b) { list.push_back(b); });
+        if ((rc = reserve_update_scratch(m, 0, list.size() + 1))) return rc;
+        uint32_t *d_list = reinterpret_cast<uint32_t *>(m->up.far_list);        // ([nb] uint2: room for the list)
+        if (!list.empty()) HIPCHK(hipMemcpyAsync(d_list, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        HIPCHK(map_pointcloud_listed(dm, d_list, static_cast<uint32_t>(list.size()), m->up.far_flag, m->up.far_sel, m->up.temp,
+                                     m->up.temp_bytes, m->d_pc, s));
+        HIPCHK(hipStreamSynchronize(s));                                         // (`list` is pageable and leaves scope)
+    } else {
+        HIPCHK(map_pointcloud_device(dm, m->ctr.blocks_hi, m->up.far_flag, m->up.far_sel, m->up.temp,
+                                     m->up.temp_bytes, m->d_pc, s));
+    }
     // The destination is the caller's pageable buffer, and under the reference's interface a FRESH
     // one every call (`std::vector<Eigen::Vector4d> Pointcloud()` returns by value: tens of MB
     // straight from mmap).  The runtime's staged copy moves 63 MB in 1.2 ms into pages that exist —

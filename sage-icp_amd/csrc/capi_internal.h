@@ -697,6 +697,19 @@ struct sageicp_map {
     mutable uint32_t *d_free = nullptr;
     mutable MapCounters *d_ctr = nullptr;
     mutable MapCounters *h_ctr = nullptr;       // pinned
+    mutable uint32_t *h_ctr_aux = nullptr;      // pinned, 16 words: what else a device update hands back (far voxels found)
+    // reference-order maps: the lists a device update exchanges with the host's bucket array (pinned)
+    mutable uint2 *h_lists = nullptr;
+    mutable size_t h_lists_cap = 0;
+    int reserve_lists(size_t n) const {
+        if (n + 2 <= h_lists_cap) return SAGEICP_OK;
+        if (h_lists) HIPCHK(hipHostFree(h_lists));
+        h_lists = nullptr; h_lists_cap = 0;
+        const size_t c = n + n / 2 + 4096;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h_lists), c * sizeof(uint2), hipHostMallocDefault));
+        h_lists_cap = c;
+        return SAGEICP_OK;
+    }
     mutable size_t d_aux_cap = 0;               // blocks the auxiliary arrays hold
     mutable bool aux_valid = false;
     mutable uint64_t aux_generation = 0;

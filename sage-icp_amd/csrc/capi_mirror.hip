@@ -230,11 +230,11 @@ int reserve_update_scratch(const sageicp_map *m, size_t n, size_t nb) {
     UpdateScratch &u = m->up;
     if (n > m->up_n) {
         const size_t c = n + n / 2 + 1024;
-        void *olds[] = {u.raw, u.w, u.keys, u.keys_alt, u.idx, u.idx_alt, u.head_slot, u.flag, u.rank, u.want};
+        void *olds[] = {u.raw, u.w, u.keys, u.keys_alt, u.idx, u.idx_alt, u.head_slot, u.flag, u.rank, u.want, u.new_list};
         for (void *q : olds)
             if (q) HIPCHK(hipFree(q));
-        u = UpdateScratch{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                          u.far_flag, u.far_sel, u.n_sel, u.temp, u.temp_bytes};
+        u.raw = u.w = nullptr; u.keys = u.keys_alt = nullptr; u.idx = u.idx_alt = u.head_slot = nullptr;
+        u.flag = u.rank = nullptr; u.want = nullptr; u.new_list = nullptr;
         m->up_n = 0;
         HIPCHK(hipMalloc(&u.raw, c * sizeof(Point4)));
         HIPCHK(hipMalloc(&u.w, c * sizeof(Point4)));
@@ -246,16 +246,20 @@ int reserve_update_scratch(const sageicp_map *m, size_t n, size_t nb) {
         HIPCHK(hipMalloc(&u.flag, (c + 1) * sizeof(UpdateEvents)));
         HIPCHK(hipMalloc(&u.rank, (c + 1) * sizeof(UpdateEvents)));
         HIPCHK(hipMalloc(&u.want, c));
+        HIPCHK(hipMalloc(&u.new_list, c * sizeof(uint2)));
         m->up_n = c;
     }
     if (nb > m->up_nb) {
         const size_t c = nb + nb / 2 + 1024;
         if (u.far_flag) HIPCHK(hipFree(u.far_flag));
         if (u.far_sel) HIPCHK(hipFree(u.far_sel));
+        if (u.far_list) HIPCHK(hipFree(u.far_list));
         u.far_flag = u.far_sel = nullptr;
+        u.far_list = nullptr;
         m->up_nb = 0;
         HIPCHK(hipMalloc(&u.far_flag, c * sizeof(uint32_t)));
         HIPCHK(hipMalloc(&u.far_sel, c * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&u.far_list, c * sizeof(uint2)));
         m->up_nb = c;
     }
     if (!u.n_sel) HIPCHK(hipMalloc(&u.n_sel, sizeof(uint32_t)));
@@ -299,6 +303,7 @@ int grow_device_blocks(const sageicp_map *m, size_t blocks, size_t keep) {
     if (!m->d_ctr) {
         HIPCHK(hipMalloc(&m->d_ctr, sizeof(MapCounters)));
         HIPCHK(hipHostMalloc(&m->h_ctr, sizeof(MapCounters), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&m->h_ctr_aux), 16 * sizeof(uint32_t), hipHostMallocDefault));
     }
     return SAGEICP_OK;
 }
@@ -471,8 +476,20 @@ int device_update(sageicp_map *m, const double *xyzl, uint64_t n, const double p
     pol.critical = h.critical;
     pol.n_labels = static_cast<int>(h.basic_labels.size());
     for (int i = 0; i < pol.n_labels; ++i) pol.labels[i] = h.basic_labels[i];
-    HIPCHK(map_update_device(dm, pol, us, static_cast<int>(n), pose, bound, s));
+    const bool ref_order = h.track_order;
+    if (!ref_order) {
+        us.new_list = nullptr;
+        us.far_list = nullptr;
+        HIPCHK(map_update_device(dm, pol, us, static_cast<int>(n), pose, bound, s));
+    } else {
+        // A map in reference-order mode: the bucket array of the reference's robin_map lives on the host (host_map.hpp,
+        // RobinTable); the device inserts and FINDS the far voxels, the host replays the new voxels (arrival order) and the
+        // erase-while-iterating sweep on that array (VoxelHashMap.cpp:166-172,176-184) — only the voxels concerned, a few
+        // thousand words across PCIe — and the device evicts what the sweep reached.
+        HIPCHK(map_update_insert_find_far(dm, pol, us, static_cast<int>(n), pose, bound, s));
+    }
     HIPCHK(hipMemcpyAsync(m->h_ctr, m->d_ctr, sizeof(MapCounters), hipMemcpyDeviceToHost, s));
+    if (ref_order) HIPCHK(hipMemcpyAsync(&m->h_ctr_aux[0], us.n_sel, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (m->h_ctr->overflow & 2u) {
         // nothing was inserted or evicted (every kernel checks the flag first)
@@ -499,6 +516,32 @@ int device_update(sageicp_map *m, const double *xyzl, uint64_t n, const double p
         for (int j = 0; j < 8; ++j) m->h_ctr->dbg_sum[j] = m->h_ctr->dbg_max[j] = 0;
     }
 #endif
+    if (ref_order) {
+        const uint32_t n_new = m->h_ctr->n_new, n_far = m->h_ctr_aux[0];
+        if ((rc = m->reserve_lists(static_cast<size_t>(n_new) + n_far))) return rc;
+        uint2 *hl = m->h_lists;
+        if (n_new) HIPCHK(hipMemcpyAsync(hl, us.new_list, n_new * sizeof(uint2), hipMemcpyDeviceToHost, s));
+        if (n_far) HIPCHK(hipMemcpyAsync(hl + n_new, us.far_list, n_far * sizeof(uint2), hipMemcpyDeviceToHost, s));
+        if (n_new || n_far) HIPCHK(hipStreamSynchronize(s));
+        RobinTable &order = const_cast<HostMap &>(h).order;
+        for (uint32_t j = 0; j < n_new; ++j) order.insert(hl[j].y, hl[j].x);                 // arrival order
+        std::vector<std::pair<uint32_t, uint32_t>> far(n_far);
+        for (uint32_t j = 0; j < n_far; ++j) far[j] = {hl[n_new + j].y, hl[n_new + j].x};
+        uint32_t *erased = reinterpret_cast<uint32_t *>(hl);        // (the lists are consumed: the erased blocks go back in their place)
+        uint32_t n_er = 0;
+        order.sweep_erase_listed(std::move(far), [&](uint32_t b) { erased[1 + n_er++] = b; });
+        erased[0] = n_er;
+        if (n_er) {
+            // far_sel <- the erased blocks in the order of their erasure (the order they go onto the free list), n_sel <- their number
+            HIPCHK(hipMemcpyAsync(us.n_sel, erased, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(us.far_sel, erased + 1, n_er * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            HIPCHK(map_evict_listed(dm, us.far_sel, us.n_sel, n_er, s));
+            HIPCHK(hipMemcpyAsync(m->h_ctr, m->d_ctr, sizeof(MapCounters), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+        } else {
+            m->h_ctr->n_far = 0;
+        }
+    }
     m->ctr = *m->h_ctr;
     m->on_device = true;
     m->cand_stale = true;

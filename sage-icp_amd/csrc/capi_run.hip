@@ -684,18 +684,6 @@ int device_update_all(sageicp_map *m, const double *xyzl, uint64_t n, const doub
                       const Point4 *d_points) {
     if (m->replicas_diverged)
         return fail(SAGEICP_ERR_INVALID, "the copies of this multi-device map diverged in an earlier failed update: Clear() it");
-    if (m->host.track_order) {
-        // a reference-order map is maintained on the host (host_map.hpp: the bucket array of the
-        // reference's robin_map is host state); the device mirror follows by dirty ranges
-        std::vector<double> pts_host;
-        if (d_points) {
-            pts_host.resize(4 * n);
-            HIPCHK(hipSetDevice(m->device));
-            if (n) HIPCHK(hipMemcpy(pts_host.data(), d_points, n * sizeof(Point4), hipMemcpyDeviceToHost));
-            xyzl = pts_host.data();
-        }
-        return sageicp_map_update_pose(m, xyzl, n, pose);
-    }
     int rc = device_update(m, xyzl, n, pose, d_points);
     if (rc || m->replicas.empty()) return rc;       // (a failed device update changes nothing on its device)
     std::vector<double> host;

@@ -86,6 +86,10 @@ struct UpdateScratch {       // device buffers sized for n points / nb blocks (c
     uint32_t *far_flag;      // [nb]
     uint32_t *far_sel;       // [nb]
     uint32_t *n_sel;         // [1]
+    // reference-order maps (host_map.hpp: the bucket array of the reference's robin_map lives on the host): what the host
+    // replays — the voxels this update created, in arrival order, and the voxels now out of range
+    uint2 *new_list;         // optional [n]: {block, the reference's 20-bit hash of the voxel} of the j-th new voxel
+    uint2 *far_list;         // optional [nb]: the same for far_sel[j]
     void *temp;
     size_t temp_bytes;
 };
@@ -100,6 +104,18 @@ void map_derive_block_of(const DevMap &M, uint32_t blocks_hi, hipStream_t s);
 // `blocks_hi_bound` >= the map's block high-water mark after the insert (grid size only).
 hipError_t map_update_device(const DevMap &M, const UpdatePolicy &P, const UpdateScratch &S, int n,
                              const double pose[7], uint32_t blocks_hi_bound, hipStream_t s);
+
+// The two halves of map_update_device for a map in reference-order mode: (1) transform + insert, then the far voxels
+// are FOUND (far_sel / n_sel / far_list) but nothing is evicted; the host decides which of them the reference's
+// erase-while-iterating sweep reaches in this frame (RobinTable::sweep_erase_listed) and (2) evicts exactly those, in
+// the order given (the order they go onto the free list).  `d_list` / `d_n`: device memory.
+hipError_t map_update_insert_find_far(const DevMap &M, const UpdatePolicy &P, const UpdateScratch &S, int n,
+                                      const double pose[7], uint32_t blocks_hi_bound, hipStream_t s);
+hipError_t map_evict_listed(const DevMap &M, const uint32_t *d_list, const uint32_t *d_n, uint32_t bound, hipStream_t s);
+// Pointcloud() in a given order of the voxels: the points of blocks list[0], list[1], ... (n_list of them) packed into
+// `out`; counts / offsets: [n_list + 1] scratch.
+hipError_t map_pointcloud_listed(const DevMap &M, const uint32_t *d_list, uint32_t n_list, uint32_t *counts, uint32_t *offsets,
+                                 void *temp, size_t temp_bytes, Point4 *out, hipStream_t s);
 
 // Pointcloud() of the HBM copy: the live points of blocks [0, blocks_hi) packed into `out` in
 // block-pool order (what HostMap::pointcloud emits).  counts / offsets: [blocks_hi + 1] scratch;

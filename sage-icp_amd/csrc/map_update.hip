@@ -36,6 +36,11 @@ struct Pose34 {
     double t[3];
 };
 
+// core/VoxelHashMap.hpp:72-77 (robin_order.hpp: reference_voxel_hash) — what the host's bucket array is keyed by
+__device__ __forceinline__ uint32_t ref_voxel_hash(int x, int y, int z) {
+    return ((1u << 20) - 1u) & (static_cast<uint32_t>(x) * 73856093u ^ static_cast<uint32_t>(y) * 19349663u ^
+                                static_cast<uint32_t>(z) * 83492791u);
+}
 __device__ __forceinline__ unsigned long long pack_key(int x, int y, int z) {
     return (static_cast<unsigned long long>(static_cast<uint32_t>(x + kKeyBias)) << 42) |
            (static_cast<unsigned long long>(static_cast<uint32_t>(y + kKeyBias)) << 21) |
@@ -217,7 +222,7 @@ struct RegionPlan {
 __global__ __launch_bounds__(256) void k_up_insert(const unsigned long long *keys, const uint32_t *idx,
                                                    int n, const Point4 *w, const uint32_t *head_slot,
                                                    const int8_t *want_in, const UpdateEvents *rank,
-                                                   DevMap M, UpdatePolicy P) {
+                                                   DevMap M, UpdatePolicy P, uint2 *new_list) {
     __shared__ unsigned long long sk[256];
     __shared__ Point4 sp[256];
     __shared__ uint8_t sc[256];
@@ -282,6 +287,7 @@ __global__ __launch_bounds__(256) void k_up_insert(const unsigned long long *key
             M.table[s].z = vz;
             reg = nreg;
             M.block_of[reg & 0x0FFFFFFFu] = b;
+            if (new_list) new_list[j] = make_uint2(b, ref_voxel_hash(vx, vy, vz));      // (j: its rank among the new voxels = arrival order)
         } else {
             const uint32_t blk = M.table[s].blk;
             b = M.block_of[blk >> 8];
@@ -459,6 +465,31 @@ __global__ __launch_bounds__(256) void k_far_apply(DevMap M, const uint32_t *sel
                   ~static_cast<unsigned long long>(removed) + 1ull);
 }
 
+__global__ __launch_bounds__(256) void k_far_keys(DevMap M, const uint32_t *sel, const uint32_t *n_sel, uint32_t bound, uint2 *far_list) {
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= bound || j >= *n_sel) return;
+    const uint32_t b = sel[j];
+    const Slot e = M.table[M.slot_of[b]];
+    far_list[j] = make_uint2(b, ref_voxel_hash(e.x, e.y, e.z));
+}
+__global__ __launch_bounds__(256) void k_pc_counts_listed(DevMap M, const uint32_t *list, uint32_t n_list, uint32_t *counts) {
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j > n_list) return;
+    uint32_t c = 0;
+    if (j < n_list) {
+        const uint32_t s = M.slot_of[list[j]];
+        if (s != kNoSlot) c = M.table[s].blk & 255u;
+    }
+    counts[j] = c;
+}
+__global__ __launch_bounds__(256) void k_pc_gather_listed(DevMap M, const uint32_t *list, uint32_t n_list, uint32_t span,
+                                                          const uint32_t *counts, const uint32_t *offsets, Point4 *out) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const uint32_t q = static_cast<uint32_t>(i / span), j = static_cast<uint32_t>(i % span);
+    if (q >= n_list || j >= counts[q]) return;
+    out[static_cast<size_t>(offsets[q]) + j] = M.pts[static_cast<size_t>(M.regions[list[q]] & 0x0FFFFFFFu) * kDevUnitPoints + j];
+}
+
 __global__ void k_far_after(MapCounters *ctr, const uint32_t *n_sel) {
     if (threadIdx.x || blockIdx.x) return;
     const uint32_t nf = *n_sel;
@@ -539,8 +570,8 @@ size_t map_update_temp_bytes(int n, int nb) {
     return std::max(std::max(a, d), std::max(b, c)) + 256;
 }
 
-hipError_t map_update_device(const DevMap &M, const UpdatePolicy &P, const UpdateScratch &S, int n,
-                             const double pose[7], uint32_t blocks_hi_bound, hipStream_t s) {
+static hipError_t update_insert(const DevMap &M, const UpdatePolicy &P, const UpdateScratch &S, int n, const double pose[7],
+                                hipStream_t s) {
     hipError_t e;
     if (n > 0) {
         Pose34 T;
@@ -567,21 +598,70 @@ hipError_t map_update_device(const DevMap &M, const UpdatePolicy &P, const Updat
                                     EventsPlus(), s);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_up_insert, dim3(grid), dim3(256), 0, s, S.keys_alt, S.idx_alt, n, S.w,
-                           S.head_slot, S.want, S.rank, M, P);
+                           S.head_slot, S.want, S.rank, M, P, S.new_list);
         hipLaunchKernelGGL(k_up_after_insert, dim3(1), dim3(64), 0, s, M, S.rank, n);
         hipLaunchKernelGGL(k_up_push_freed, dim3(1), dim3(1024), 0, s, M);
     }
+    return hipSuccess;
+}
+static hipError_t find_far(const DevMap &M, const UpdatePolicy &P, const UpdateScratch &S, const double pose[7],
+                           uint32_t blocks_hi_bound, hipStream_t s) {
+    const int gb = static_cast<int>((blocks_hi_bound + 255u) / 256u);
+    hipLaunchKernelGGL(k_far_flags, dim3(gb), dim3(256), 0, s, M, P, pose[4], pose[5], pose[6],
+                       blocks_hi_bound, S.far_flag);
+    size_t tb = S.temp_bytes;
+    return rocprim::select(S.temp, tb, rocprim::counting_iterator<uint32_t>(0), S.far_flag, S.far_sel,
+                           S.n_sel, static_cast<size_t>(blocks_hi_bound), s);
+}
+hipError_t map_evict_listed(const DevMap &M, const uint32_t *d_list, const uint32_t *d_n, uint32_t bound, hipStream_t s) {
+    if (bound == 0) return hipSuccess;
+    const int gb = static_cast<int>((bound + 255u) / 256u);
+    hipLaunchKernelGGL(k_far_apply, dim3(gb), dim3(256), 0, s, M, d_list, d_n, bound);
+    hipLaunchKernelGGL(k_far_after, dim3(1), dim3(64), 0, s, M.ctr, d_n);
+    return hipGetLastError();
+}
+
+hipError_t map_update_device(const DevMap &M, const UpdatePolicy &P, const UpdateScratch &S, int n,
+                             const double pose[7], uint32_t blocks_hi_bound, hipStream_t s) {
+    hipError_t e = update_insert(M, P, S, n, pose, s);
+    if (e != hipSuccess) return e;
     if (blocks_hi_bound > 0) {
-        const int gb = static_cast<int>((blocks_hi_bound + 255u) / 256u);
-        hipLaunchKernelGGL(k_far_flags, dim3(gb), dim3(256), 0, s, M, P, pose[4], pose[5], pose[6],
-                           blocks_hi_bound, S.far_flag);
-        size_t tb = S.temp_bytes;
-        e = rocprim::select(S.temp, tb, rocprim::counting_iterator<uint32_t>(0), S.far_flag, S.far_sel,
-                            S.n_sel, static_cast<size_t>(blocks_hi_bound), s);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_far_apply, dim3(gb), dim3(256), 0, s, M, S.far_sel, S.n_sel, blocks_hi_bound);
-        hipLaunchKernelGGL(k_far_after, dim3(1), dim3(64), 0, s, M.ctr, S.n_sel);
+        if ((e = find_far(M, P, S, pose, blocks_hi_bound, s)) != hipSuccess) return e;
+        if ((e = map_evict_listed(M, S.far_sel, S.n_sel, blocks_hi_bound, s)) != hipSuccess) return e;
     }
+    return hipGetLastError();
+}
+
+hipError_t map_update_insert_find_far(const DevMap &M, const UpdatePolicy &P, const UpdateScratch &S, int n,
+                                      const double pose[7], uint32_t blocks_hi_bound, hipStream_t s) {
+    hipError_t e = update_insert(M, P, S, n, pose, s);
+    if (e != hipSuccess) return e;
+    if (blocks_hi_bound > 0) {
+        if ((e = find_far(M, P, S, pose, blocks_hi_bound, s)) != hipSuccess) return e;
+        if (S.far_list) {
+            const int gb = static_cast<int>((blocks_hi_bound + 255u) / 256u);
+            hipLaunchKernelGGL(k_far_keys, dim3(gb), dim3(256), 0, s, M, S.far_sel, S.n_sel, blocks_hi_bound, S.far_list);
+        }
+    } else {
+        e = hipMemsetAsync(S.n_sel, 0, sizeof(uint32_t), s);
+        if (e != hipSuccess) return e;
+    }
+    return hipGetLastError();
+}
+
+hipError_t map_pointcloud_listed(const DevMap &M, const uint32_t *d_list, uint32_t n_list, uint32_t *counts, uint32_t *offsets,
+                                 void *temp, size_t temp_bytes, Point4 *out, hipStream_t s) {
+    if (n_list == 0) return hipSuccess;
+    const int gb = static_cast<int>((n_list + 1u + 255u) / 256u);
+    hipLaunchKernelGGL(k_pc_counts_listed, dim3(gb), dim3(256), 0, s, M, d_list, n_list, counts);
+    size_t tb = temp_bytes;
+    hipError_t e = rocprim::exclusive_scan(temp, tb, counts, offsets, 0u, static_cast<size_t>(n_list) + 1,
+                                           rocprim::plus<uint32_t>(), s);
+    if (e != hipSuccess) return e;
+    const uint32_t span = static_cast<uint32_t>(M.cap);
+    const uint64_t nslots = static_cast<uint64_t>(n_list) * span;
+    hipLaunchKernelGGL(k_pc_gather_listed, dim3(static_cast<unsigned>((nslots + 255) / 256)), dim3(256), 0, s, M,
+                       d_list, n_list, span, counts, offsets, out);
     return hipGetLastError();
 }
 

@@ -37,6 +37,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 namespace sageicp {
@@ -250,6 +251,38 @@ public:
             on_erase(v);
             erase_at(i);          // bucket i now holds what stood behind it; the loop moves on to i + 1
         }
+    }
+
+    // The same sweep when only the FAR entries are known (a map whose points live in HBM: the device finds the far
+    // voxels, the host owns this array): `far` = (hash, val) of every entry the predicate holds for, any order.
+    // The full sweep looks at every bucket in index order; an erase at bucket p moves the entries behind it one bucket
+    // back, and the loop goes on at p + 1 — so exactly one kind of far entry is NOT erased in this sweep: the one that
+    // stood at p + 1 and moved into p, behind the loop.  Every other entry that moved is still ahead of it.  Hence: the
+    // far entries in bucket order; one that is found behind the position the loop has reached was skipped, every
+    // other one is erased where it stands now.  (An entry cannot pass the loop the other way: bucket 0 is looked at
+    // first, before anything was erased.)  O(far entries), not O(buckets).
+    template <class E>
+    void sweep_erase_listed(std::vector<std::pair<uint32_t, uint32_t>> far, E on_erase) {
+        std::vector<std::pair<size_t, size_t>> at(far.size());          // (bucket before the sweep, index into far)
+        for (size_t k = 0; k < far.size(); ++k) at[k] = {find(far[k].first, far[k].second), k};
+        std::sort(at.begin(), at.end());
+        size_t next = 0;                                                  // the bucket the loop looks at next
+        for (const auto &pk : at) {
+            const auto &f = far[pk.second];
+            const size_t pos = find(f.first, f.second);
+            if (pos < next) continue;                                     // moved into the bucket just erased: not looked at
+            on_erase(f.second);
+            erase_at(pos);
+            next = pos + 1;
+        }
+    }
+    // the bucket of the entry (hash, val), which must be in the table
+    size_t find(uint32_t hash, uint32_t val) const {
+        const size_t mask = b_.size() - 1;
+        size_t i = hash & mask;
+        for (size_t n = 0; n < b_.size(); ++n, i = (i + 1) & mask)
+            if (b_[i] && static_cast<uint32_t>(b_[i] & kValMask) == val) return i;
+        return b_.size();
     }
 
 private:

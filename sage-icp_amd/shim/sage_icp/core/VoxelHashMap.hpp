@@ -44,10 +44,11 @@ struct VoxelHashMap {
         // The drop-in node keeps the voxels the reference keeps: RemovePointsFarFromLocation erases while it
         // iterates its robin_map (VoxelHashMap.cpp:176-184), so the entry a deletion shifts into the bucket just
         // erased survives until a later frame, and Pointcloud() lists bucket order (:132-142).  A map in
-        // reference-order mode reproduces both exactly (include/sageicp.h, sageicp_map_set_reference_order) at
-        // ~3 ms of host work per streamed frame; -DSAGE_ICP_SHIM_FAST_MAP keeps the map on the GPU instead
-        // (0.3 ms; every out-of-range voxel is removed at once, block-pool order) — poses are the same on every
-        // stream measured.
+        // reference-order mode reproduces both exactly (include/sageicp.h, sageicp_map_set_reference_order); since
+        // round 6 its Update() runs on the GPU as well — the device inserts and finds the far voxels, the host replays
+        // only the voxels concerned on its copy of the bucket array — at 0.38 ms per streamed frame against 0.25 ms
+        // for -DSAGE_ICP_SHIM_FAST_MAP (every out-of-range voxel removed at once, block-pool order); poses are the
+        // same on every stream measured.
         if (sageicp_map_set_reference_order(map_, 1) != 0) {
             const std::string why = sageicp_last_error();
             sageicp_map_destroy(map_);

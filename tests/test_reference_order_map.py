@@ -224,3 +224,61 @@ def test_random_update_sequences_against_the_oracle(sage, oracle_ref):
         assert m.reference_order() == 1
 
     run()
+
+
+@pytest.mark.gpu
+def test_random_update_sequences_on_the_device_against_the_oracle(gpu_sage, oracle_ref):
+    """the same property with Update(points, pose) on the DEVICE (sageicp_map_update_pose_device on a map in
+    reference-order mode: the device inserts and finds the far voxels, the host replays only the voxels concerned on
+    its bucket array — RobinTable::sweep_erase_listed — and the device evicts what the sweep reached): after every
+    update the map is the oracle's in mode 3, Pointcloud() byte for byte and IN ORDER, also across Clear(), jumps back
+    into evicted ground, and a switch to host-side updates and back"""
+    from hypothesis import given, settings, HealthCheck, strategies as st
+
+    @settings(max_examples=25, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(seed=st.integers(0, 2**31 - 1), vs=st.sampled_from([0.5, 1.0, 2.0]), rng_m=st.sampled_from([8.0, 20.0, 45.0]),
+           basic=st.integers(1, 6), critical=st.integers(0, 6), step=st.sampled_from([0.0, 3.0, 9.0, 25.0]),
+           n_pts=st.sampled_from([1, 40, 600, 3000]))
+    def run(seed, vs, rng_m, basic, critical, step, n_pts):
+        rng = np.random.default_rng(seed)
+        m = gpu_sage.VoxelHashMap(vs, rng_m, basic, critical, [40, 50]).set_reference_order(True)
+        om = oracle_ref.Map(vs, rng_m, basic, critical, [40, 50])
+        centre = np.zeros(3)
+        for f in range(10):
+            if f == 6 and seed % 3 == 0:
+                m.Clear(); om.clear()
+            centre = centre + [step, rng.normal() * 0.5, 0.0] if seed % 5 or f != 7 else np.zeros(3)
+            pts = _cloud(rng, n_pts, np.zeros(3), spread=rng_m * 1.2)       # in the sensor frame
+            pose = np.array([0.0, 0.0, 0.0, 1.0, centre[0], centre[1], centre[2]])
+            if f == 4 and seed % 2 == 0:
+                m.Update(oracle_ref.transform_points(pose, pts), centre)    # (a host-side update in between)
+            else:
+                m.UpdateOnDevice(pts, pose)
+            om.update(pts, pose)
+            assert m.size() == om.size() and m.num_voxels() == om.num_voxels(), "frame %d" % f
+            assert np.array_equal(m.Pointcloud(), om.pointcloud()), "frame %d" % f
+        assert m.reference_order() == 1
+
+    run()
+
+
+@pytest.mark.gpu
+def test_copy_of_a_device_resident_reference_order_map(gpu_sage, oracle_ref):
+    """the copy of a map keeps its mode and its bucket array (OdometryServer.cpp:104 copy-assigns the
+    pipeline), also when the points live in HBM: the copy lists the same Pointcloud() and goes on exactly like the original"""
+    rng = np.random.default_rng(77)
+    m = gpu_sage.VoxelHashMap(1.0, 25.0).set_reference_order(True)
+    om = oracle_ref.Map(1.0, 25.0)
+    pose = lambda c: np.array([0.0, 0.0, 0.0, 1.0, c, 0.0, 0.0])          # noqa: E731
+    for f in range(4):
+        pts = _cloud(rng, 4000, np.zeros(3), spread=30.0)
+        m.UpdateOnDevice(pts, pose(6.0 * f))
+        om.update(pts, pose(6.0 * f))
+    c = m.clone()
+    assert c.reference_order() == 1 and np.array_equal(c.Pointcloud(), om.pointcloud())
+    for f in range(4, 7):
+        pts = _cloud(rng, 4000, np.zeros(3), spread=30.0)
+        for x in (m, c):
+            x.UpdateOnDevice(pts, pose(6.0 * f))
+        om.update(pts, pose(6.0 * f))
+        assert np.array_equal(c.Pointcloud(), om.pointcloud()) and np.array_equal(m.Pointcloud(), om.pointcloud())

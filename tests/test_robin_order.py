@@ -231,3 +231,25 @@ def test_product_replay_refuses_what_it_does_not_model(sage):
     assert L.sageicp_robin_iteration_order(keys.ctypes.data, len(keys), out.ctypes.data) == sage.ERR_CAPACITY
     assert b"probe distance" in L.sageicp_last_error()
     assert L.sageicp_robin_iteration_order(keys.ctypes.data, 100, out.ctypes.data) == 0      # 100 in a row is fine
+
+
+@pytest.mark.parametrize("seed,n,spread,p_far", [(1, 300, 6, 0.5), (2, 5000, 20, 0.1), (3, 5000, 12, 0.6), (4, 40000, 40, 0.03),
+                                                 (5, 2000, 8, 1.0), (6, 7, 2, 0.5), (7, 20000, 25, 0.3)])
+def test_listed_sweep_equals_the_sweep_as_written(sage, seed, n, spread, p_far):
+    """a map whose points live in HBM knows only WHICH voxels are far (the device finds them); its host-side bucket array
+    must then erase — and skip — exactly what the reference's erase-while-iterating sweep does (VoxelHashMap.cpp:176-184):
+    RobinTable::sweep_erase_listed against sweep_erase, erasure order and the order of what is left"""
+    rng = np.random.default_rng(seed)
+    vox = np.unique(rng.integers(-spread, spread + 1, size=(3 * n, 3)), axis=0)
+    rng.shuffle(vox)
+    vox = vox[:n]
+    far = (rng.random(len(vox)) < p_far).astype(np.uint8)
+    # clustered far sets as a real sweep sees them: everything beyond a radius
+    if seed % 2 == 0:
+        far = (np.linalg.norm(vox, axis=1) > 0.7 * spread).astype(np.uint8)
+    e0, a0 = sage.robin_sweep(vox, far, listed=False)
+    e1, a1 = sage.robin_sweep(vox, far, listed=True)
+    assert np.array_equal(e0, e1) and np.array_equal(a0, a1)
+    assert len(e0) + len(a0) == len(vox) and set(e0.tolist()) <= set(np.flatnonzero(far).tolist())
+    if far.sum() > 50 and far.mean() > 0.2:
+        assert len(e0) < far.sum()           # (the sweep does skip some: the behaviour under test exists)
