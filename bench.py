@@ -61,6 +61,10 @@ def parse():
                          "value = frames of all ranks per second, scaling weak")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="CPU time budget of the cpu_baseline sample")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "direct", "rccl"],
+                    help="N > 1, query-sharded: how the ranks' Gauss-Newton sums meet — 'direct' (stores over xGMI into HIP-IPC "
+                         "mapped blocks, inside the solving wave / k_fin), 'rccl' (ncclAllReduce between two k_fin launches), "
+                         "'auto' (direct when every rank can set it up and it passes its cross-check against RCCL, else RCCL)")
     ap.add_argument("--no-profile-events", action="store_true",
                     help="do not record per-kernel HIP events in the timed region")
     return ap.parse_args()
@@ -364,7 +368,7 @@ def main():
     if use_dist and args.independent:
         exchange = "none: independent frames, one per rank"
     elif use_dist:
-        have_rccl = backend == "nccl" and os.environ.get("SAGEICP_NO_RCCL", "0") != "1"
+        have_rccl = backend == "nccl" and os.environ.get("SAGEICP_NO_RCCL", "0") != "1" and args.exchange != "direct"
         if have_rccl:
             ids = [sage.Comm.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
@@ -374,7 +378,9 @@ def main():
             comm = sage.Comm(None, rank, world, local_dev)
         # Direct exchange over xGMI (HIP IPC): preferred when every rank can set it up, RCCL
         # otherwise (SAGEICP_NO_P2P=1 forces RCCL).
-        if os.environ.get("SAGEICP_NO_P2P", "0") != "1" and world <= 8:
+        if args.exchange == "rccl" and not have_rccl:
+            raise SystemExit("--exchange rccl: no RCCL side (backend %s)" % backend)
+        if os.environ.get("SAGEICP_NO_P2P", "0") != "1" and args.exchange != "rccl" and world <= 8:
             try:
                 mine = comm.p2p_export()
             except Exception as e:                  # noqa
@@ -543,6 +549,19 @@ def main():
                 os.environ["SAGEICP_LOOP"] = loop_env
             sage.set_profiling(0)
 
+    # what every rank ran, for the line: the form of the loop in the timed frames and what its map handle says about fall-backs
+    ls = vmap.loop_status()
+    mine = {"rank": rank,
+            "loop_form": "one launch" if all(st.single_launch for st in stats) else
+                         ("launch per iteration" if not any(st.single_launch for st in stats) else "mixed"),
+            "lanes_per_query": int(stats[-1].lanes_per_query), "queries": int(hi - lo),
+            "calls_single_launch": int(ls.calls_single_launch), "calls_per_iteration": int(ls.calls_per_iteration),
+            "loop_timeouts": int(ls.timeouts), "last_fallback": int(ls.last_fallback)}
+    per_rank = [mine]
+    if use_dist:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+
     if rank != 0:
         if use_dist:
             dist.barrier()
@@ -696,6 +715,8 @@ def main():
                    "rccl_ranks": None if comm is None else comm.describe()["rccl_ranks"],
                    "comm": None if comm is None else comm.describe(),
                    "exchange_cross_check": cross_check,
+                   "exchange_requested": args.exchange,
+                   "per_rank": per_rank,
                    "iteration_breakdown": breakdown,
                    "scan_points": len(scan), "map_points": vmap.size(),
                    "map_voxels": vmap.num_voxels(), "iterations_per_frame": iters,

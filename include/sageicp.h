@@ -221,6 +221,8 @@ int sageicp_register_frame_resident(const sageicp_map *map, const sageicp_frame 
 #define SAGEICP_LOOP_FALLBACK_COOLDOWN 2         /* the call fell into the cool-down after such a time-out */
 #define SAGEICP_LOOP_FALLBACK_DOES_NOT_FIT 3     /* the frame needs more LDS than the machine has (~170k points), or the form is
                                                   * switched off (SAGEICP_LOOP=0), or the call runs under an RCCL communicator */
+#define SAGEICP_LOOP_FALLBACK_PEER 4             /* multi-GPU: another rank's one-launch loop timed out; every rank left the same
+                                                  * exchange with it and registered the frame again, in step */
 typedef struct sageicp_loop_status {
     uint64_t calls_single_launch;       /* registrations of this handle that ran in one launch */
     uint64_t calls_per_iteration;       /* ... through the launch-per-iteration form */

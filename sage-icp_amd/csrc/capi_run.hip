@@ -92,6 +92,9 @@ static bool wants_flat(const sageicp_map *m, int lw) {
 // (raised while a frame whose sums left the range of the fixed-point accumulators is registered again at a
 // coarser scale: the sums are accumulated at 2^(-24 g_acc_shift) of their value — see the end of run_icp)
 static thread_local int g_acc_shift = 0;
+// (a frame started again because a peer rank left its one-launch loop: see the end of run_icp)
+static thread_local int g_restarts = 0;
+static thread_local bool g_no_loop = false;
 
 // k_icp's arguments for a search of `n` queries against the HBM copy of `m`
 IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, double sem_th, int lw) {
@@ -328,11 +331,12 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     // (SAGEICP_CHUNKED=1 asks for the chunked launch-per-iteration loop by name)
     const bool loop_shape = (!comm || (p2p && !comm->device_shared && env_int("SAGEICP_CHUNKED", 0) == 0)) &&
                             plan_loop(m, n, sem_th, &plan);
+    const bool restarted = g_no_loop;          // (lanes per query as the plan says; the loop form not again for this frame)
     const int lw = loop_shape ? plan.lw : icp_lw(n, sparse_voxels(m));
     // a launch that timed out (its grid was not resident as a whole: the GPU is shared with other work)
     // cost 50 ms before the frame went through the other loop: the next calls do not try again
-    bool use_loop = loop_shape;
-    sc.last_fallback = loop_shape ? SAGEICP_LOOP_FALLBACK_NONE : SAGEICP_LOOP_FALLBACK_DOES_NOT_FIT;
+    bool use_loop = loop_shape && !restarted;
+    sc.last_fallback = !loop_shape ? SAGEICP_LOOP_FALLBACK_DOES_NOT_FIT : (restarted ? SAGEICP_LOOP_FALLBACK_PEER : SAGEICP_LOOP_FALLBACK_NONE);
     if (use_loop && sc.loop_cooldown > 0) {
         --sc.loop_cooldown;
         use_loop = false;
@@ -408,8 +412,12 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
             L.timeout_ticks = static_cast<unsigned long long>(ticks);
         // (under a communicator the workgroups wait for a pose that waits for the peers' sums: their patience has
         // to outlast the exchange's — a peer's first launches of a process can take a second)
+        L.count_timeout_ticks = L.timeout_ticks;       // (the solving wave's wait for its own workgroups: local, short)
         if (comm && env_int("SAGEICP_LOOP_TIMEOUT_TICKS", 0) == 0)
             L.timeout_ticks = std::max(L.timeout_ticks, xp.timeout_ticks + 100000000ull);
+        // (tests: ONE rank of a communicator loses its grid — the others must follow it out of the launch)
+        if (comm && env_int("SAGEICP_LOOP_COUNT_TIMEOUT_RANK", -1) == comm->rank)
+            L.count_timeout_ticks = static_cast<unsigned long long>(std::max(1, env_int("SAGEICP_LOOP_COUNT_TIMEOUT_TICKS", 1)));
         L.max_iterations = max_it;
         L.epoch = ++sc.loop_epoch;
         for (int i = 0; i < 7; ++i) L.T0[i] = init[i];
@@ -467,8 +475,13 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
             // a wait inside the launch timed out (the grid was not resident as a whole: another stream
             // or process held CUs): the launch-per-iteration loop below registers the frame instead,
             // with the same lanes per query
+            if (sc.h_state->peer_aborted) {
+                // not this rank's grid: a peer lost its one-launch loop and every rank left the same exchange with it
+                // (sageicp_types.h, P2pBlock::abort_tag) — this frame goes through the other form on every rank, in step; no cool-down here
+                sc.last_fallback = SAGEICP_LOOP_FALLBACK_PEER;
+            } else {
             sc.loop_cooldown = std::max(0, env_int("SAGEICP_LOOP_COOLDOWN", 256));
-            if (env_int("SAGEICP_LOOP_TIMEOUT_TICKS", 0) == 0 && sc.loop_derate < 16) ++sc.loop_derate;
+            if (env_int("SAGEICP_LOOP_TIMEOUT_TICKS", 0) == 0 && env_int("SAGEICP_LOOP_COUNT_TIMEOUT_RANK", -1) < 0 && sc.loop_derate < 16) ++sc.loop_derate;
             ++sc.loop_timeouts;
             sc.last_fallback = SAGEICP_LOOP_FALLBACK_TIMEOUT;
             {
@@ -480,13 +493,9 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
                                          "loop, the next %d calls of this map too, later plans take %d workgroups fewer "
                                          "(sageicp_map_loop_status() reports the state)\n", sc.loop_cooldown, 32 * sc.loop_derate);
             }
-            if (comm) {
-                // (the peers are somewhere inside their loops: there is no starting again in step)
-                comm->p2p = false;
-                comm->poisoned = true;
-                return fail(SAGEICP_ERR_RCCL, "one-launch loop under a communicator: a wait inside the launch timed out "
-                                              "(the GPU is shared with other work?); SAGEICP_LOOP=0 selects the launch-per-iteration loop");
             }
+            // (under a communicator the solving wave told the peers through the exchange it was about to make: they left
+            // it with this rank, the exchange counts as made on every rank, and all of them register the frame again below)
             fill_state(sc.h_state, init);
             if (polled) {
                 std::memset(sc.h_prog, 0, sizeof(IcpProgress));
@@ -627,6 +636,16 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         }
     }
     const IcpState &st = *sc.h_state;
+    if (st.peer_aborted && !looped && comm && g_restarts < 4) {
+        // a peer gave up its one-launch loop at an exchange this rank made from k_fin: every rank starts the frame again
+        // (this one in the form it already had)
+        ++g_restarts;
+        g_no_loop = true;
+        const int rc2 = run_icp(m, d_frame, n, init, max_dist, kernel, sem_th, comm, out, stats, us_upload, t_begin);
+        g_no_loop = false;
+        --g_restarts;
+        return rc2;
+    }
     if (st.bad_input)
         return fail(SAGEICP_ERR_INVALID, "the frame holds a coordinate or label that is not finite (NaN / Inf)");
     if (st.acc_overflow && !comm && g_acc_shift < 2) {

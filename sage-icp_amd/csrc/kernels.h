@@ -175,6 +175,8 @@ struct LoopParams {
                                    // groups [xcd_first[x], xcd_first[x + 1]) of the (spatially sorted) frame
     uint32_t xcd_first[9];
     unsigned long long timeout_ticks;      // s_memrealtime ticks (100 MHz) any wait may take
+    unsigned long long count_timeout_ticks;    // ... the solving wave's wait for its own workgroups' sums (the same, except
+                                           // under a communicator: timeout_ticks then also covers the peers' exchange)
     int max_iterations;            // kMaxIterations (tests: fewer)
     unsigned long long epoch;      // identifies this call: the solving wave is launched FIRST (it must be resident when the
                                    // grid fills the machine) and waits for LoopShared::go to carry this number

@@ -1706,6 +1706,9 @@ __device__ __forceinline__ void exchange_sums(IcpState *st, const P2pParams &X) 
                 break;
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        // a peer gave up its one-launch loop at this exchange (P2pBlock::abort_tag)
+        if (__hip_atomic_load(&mine->abort_tag[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == tag) s_late = 2;
     }
     __syncthreads();
     if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
@@ -1718,7 +1721,10 @@ __device__ __forceinline__ void exchange_sums(IcpState *st, const P2pParams &X) 
     }
     if (t == 0) {
         *X.exchanges = tag;
-        if (s_late) {                          // stop the loop; the host reports the failure
+        if (s_late == 2) {                     // every rank leaves this exchange and starts the frame again (run_icp)
+            st->peer_aborted = 1;
+            st->done = 1;
+        } else if (s_late) {                   // stop the loop; the host reports the failure
             st->exchange_failed = 1;
             st->done = 1;
         }
@@ -1827,8 +1833,9 @@ __device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long lo
 
 // exchange_sums for ONE wave (the solving wave of k_loop_solve): S (LDS) holds this rank's sums on entry
 // and the sums over all ranks, added in rank order, on exit; `g` is the exchange counter (the same on
-// every rank).  Returns false when a peer's sums did not arrive in time.
-__device__ __forceinline__ bool exchange_sums_wave(double *S, const P2pParams &X, unsigned long long g) {
+// every rank).  Returns 0, 1 when a peer's sums did not arrive in time, 2 when a peer gave up its one-launch loop at
+// this exchange (P2pBlock::abort_tag).
+__device__ __forceinline__ int exchange_sums_wave(double *S, const P2pParams &X, unsigned long long g) {
     const int lane = static_cast<int>(threadIdx.x & 63u);
     const int slot = static_cast<int>(g & 1ull);
     const unsigned long long tag = g + 1ull;
@@ -1844,7 +1851,7 @@ __device__ __forceinline__ bool exchange_sums_wave(double *S, const P2pParams &X
         for (int r = 0; r < X.nranks; ++r)
             __hip_atomic_store(&X.block[r]->flag[X.rank], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     P2pBlock *mine = X.block[X.rank];
-    bool late = false;
+    bool late = false, gone = false;
     if (lane < X.nranks) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while (__hip_atomic_load(&mine->flag[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < tag) {
@@ -1854,8 +1861,11 @@ __device__ __forceinline__ bool exchange_sums_wave(double *S, const P2pParams &X
                 break;
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        gone = __hip_atomic_load(&mine->abort_tag[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == tag;
     }
     late = __any(late);
+    gone = __any(gone);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     if (lane < kNumSums) {
         double s = 0.0;
@@ -1864,7 +1874,22 @@ __device__ __forceinline__ bool exchange_sums_wave(double *S, const P2pParams &X
         S[lane] = s;
     }
     __builtin_amdgcn_wave_barrier();
-    return !late;
+    return gone ? 2 : (late ? 1 : 0);
+}
+// This rank leaves its one-launch loop at exchange `g` (a wait inside the launch timed out): the peers are told through
+// the flag of that exchange, so that everybody leaves it together.
+__device__ __forceinline__ void exchange_abort_wave(const P2pParams &X, unsigned long long g) {
+    const int lane = static_cast<int>(threadIdx.x & 63u);
+    if (lane == 0)
+        for (int r = 0; r < X.nranks; ++r)
+            __hip_atomic_store(&X.block[r]->abort_tag[X.rank], g + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0)          // ... and the flag of the exchange, so that nobody waits for this rank's sums
+        for (int r = 0; r < X.nranks; ++r)
+            __hip_atomic_store(&X.block[r]->flag[X.rank], g + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // One iteration's finish by the solving wave (all 64 lanes, uniform data).  Returns the value of the
@@ -1906,12 +1931,21 @@ __device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, c
             if (__all(ok)) break;
             unsigned long long ab = 0ull;
             if (lane == 0) ab = ld_agent(&sh->abort_word[0]);
-            const bool late = __builtin_amdgcn_s_memrealtime() - t0 > L.timeout_ticks;
+            // (its own workgroups' counts are a local matter: the short wait also under a communicator, where the
+            // workgroups' patience — timeout_ticks — has to outlast the exchange with the peers)
+            const bool late = __builtin_amdgcn_s_memrealtime() - t0 > L.count_timeout_ticks;
             if (__any(ab != 0ull) || late) {
                 if (lane == 0) {
                     st_agent(&sh->abort_word[0], 1ull);
                     st->loop_aborted = 1;
                     st_agent(&sh->pose[24], (tag << 32) | 2ull);
+                }
+                if (X.nranks > 1) {
+                    // the peers are inside (or on their way to) this very exchange: they leave it with us, and every
+                    // rank registers the frame again through the launch-per-iteration form, in step (run_icp)
+                    exchange_abort_wave(X, xg);
+                    xg += 1ull;
+                    if (lane == 0) *X.exchanges = xg;
                 }
                 return 2u;
             }
@@ -1947,9 +1981,20 @@ __device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, c
     // 2. multi-GPU: this rank's sums -> the sums over all ranks (direct exchange over xGMI, P2pBlock)
     bool exchange_failed = false;
     if (X.nranks > 1) {
-        exchange_failed = !exchange_sums_wave(S, X, xg);
+        const int ex = exchange_sums_wave(S, X, xg);
         xg += 1ull;
         if (lane == 0) *X.exchanges = xg;
+        exchange_failed = ex == 1;
+        if (ex == 2) {
+            // a peer gave up its one-launch loop at this exchange: so does this rank (its workgroups see the abort word)
+            if (lane == 0) {
+                st_agent(&sh->abort_word[0], 1ull);
+                st->loop_aborted = 1;
+                st->peer_aborted = 1;
+                st_agent(&sh->pose[24], (tag << 32) | 2ull);
+            }
+            return 2u;
+        }
     }
 
     // 3. solve, compose, test (Registration.cpp:92-93,135-137) — as k_fin's solve_and_publish

@@ -136,6 +136,11 @@ constexpr int kMaxRanks = 8;
 struct P2pBlock {
     unsigned long long flag[kMaxRanks];            // written by rank i: the tag of its last exchange
     double sums[2][kMaxRanks][kNumSums];
+    // written by rank i: the tag of the exchange at which it last GAVE UP its one-launch loop (a wait inside the launch
+    // timed out): nobody's sums of that exchange are used, every rank counts it as made and registers the frame again
+    // through the launch-per-iteration form.  Its own word, never overwritten by the tags of later exchanges: a peer that
+    // looks late still finds it (a rank cannot give up twice before every peer has been through the first).
+    unsigned long long abort_tag[kMaxRanks];
 };
 struct P2pParams {
     int nranks, rank;
@@ -153,7 +158,8 @@ struct IcpState {
     int32_t iter;       // iterations completed
     int32_t done;       // 1: converged or hit kMaxIterations -> later launches are no-ops
     int32_t converged;
-    uint32_t pad0_;
+    int32_t peer_aborted;           // multi-GPU: a peer left its one-launch loop (a wait timed out there) and said so through the
+                                    // exchange: every rank leaves the same exchange and registers the frame again, in step
     double sums[kNumSums];          // last reduced GN sums (diagnostics / multi-GPU exchange)
     unsigned long long sum_candidates;  // sum over launches and queries of C_q (roofline bytes)
     unsigned long long sum_pairs;       // (query, candidate) pairs k_icp actually scanned

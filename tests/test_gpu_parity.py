@@ -793,6 +793,46 @@ def test_direct_exchange_between_two_processes(gpu_sage, tmp_path, chunked):
         assert "one launch" in br["loop_form"] and br["iteration_us"] > 1.0
 
 
+def test_one_rank_loses_its_one_launch_loop_and_all_ranks_follow_in_step(gpu_sage):
+    """under a communicator a k_loop wait that timed out used to be a hard error that poisoned the
+    communicator.  Now the rank that gives up says so through the exchange it was about to make (P2pBlock::abort_tag),
+    every rank leaves that exchange with it and registers the frame again through the launch-per-iteration form — same
+    lanes per query, same bits: two processes on the one GPU, rank 1's solving wave gives its own workgroups 10 ns
+    (SAGEICP_LOOP_COUNT_TIMEOUT_RANK=1) in every frame; the run ends normally with the registration of an untroubled run,
+    and the line says what happened on which rank"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SAGEICP_BENCH_DEVICE="0", SAGEICP_BENCH_BACKEND="gloo", SAGEICP_P2P_TIMEOUT_S="5",
+               MASTER_ADDR="127.0.0.1", SAGEICP_LOOP_COOLDOWN="0")
+    common = ["--steps", "2", "--warmup", "1", "--scale", "0.1", "--no-cpu-baseline"]
+
+    def two_ranks(extra, port):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                            "--gpus", "2", "--exchange", "direct"] + common,
+                           capture_output=True, text=True, env=dict(env, **extra), timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads(r.stdout.strip().splitlines()[-1]), r.stderr
+
+    good, _ = two_ranks({}, 29541)
+    hurt, err = two_ranks({"SAGEICP_LOOP_COUNT_TIMEOUT_RANK": "1", "SAGEICP_LOOP_COUNT_TIMEOUT_TICKS": "1"}, 29543)
+    assert [r["loop_form"] for r in good["config"]["per_rank"]] == ["one launch", "one launch"]
+    assert good["config"]["exchange"] == hurt["config"]["exchange"] == "direct"
+    # every frame of the troubled run went through the launch-per-iteration form on BOTH ranks: rank 1 because its own launch
+    # gave up (TIMEOUT = 1), rank 0 because its peer said so (PEER = 4)
+    pr = {r["rank"]: r for r in hurt["config"]["per_rank"]}
+    assert pr[0]["loop_form"] == pr[1]["loop_form"] == "launch per iteration"
+    assert pr[1]["loop_timeouts"] >= 3 and pr[1]["last_fallback"] == 1
+    assert pr[0]["loop_timeouts"] == 0 and pr[0]["last_fallback"] == 4
+    assert "timed out" in err
+    # ... and registered the frame exactly as the untroubled run did
+    assert hurt["config"]["iterations_per_frame"] == good["config"]["iterations_per_frame"]
+    assert hurt["config"]["converged"] and hurt["config"]["pose_error_vs_planted"] == good["config"]["pose_error_vs_planted"]
+    assert hurt["config"]["correspondences_first_last"] == good["config"]["correspondences_first_last"]
+
+
 def test_bench_independent_frames_mode(gpu_sage):
     """bench.py --independent (the throughput curve of BASELINE config 5): two ranks on the one GPU
     of the box, each registering the whole frame against its own map, no exchange: weak scaling,
