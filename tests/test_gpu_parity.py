@@ -1024,6 +1024,21 @@ def test_big_frame_at_utm_coordinates_does_not_wrap_the_accumulators(gpu_sage, o
     assert np.abs(moved[:, :3] - (frame[:2000, :3] - plant[:3])).max() < 1e-2       # (stops at |step| < 1e-4 with a lever of 4e6 m)
 
 
+def test_association_decider_scene(gpu_sage, oracle):
+    """tests/sqnorm3_decider.py (the scene that settles SAGE_SQNORM3_ORDER wherever the reference builds): the product
+    returns the neighbour its build's association keeps — the oracle's of the same build, the one the construction predicts"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from sqnorm3_decider import decider_scene
+    pts, qs, picks = decider_scene()
+    a, b = both_maps(gpu_sage, oracle, pts)
+    _, tgt, idx = a.GetCorrespondences(qs, 1.0, 0.4, with_index=True)
+    _, otgt, oidx = b.get_correspondences(qs, 1.0, 0.4, with_index=True)
+    assert np.array_equal(idx, oidx) and np.array_equal(tgt, otgt) and len(tgt) == len(qs)
+    got = [int(np.flatnonzero((pts == t).all(1))[0]) for t in tgt]
+    assert got == picks[oracle.SQNORM3_ORDER].tolist()
+
+
 def test_counters_can_be_switched_off(gpu_sage, oracle):
     """sageicp_set_counting(0): a call that returns statistics no longer counts candidates and pairs (what bench.py's
     timed region does: the C++ shim's calls never count) — same pose to the bit, the other statistics unchanged"""

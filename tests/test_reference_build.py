@@ -39,6 +39,26 @@ def test_recipe_is_committed_and_names_the_reference_sources_unmodified():
     assert "oracle/_ref/" in open(os.path.join(ROOT, ".gitignore")).read()
 
 
+def test_decider_scene_separates_the_two_associations():
+    """(always runs) tests/sqnorm3_decider.py: the oracle built with SAGE_SQNORM3_ORDER=2 and the one built with 0 return
+    DIFFERENT nearest neighbours on it, the ones the construction predicts — so the reference's answer on this scene
+    (test_reference_settles_the_association below, where it can be built) names the build that is right"""
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import numpy as np, oracle; from sqnorm3_decider import decider_scene\n"
+            "pts, qs, picks = decider_scene(); m = oracle.Map(1.0, 100.0); m.add_points(pts)\n"
+            "src, tgt, idx = m.get_correspondences(qs, 1.0, 0.4, nthreads=1, with_index=True)\n"
+            "assert len(tgt) == len(qs)\n"
+            "got = [int(np.flatnonzero((pts == t).all(1))[0]) for t in tgt]\n"
+            "print(oracle.SQNORM3_ORDER, got == picks[oracle.SQNORM3_ORDER].tolist())\n") % (ROOT, os.path.join(ROOT, "tests"))
+    out = {}
+    for order in ("2", "0"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SAGE_SQNORM3_ORDER=order), capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[order] = r.stdout.split()
+    assert out["2"] == ["2", "True"] and out["0"] == ["0", "True"]
+
+
 @pytest.fixture(scope="module")
 def ref():
     if not os.path.isdir(REF):
@@ -105,5 +125,29 @@ def test_oracle_against_the_reference_build(ref, name, scale, params):
             assert m == om.size() and np.array_equal(pc[:m], om.pointcloud())
         finally:
             oracle.set_robin_order(0)
+    finally:
+        ref.ref_map_destroy(rm)
+
+
+def test_reference_settles_the_association(ref):
+    """ONE command where Eigen exists: which nearest neighbour does the reference's GetCorrespondences return on the decider
+    scene?  The default build (SAGE_SQNORM3_ORDER=2: Eigen 3.4's packet reduction, derived) must be the one that agrees —
+    otherwise set the switch to 0 in sageicp_types.h / sage_oracle.cpp (one line each) and the suite is the reference's."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from sqnorm3_decider import decider_scene
+    pts, qs, picks = decider_scene()
+    rm = ref.ref_map_create(1.0, 100.0, 20, 20, _ptr(LABELS), len(LABELS))
+    try:
+        pts = np.ascontiguousarray(pts)
+        qs = np.ascontiguousarray(qs)
+        ref.ref_map_add_points(rm, _ptr(pts), len(pts))
+        src, tgt = np.zeros_like(qs), np.zeros_like(qs)
+        n = ref.ref_get_correspondences(rm, _ptr(qs), len(qs), 1.0, 0.4, _ptr(src), _ptr(tgt))
+        assert n == len(qs)
+        got = np.array([int(np.flatnonzero((pts == t).all(1))[0]) for t in tgt[:n]])
+        is2, is0 = bool(np.array_equal(got, picks[2])), bool(np.array_equal(got, picks[0]))
+        assert is2 or is0, "the reference follows neither association on every case: %s" % got
+        assert is2, "the reference adds x^2 + (y^2 + z^2): build oracle and product with SAGE_SQNORM3_ORDER=0"
     finally:
         ref.ref_map_destroy(rm)
