@@ -265,8 +265,11 @@ static bool plan_loop(const sageicp_map *m, uint64_t n, double sem_th, LoopPlan 
         // ... and fewer once the units outnumber the waves the machine holds (7 per SIMD less the residency margin):
         // a second pass of some waves costs more than a longer chain in everybody's first — 60k queries against
         // dense voxels: 24.5 us per iteration with four lanes, 26.0 with eight; 30k: 21.7 / 19.6 (profiles/r05)
+        // (round 6, second scene family — profiles/r06/ring_probe.txt: 52k queries of ring geometry, 6,592 units at eight
+        // lanes on 6,656 waves: four lanes 3 % faster; the first family's 60k: 24.5 against 26.0 — the switch sits at four
+        // fifths of the resident waves, ~42k queries)
         const uint64_t resident_waves = 4ull * SAGE_LOOP_OCC * cus * 15 / 16;
-        while (lw > 2 && groups_at(lw) > resident_waves) --lw;
+        while (lw > 2 && groups_at(lw) > resident_waves * 4 / 5) --lw;
     }
     const bool dbg = env_int("SAGEICP_LOOP_DEBUG", 0) != 0;
     bool ok = !env_gpw && one_pass(lw, env_nw ? env_nw : 4, out);

@@ -293,3 +293,185 @@ def make_stream(seed, n_frames, points_per_frame=30000, half=120.0, step=(1.0, 0
                       a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2]])
         T = np.concatenate([q / np.linalg.norm(q), t])
     return frames, poses
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# A second scene family (round 6): the same street, but SEEN as a spinning 64-beam sensor sees it — rays cast from the
+# sensor, so the density of a scan falls with range ring by ring, surfaces are occluded, and a map built from such scans
+# is dense near the driven path and thin far from it.  (sample_surfaces / make_scan draw points on the surfaces directly,
+# thinned by a range rule: every surface is seen from everywhere.)  Used to check that the library's break-points (lanes per
+# query, compact-scan filter, flat order: capi_internal.h::icp_lw, capi_run.hip::wants_filter / wants_flat) — measured on
+# the first family — hold on scans of LiDAR geometry: profiles/README.md, tests/test_gpu_parity.py.
+def _blob_cells(lo, hi):
+    """the vegetation blobs of sample_surfaces whose 16-m grid cells intersect [lo, hi]^2: (cx, cy) arrays"""
+    g = np.arange(np.floor(lo / 16.0), np.floor(hi / 16.0) + 1.0)
+    gx, gy = np.meshgrid(g, g, indexing="ij")
+    gx, gy = gx.ravel(), gy.ravel()
+    h = (gx * 73856093.0 + gy * 19349663.0) % 1024.0
+    cx = gx * 16.0 + 4.0 + (h % 32.0) / 4.0
+    cy = gy * 16.0 + 4.0 + (np.floor(h / 32.0)) / 4.0
+    off = _road_offset(cy)
+    cy = np.where(np.abs(off) < 20.0, cy + np.sign(off + 1e-9) * (20.0 - np.abs(off)), cy)
+    return cx, cy
+
+
+def make_ring_scan(rng, T, beams=64, az_steps=2048, max_range=100.0, min_range=5.0, label_max_range=50.0,
+                   elev_deg=(2.0, -24.8), dropout=0.02):
+    """One revolution of a 64-beam sensor (HDL-64E geometry: beams from +2 to -24.8 degrees, `az_steps` firings per turn)
+    at pose T in the street scene, by ray casting: ground strips, building walls, fences, poles, trunks, vegetation blobs
+    (spheres), parked cars (boxes) — nearest hit per ray.  Returns the hits in the SENSOR frame, (n, 4), fp32-rounded,
+    labels zeroed beyond `label_max_range` (Preprocessing.cpp:177-178); rays without a hit inside (min, max) range drop out."""
+    R = quat_to_mat(T[:4])
+    o = np.asarray(T[4:], dtype=np.float64)
+    az = (np.arange(az_steps) + rng.uniform(0, 1)) * (2 * np.pi / az_steps)
+    el = np.deg2rad(np.linspace(elev_deg[0], elev_deg[1], beams))
+    ca, sa = np.cos(az)[:, None], np.sin(az)[:, None]
+    ce, se = np.cos(el)[None, :], np.sin(el)[None, :]
+    dl = np.stack([ca * ce, sa * ce, np.broadcast_to(se, (az_steps, beams))], axis=-1)      # sensor frame
+    d = dl @ R.T                                                                           # map frame
+    tmin = np.full((az_steps, beams), np.inf)
+    lab = np.zeros((az_steps, beams))
+    dx, dy, dz = d[..., 0], d[..., 1], d[..., 2]
+
+    def take(t, label, ok):
+        better = ok & (t > 0.0) & (t < tmin)
+        tmin[better] = t[better]
+        lab[better] = label[better] if isinstance(label, np.ndarray) else label
+
+    with np.errstate(divide="ignore", invalid="ignore"):
+        # ground, labelled by the strip it lies in
+        t = (GROUND_Z - o[2]) / dz
+        y = o[1] + t * dy
+        dd = np.abs(_road_offset(y))
+        even = (_line_index(y) % 2) == 0
+        gl = np.full(y.shape, 72.0)
+        gl[dd < 9.0] = 48.0
+        gl[(dd < 6.5) & even] = 44.0
+        gl[dd < 4.0] = 40.0
+        take(t, gl, dz < 0.0)
+        # walls (30 m on, 10 m off) and fences along every road line within reach
+        k0 = np.round(o[1] / ROAD_PITCH)
+        for k in (k0 - 1, k0, k0 + 1):
+            for side in (-1.0, 1.0):
+                yw = ROAD_PITCH * k + side * 15.0
+                t = (yw - o[1]) / dy
+                x = o[0] + t * dx
+                z = o[2] + t * dz
+                take(t, 50.0, ((x % 40.0) < 30.0) & (z > GROUND_Z) & (z < 6.0))
+                yf = ROAD_PITCH * k + side * 11.0
+                t = (yf - o[1]) / dy
+                z = o[2] + t * dz
+                take(t, 51.0, (z > GROUND_Z) & (z < GROUND_Z + 1.5))
+
+    # small objects: only the rays whose azimuth can reach them are tested
+    dxy = np.hypot(dx, dy)
+    yaw = np.arctan2(R[1, 0], R[0, 0])
+
+    def window(cx, cy, r):
+        rel = np.array([cx - o[0], cy - o[1]])
+        dist = np.hypot(*rel)
+        if dist > max_range + r or dist < r + 0.5:
+            return None
+        a0 = np.arctan2(rel[1], rel[0]) - yaw
+        half_w = np.arcsin(min(1.0, r / dist)) + 2 * np.pi / az_steps
+        i0 = int(np.floor((a0 - half_w) / (2 * np.pi) * az_steps))
+        i1 = int(np.ceil((a0 + half_w) / (2 * np.pi) * az_steps)) + 1
+        return np.arange(i0, i1) % az_steps
+
+    def cylinder(cx, cy, r, z0, z1, label_fn):
+        idx = window(cx, cy, r)
+        if idx is None:
+            return
+        ex, ey = dx[idx], dy[idx]
+        fx, fy = o[0] - cx, o[1] - cy
+        a = ex * ex + ey * ey
+        b = 2 * (fx * ex + fy * ey)
+        c = fx * fx + fy * fy - r * r
+        disc = b * b - 4 * a * c
+        with np.errstate(invalid="ignore", divide="ignore"):
+            t = (-b - np.sqrt(disc)) / (2 * a)
+        z = o[2] + t * dz[idx]
+        ok = (disc > 0) & (t > 0) & (z > z0) & (z < z1)
+        sub_t, sub_l = tmin[idx], lab[idx]
+        better = ok & (t < sub_t)
+        sub_t[better] = t[better]
+        sub_l[better] = label_fn(z[better])
+        tmin[idx], lab[idx] = sub_t, sub_l
+
+    def sphere(cx, cy, cz, r, label):
+        idx = window(cx, cy, r)
+        if idx is None:
+            return
+        f = o - np.array([cx, cy, cz])
+        dd_ = d[idx]
+        b = 2 * (dd_ @ f)
+        c = f @ f - r * r
+        disc = b * b - 4 * c
+        with np.errstate(invalid="ignore"):
+            t = (-b - np.sqrt(disc)) / 2
+        ok = (disc > 0) & (t > 0)
+        sub_t, sub_l = tmin[idx], lab[idx]
+        better = ok & (t < sub_t)
+        sub_t[better] = t[better]
+        sub_l[better] = label
+        tmin[idx], lab[idx] = sub_t, sub_l
+
+    def box(cx, cy, hx, hy, z0, z1, label):
+        idx = window(cx, cy, np.hypot(hx, hy))
+        if idx is None:
+            return
+        lo = np.array([cx - hx, cy - hy, z0])
+        hi = np.array([cx + hx, cy + hy, z1])
+        dd_ = d[idx]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t1 = (lo - o) / dd_
+            t2 = (hi - o) / dd_
+        tn = np.minimum(t1, t2).max(axis=-1)
+        tf = np.maximum(t1, t2).min(axis=-1)
+        ok = (tn < tf) & (tn > 0)
+        sub_t, sub_l = tmin[idx], lab[idx]
+        better = ok & (tn < sub_t)
+        sub_t[better] = tn[better]
+        sub_l[better] = label
+        tmin[idx], lab[idx] = sub_t, sub_l
+
+    reach = max_range
+    for k in (k0 - 1, k0, k0 + 1):
+        for side in (-1.0, 1.0):
+            for px in np.arange(np.ceil((o[0] - reach) / 25.0), np.floor((o[0] + reach) / 25.0) + 1) * 25.0:
+                cylinder(px, ROAD_PITCH * k + side * 7.5, 0.08, GROUND_Z, 5.0, lambda z: np.where(z > 4.4, 81.0, 80.0))
+            for cxx in np.arange(np.ceil((o[0] - reach) / 12.0), np.floor((o[0] + reach) / 12.0) + 1) * 12.0:
+                box(cxx, ROAD_PITCH * k + side * 5.2, 2.1, 0.9, GROUND_Z, GROUND_Z + 1.5, 10.0)
+    bx, by = _blob_cells(min(o[0], o[1]) - reach, max(o[0], o[1]) + reach)
+    for cx, cy in zip(bx, by):
+        sphere(cx, cy, 1.5, 2.0, 70.0)
+        cylinder(cx, cy, 0.15, GROUND_Z, 1.0, lambda z: np.full(z.shape, 71.0))
+
+    hit = np.isfinite(tmin)
+    t = tmin + rng.normal(0, 0.02, tmin.shape)
+    hit &= (t > min_range) & (t < max_range) & (rng.random(tmin.shape) > dropout)
+    pts = dl[hit] * t[hit][:, None]                      # sensor frame: range along the ray
+    l = lab[hit]
+    l[t[hit] > label_max_range] = 0.0
+    l[rng.random(len(l)) < 0.005] = 0.0
+    out = np.empty((len(pts), 4))
+    out[:, :3] = pts.astype(np.float32).astype(np.float64)
+    out[:, 3] = l
+    return np.ascontiguousarray(out)
+
+
+def make_ring_workload(new_map, n_map_scans=30, step=2.0, az_steps=2048, voxel=1.0, seed=0xA64, scan_az_steps=2048):
+    """Ring family: a map built from `n_map_scans` revolutions taken every `step` metres along the road (inserted through
+    new_map().AddPoints in the map frame, as the pipeline's Update does), and one more revolution from a pose between the
+    last two, registered from a guess half a metre off.  Returns dict(map, scan, T_gt, stream, voxel) like make_workload."""
+    rng = np.random.default_rng(seed)
+    m = new_map()
+    stream = []
+    for k in range(n_map_scans):
+        T = pose_from_rpy_t([0.0, 0.0, 0.3 * k], [step * k, 0.4 * np.sin(0.2 * k), 0.0])
+        s = apply_pose(T, make_ring_scan(rng, T, az_steps=az_steps))
+        m.AddPoints(s)
+        stream.append(s)
+    T_gt = pose_from_rpy_t([0.1, 0.1, 0.3 * (n_map_scans - 1.5) + 1.0], [step * (n_map_scans - 1.5) + 0.5, 0.1, 0.02])
+    scan = make_ring_scan(rng, T_gt, az_steps=scan_az_steps)
+    return dict(map=m, scan=scan, T_gt=T_gt.copy(), stream=np.concatenate(stream), voxel=voxel)

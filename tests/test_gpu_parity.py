@@ -605,6 +605,37 @@ def test_register_frame_property(gpu_sage, oracle, seed, vs, sigma, th, lw, comp
                 os.environ[k] = v
 
 
+@pytest.mark.parametrize("div,lw", [(1, None), (1, 1), (1, 3), (2, None), (4, None), (4, 2), (10, None), (10, 4)])
+def test_ring_geometry_scene_family(gpu_sage, oracle, div, lw, monkeypatch):
+    """the second scene family (synthetic.make_ring_scan: one revolution of a 64-beam sensor, by ray casting — density
+    falling with range ring by ring, occlusion; a map built from such revolutions along a road): the library's own choice
+    of lanes / scan form / loop and forced alternatives against the oracle's full registration — pose, iteration count,
+    correspondence counts, exact C_q — at the scan's full size and at the sizes the pipeline's down-sampling leaves"""
+    from sage_icp_amd import synthetic as syn
+    if lw is not None:
+        monkeypatch.setenv("SAGEICP_LW", str(lw))
+    w = syn.make_ring_workload(lambda: gpu_sage.VoxelHashMap(1.0, 100.0), n_map_scans=12, az_steps=1024, scan_az_steps=2048)
+    om = oracle.Map(1.0, 100.0)
+    om.add_points(w["stream"])
+    assert om.size() == w["map"].size() and om.num_voxels() == w["map"].num_voxels()
+    scan = np.ascontiguousarray(w["scan"][::div])
+    guess = w["T_gt"].copy()
+    guess[4] -= 0.4
+    for params in ("cold", "steady"):
+        p = syn.PARAMS[params]
+        pose, st = gpu_sage.register_frame(scan, w["map"], guess, p["max_dist"], p["kernel"], p["sem_th"], return_stats=True)
+        opose, ost = om.register_frame(scan, guess, p["max_dist"], p["kernel"], p["sem_th"])
+        dt, dr = pose_error(oracle, opose, pose)
+        assert dt < 1e-7 and dr < 1e-7
+        assert st.iterations == ost.iterations and st.converged == ost.converged == 1
+        assert st.n_corr_first == ost.n_corr_first and st.n_corr_last == ost.n_corr_last
+        assert st.sum_candidates == ost.sum_candidates_total
+        if lw is not None:
+            assert st.lanes_per_query == 1 << lw
+    gt, gr = pose_error(oracle, w["T_gt"], pose)
+    assert gt < 0.1 and gr < 5e-3                  # the revolution is placed where it was taken
+
+
 def test_streaming_frames_with_map_updates(gpu_sage, oracle, scan_form):
     """c3-style: register, update the map with the frame at the new pose, repeat — both
     backends restarted from the same state every frame."""
