@@ -11,7 +11,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["csrc/kernels.hip", "csrc/sort.hip", "csrc/preprocess.hip", "csrc/map_update.hip",
            "csrc/capi_mirror.hip", "csrc/capi_run.hip", "csrc/capi.hip"]
-HEADERS = ["csrc/kernels.h", "csrc/sageicp_types.h", "csrc/se3_math.h", "csrc/host_map.hpp", "csrc/pipeline.hpp", "csrc/map_update.h", "csrc/metrics.hpp", "csrc/robin_order.hpp", "csrc/capi_internal.h",
+HEADERS = ["csrc/kernels.h", "csrc/sageicp_types.h", "csrc/se3_math.h", "csrc/host_map.hpp", "csrc/pipeline.hpp", "csrc/map_update.h", "csrc/metrics.hpp", "csrc/robin_order.hpp", "csrc/capi_internal.h", "csrc/probes.h",
            "../include/sageicp.h"]
 OUT = os.path.join(HERE, "libsageicp_hip.so")
 OBJ_DIR = os.path.join(HERE, "build")
@@ -89,6 +89,25 @@ def build_sqnorm3_variant(force=False, verbose=False):
         if not any(os.path.getmtime(os.path.join(HERE, f)) > t for f in SOURCES + HEADERS):
             return out
     return build(force=True, verbose=verbose, out=out, defines=("SAGE_SQNORM3_ORDER=0",))
+
+
+PROBE_DEFINES = ("SAGE_NN_TIMING", "SAGE_LOOP_TIMING", "SAGE_GN_TIMING", "SAGE_ICP_DELAY_PROBE", "SAGE_LOOP_INGRID")
+
+
+def compile_probe_variants(jobs=None):
+    """Smoke target: the device code of kernels.hip with each probe switch (csrc/probes.h and the stamps beside the loops),
+    compiled and thrown away — so that the instrumented builds profiles/ relies on do not rot.  Returns {define: stderr}
+    of the variants that failed (empty: all fine)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    src = os.path.join(HERE, "csrc/kernels.hip")
+
+    def one(d):
+        r = subprocess.run([hipcc] + FLAGS + ["-D" + d, "--cuda-device-only", "-c", src, "-o", os.devnull],
+                           capture_output=True, text=True)
+        return d, (r.stderr if r.returncode else "")
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=jobs or min(len(PROBE_DEFINES), os.cpu_count() or 1)) as ex:
+        return {d: err for d, err in ex.map(one, PROBE_DEFINES) if err}
 
 
 if __name__ == "__main__":

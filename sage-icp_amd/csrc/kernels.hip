@@ -83,6 +83,7 @@
 #include "kernels.h"
 #include "se3_math.h"
 #include "sageicp_types.h"
+#include "probes.h"
 
 namespace sageicp {
 
@@ -329,15 +330,6 @@ __global__ __launch_bounds__(256) void k_rows(IcpParams P) {
 }
 
 // ------------------------------------------------------------------------------------- k_icp
-#ifdef SAGE_NN_TIMING
-constexpr unsigned kNnTimingSlots = 1u << 17;
-__device__ unsigned long long g_nn_phase[8ull * kNnTimingSlots];   // per wave: 5 phases, lifetime, realtime, count
-__device__ unsigned long long g_nn_span[4ull * kNnTimingSlots];    // per wave, iteration g_nn_span_iter: start, end (100-MHz ticks), HW_ID, pairs
-__device__ int g_nn_span_iter;
-#define NN_T(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); tph[i] += _t - tprev; tprev = _t; } while (0)
-#else
-#define NN_T(i) do { } while (0)
-#endif
 
 // per-workgroup LDS header of k_icp (words): arrival counter | the workgroup's fixed-point accumulators
 // (kWgAccWords 64-bit words)
@@ -505,11 +497,6 @@ struct LoopGroup {
     unsigned long long ph[8], tprev;           // probe builds: cycles per phase of the body, summed over the iterations
 #endif
 };
-#ifdef SAGE_LOOP_TIMING
-#define LP_T(i) do { if constexpr (PERSIST) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); G->ph[i] += _t - G->tprev; G->tprev = _t; } } while (0)
-#else
-#define LP_T(i) do { } while (0)
-#endif
 constexpr int kLoopMaxWaves = kLoopMaxWavesHost;   // waves per workgroup of k_loop (<= 512 threads)
 constexpr unsigned kLoopStripe = kLoopStripeHost;  // workgroups of k_loop per XCD stripe (its grid: a multiple of 32)
 constexpr int kNoVoxel = 0x7FFFFFFF;        // a home voxel no point has (|index| < 2^20): row not built yet
@@ -568,14 +555,7 @@ void k_icp(IcpParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     if (P.check_done && P.st->done) return;
     icp_body<LW, FUSED, FILT, false, FLATQ>(P, smem);
-#ifdef SAGE_ICP_DELAY_PROBE
-    // probe: the same pass again inside the launch — what an iteration costs on L2s that were not
-    // emptied by a kernel boundary (its sums are added a second time: the solve does not care)
-    for (unsigned r = 0; r < P.dbg_repeat; ++r) {
-        __syncthreads();
-        icp_body<LW, FUSED, FILT, false, FLATQ>(P, smem);
-    }
-#endif
+    PROBE_DELAY_REPEAT((icp_body<LW, FUSED, FILT, false, FLATQ>(P, smem)));
 }
 
 template <int LW, bool FUSED, bool FILT, bool PERSIST, bool FLATQ>
@@ -584,15 +564,8 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
     constexpr int W = 1 << LW;                 // lanes per query
     constexpr int QW = 64 >> LW;               // queries per wave
     constexpr int SH = 5;                      // points are addressed by byte offset
-#ifdef SAGE_NN_TIMING
-    unsigned long long tph[5] = {0, 0, 0, 0, 0};
-    unsigned long long tprev = __builtin_amdgcn_s_memtime();
-    const unsigned long long tstart = tprev;
-    const unsigned long long rstart = __builtin_amdgcn_s_memrealtime();
-#endif
-#ifdef SAGE_ICP_DELAY_PROBE
-    const unsigned long long probe_t0 = __builtin_amdgcn_s_memrealtime();
-#endif
+    PROBE_NN_BEGIN;
+    PROBE_DELAY_BEGIN;
     int lane;
     if constexpr (PERSIST) {
         // (k_loop: re-derived in every pass — what the compiler knows to be invariant across the iteration
@@ -710,15 +683,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
         if (NP > 5) pc5 = row_piece(5);
         if (NP > 6) pc6 = row_piece(6);
     }
-#ifdef SAGE_ICP_DELAY_PROBE
-    // probe: the pose becomes available `dbg_delay` ticks (100 MHz) after this wave started, with
-    // the prologue loads above already in flight — what hiding k_fin under the prologue would cost
-    if (P.dbg_delay) {
-        __builtin_amdgcn_sched_barrier(0);
-        while (__builtin_amdgcn_s_memrealtime() - probe_t0 < P.dbg_delay) __builtin_amdgcn_s_sleep(8);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#endif
+    PROBE_DELAY_WAIT(P);
     const Query s = PERSIST ? make_query<(W >= 4)>(f, pose, pose + 9, 1, P.voxel_size, P.inv_voxel_size)
                             : make_query<(W >= 4)>(f, P.st->R, P.st->T + 4, P.apply_pose, P.voxel_size, P.inv_voxel_size);
     const bool stale = valid && (static_cast<uint32_t>(s.kx) != rk.x || static_cast<uint32_t>(s.ky) != rk.y ||
@@ -944,9 +909,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
                      ez = fabs(s.z) + 4.0 * P.voxel_size;
         slack = (ex * ex + (ey * ey + ez * ez)) * P.filt_slack;     // 2^-44 (1 + 2^10) k
     }
-#ifdef SAGE_NN_TIMING
-    unsigned n_consume = 0u, n_exact = 0u, n_exact_lanes = 0u;
-#endif
+    PROBE_NN_COUNTERS;
     double fb = best;                          // what the thresholds were derived from (>= the query's final best)
     float Ts = 0.0f, Td = 0.0f, Tmax = 0.0f;   // Tmax: the looser of the two
     auto round_up = [](double x) {             // the next fp32 above x (an infinity becomes a NaN:
@@ -1082,9 +1045,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
             float dla, dlb;
             const float da = dist32(n.a, dla), db = dist32(n.b, dlb);
             const bool la = n.ha & !(da > Tmax) & (n.ka != bkey), lb = n.hb & !(db > Tmax) & (kb != bkey);
-#ifdef SAGE_NN_TIMING
-            ++n_consume;
-#endif
+            PROBE_NN_CONSUME;
             if (__ballot(la | lb)) {
             const bool pa = la & tight(n.a, da, dla), pb = lb & tight(n.b, db, dlb);
             if (__ballot(pa | pb)) {
@@ -1092,10 +1053,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
                 // start of a cold one, 2 % near convergence): the full records of the candidates
                 // that passed (a compact offset is half the byte offset of the full record).
                 // (Parking them and fetching in batches was tried: more registers, no fewer trips.)
-#ifdef SAGE_NN_TIMING
-                ++n_exact;
-                n_exact_lanes += static_cast<unsigned>(__popcll(__ballot(pa)) + __popcll(__ballot(pb)));
-#endif
+                PROBE_NN_EXACT(pa, pb);
                 unsigned ob;
                 if constexpr (FLAT) ob = n.ob; else ob = n.oa + (static_cast<unsigned>(W) << SHC);
                 const Point4 ea = load_point(pts, pa ? n.oa << 1 : 0u);
@@ -1319,9 +1277,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
             if (ci == 0u) *reinterpret_cast<uint2 *>(lst + kStPrev) = make_uint2(found ? mkey : 0xFFFFFFFFu, woff);
             LP_T(6);
         }
-#ifdef SAGE_NN_TIMING
-        if (valid && ci == 0u && P.work) P.work[q] = npairs;
-#endif
+        PROBE_NN_WORK(P, q, valid && ci == 0u, npairs);
         // Branch-free: every lane computes the terms of "its" pair from operands that are zeroed unless it is the
         // first lane of a query with an accepted answer (the products are then exact zeros of either sign, which
         // the block sums and their digits do not tell apart) — clearing sixteen fp64 registers twice around two
@@ -1356,21 +1312,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
             // k_loop: block sums -> exact digits -> the workgroup's accumulators (the rows stay: the scratch
             // is the running wave's own)
             wave_terms_to_wgacc<LW>(t, pairs, lane, G->red, G->wgacc, kDigitLimitCounted, P.acc_scale);
-#ifdef SAGE_LOOP_TIMING
-            {
-                unsigned mx = valid ? npairs : 0u, sm = (valid && ci == 0u) ? npairs : 0u, stl = (stale && ci == 0u) ? 1u : 0u;
-                for (int d = 1; d < 64; d <<= 1) {
-                    mx = max(mx, static_cast<unsigned>(__shfl_xor(mx, d, 64)));
-                    sm += __shfl_xor(sm, d, 64);
-                    stl += __shfl_xor(stl, d, 64);
-                }
-                if (lane == 0) {
-                    atomicMax(&smem[kLpDbg], mx);
-                    atomicAdd(&smem[kLpDbg + 1], stl);
-                    atomicAdd(&smem[kLpDbg + 2], sm);
-                }
-            }
-#endif
+            PROBE_LOOP_WAVE_STATS(smem, valid, ci, npairs, stale, lane);
             LP_T(7);
             return;                             // (k_loop closes the workgroup's iteration itself)
         }
@@ -1398,35 +1340,7 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
                             P.acc + kAccWords - 1);
         }
     }
-#ifdef SAGE_NN_TIMING
-    // private slot per wave (no contended atomics: they would stall the very loads being timed)
-    NN_T(4);
-    unsigned long long np_packed, xp_packed;
-    {   // points handed to the queries of this wave: max over the queries | sum
-        unsigned mx = valid ? npairs : 0u, sm = (valid && ci == 0u) ? npairs : 0u;
-        for (int d = 1; d < 64; d <<= 1) {
-            mx = max(mx, static_cast<unsigned>(__shfl_xor(mx, d, 64)));
-            sm += __shfl_xor(sm, d, 64);
-        }
-        np_packed = (static_cast<unsigned long long>(mx) << 32) | sm;
-        // pair steps of this wave | of them with a fetch of full records | lanes that fetched
-        xp_packed = (static_cast<unsigned long long>(n_consume) << 40) | (static_cast<unsigned long long>(n_exact) << 20) | n_exact_lanes;
-    }
-    if (lane == 0 && wave_id < kNnTimingSlots && wave_id < P.nwaves) {
-        unsigned long long *tt = g_nn_phase + 8ull * wave_id;
-        for (int k = 0; k < 5; ++k) tt[k] += tph[k];
-        tt[5] += __builtin_amdgcn_s_memtime() - tstart;
-        tt[6] += __builtin_amdgcn_s_memrealtime() - rstart;
-        tt[7] += 1ull;
-        unsigned long long *sp = g_nn_span + 4ull * wave_id;
-        if (P.st->iter == g_nn_span_iter) {
-        sp[0] = rstart;
-        sp[1] = __builtin_amdgcn_s_memrealtime();
-        sp[2] = xp_packed;
-        sp[3] = np_packed;
-        }
-    }
-#endif
+    PROBE_NN_END(P, valid, ci, npairs, lane, wave_id);
 }
 
 // ------------------------------------------------------------------------------------ WaveLanes
