@@ -136,6 +136,7 @@ struct Scratch {
     double *d_partials = nullptr; size_t partials_cap = 0;
     long long *d_acc = nullptr;    // fixed-point accumulators of the Gauss-Newton sums (kernels.h, kAcc*)
     LoopShared *d_loop = nullptr;  // what the workgroups of k_loop share inside its launch (kernels.h)
+    unsigned long long go_word = 0; // (host source of a `go` word sent by a copy: run_icp)
     hipStream_t stream2 = nullptr; // the solving wave of the one-launch loop runs here, beside the grid on `stream`
                                    // (created with the first such launch: a process has few hardware queues, and
                                    // streams that never run anything still take their turn on them)

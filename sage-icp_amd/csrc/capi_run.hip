@@ -95,6 +95,7 @@ static thread_local int g_acc_shift = 0;
 // (a frame started again because a peer rank left its one-launch loop: see the end of run_icp)
 static thread_local int g_restarts = 0;
 static thread_local bool g_no_loop = false;
+static thread_local bool g_no_chain = false;     // (a frame registered again after its chained launches timed out)
 
 // k_icp's arguments for a search of `n` queries against the HBM copy of `m`
 IcpParams icp_params(const sageicp_map *m, const Point4 *d_queries, uint64_t n, double sem_th, int lw) {
@@ -390,7 +391,35 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
             (void)hipStreamSynchronize(sc->stream2);
         }
     } solver_guard;
-    if (use_loop && (rc = sc.loop_streams())) return rc;
+    // Frames beyond the LDS on one GPU: the launches of the iterations CHAINED (kernels.h, IcpParams::chain) — no k_fin between
+    // them, the solving wave of the one-launch loop resident beside them.  (Not after a one-launch loop that timed out in this
+    // call or its cool-down: a GPU that did not hold that grid is not asked to hold a resident solving wave either.)
+    const int chain_grid = n > 0 ? icp_blocks_for(static_cast<int>(n), lw) : 0;
+    // (profiling level 2 asks for the time of every kernel of every iteration, k_fin's too: the form with k_fin)
+    const bool chain = !loop_shape && !comm && polled && n > 0 && chain_grid / kChainReplicas <= 255 && !g_no_chain && !prof2 &&
+                       env_int("SAGEICP_CHAIN", 1) != 0;
+    if ((use_loop || chain) && (rc = sc.loop_streams())) return rc;
+    if (chain) {
+        L.sh = sc.d_loop;
+        L.st = sc.d_state;
+        L.wgs = chain_grid;                       // every workgroup of a launch sends its sums, also the ones past the frame's end
+        L.copies = kChainReplicas;
+        L.progress = sc.d_prog;
+        L.timeout_ticks = 100000ull * static_cast<unsigned long long>(std::max(1, env_int("SAGEICP_LOOP_TIMEOUT_MS", 50)));
+        if (const int ticks = env_int("SAGEICP_LOOP_TIMEOUT_TICKS", 0)) L.timeout_ticks = static_cast<unsigned long long>(ticks);
+        // (the solving wave waits for a whole LAUNCH here, not for resident workgroups: the first launch of a process
+        // loads code objects, a big frame's launch takes its hundred microseconds)
+        L.count_timeout_ticks = std::max<unsigned long long>(L.timeout_ticks, 20ull * 100000ull) * 10ull;
+        L.max_iterations = max_it;
+        L.epoch = ++sc.loop_epoch;
+        for (int i = 0; i < 7; ++i) L.T0[i] = init[i];
+        L.acc_unscale = 1.0 / ip.acc_scale;
+        launch_loop_solve(L, xp, sc.stream2);
+        HIPCHK(hipGetLastError());
+        solver_guard.sc = &sc;
+        solver_guard.epoch = L.epoch;
+        HIPCHK(hipEventRecord(sc.ev_solve, sc.stream2));
+    }
     if (use_loop) {
         // ---- the whole loop in one launch (kernels.hip, k_loop): first its solving wave, on its own stream —
         // it has to hold its registers before the grid fills the machine; it waits for the grid's go
@@ -399,6 +428,8 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         L.nw = plan.nw;
         L.gpw = plan.gpw;
         L.wgs = plan.wgs;
+        L.copies = kLoopReplicas;
+        L.progress = nullptr;
         L.contiguous = env_int("SAGEICP_LOOP_CONTIGUOUS", 0) ? 1 : 0;
         {
             const uint64_t qw = 64u >> plan.lw, groups = (n + qw - 1) / qw;
@@ -526,6 +557,15 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     // reads in one round trip.
     HIPCHK(hipMemsetAsync(sc.d_acc, 0, sizeof(long long) * kAccReplicas * kAccWords, s));
     ip.acc = sc.d_acc;
+    if (chain) {
+        // ... or, chained, into the counted accumulators of the shared block the solving wave reads (zeroed first: the
+        // solving wave starts on launch 0's go)
+        HIPCHK(hipMemsetAsync(sc.d_loop, 0, sizeof(LoopShared), s));
+        ip.chain = sc.d_loop;
+        ip.chain_timeout = L.timeout_ticks;
+        ip.chain_epoch = L.epoch;
+        ip.digit_limit = std::min(ip.digit_limit, std::ldexp(1.0, 40));       // (counted words: kernels.hip, kDigitLimitCounted)
+    }
     FinParams fp{};
     fp.st = sc.d_state;
     fp.partials = nullptr;
@@ -555,12 +595,15 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         const bool ev = sampled(iteration);
         if (ev) HIPCHK(hipEventRecord(sc.events[5 * slot + 1], s));
         ip.stripe_work = measures(iteration) ? st_work : nullptr;
+        ip.chain_iter = iteration;
         launch_icp(ip, lw, true, s);
+        if (chain && iteration == 0 && hipPeekAtLastError() == hipSuccess) solver_guard.sc = nullptr;      // launch 0 will say go
         if (measures(iteration)) {
             HIPCHK(stripe_order_sort(st_work, st_sorted, st_iota, st_order, stripes, sc.d_sort_temp, sc.sort_temp_bytes_, s));
             ip.stripe_order = st_order;
         }
         if (ev) HIPCHK(hipEventRecord(sc.events[5 * slot + 2], s));
+        if (chain) return SAGEICP_OK;                  // (the solving wave is already waiting for this launch's sums)
         launch_fin(fp, s);
         if (comm && !p2p) {     // k_fin left the local sums in state->sums
             ncclResult_t r = g_rccl.AllReduce(sc.d_state->sums, sc.d_state->sums, kNumSums,
@@ -610,10 +653,30 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
                     break;     // everything ran and nothing flagged the end: read the state below
             }
         }
+        if (chain && solver_guard.sc) {
+            // no launch was enqueued at all (the sort refused the frame — a non-finite point — before the host got to
+            // iteration 0): nobody will tell the solving wave to start, so it is sent home here, not when this call returns
+            sc.go_word = solver_guard.epoch | 0x8000000000000000ull;
+            HIPCHK(hipMemcpyAsync(&sc.d_loop->go[0], &sc.go_word, sizeof(sc.go_word), hipMemcpyHostToDevice, s));
+            solver_guard.sc = nullptr;
+        }
+        if (chain) HIPCHK(hipStreamWaitEvent(s, sc.ev_solve, 0));      // the solving wave writes the final state
         if (counting) launch_sum_counters(sc.d_cand, static_cast<int>(ip.nwaves), sc.d_state, s);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(sc.h_state, sc.d_state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
+        if (chain && (sc.h_state->loop_aborted || !sc.h_state->done) && !sc.h_state->bad_input) {
+            // a wait timed out (the solving wave was not resident beside the launches, or a launch took longer than its
+            // patience): the frame again with k_fin between the launches — same lanes per query, same bits
+            static std::atomic<int> told{0};
+            if (told.exchange(1) == 0 && env_int("SAGEICP_QUIET", 0) == 0)
+                std::fprintf(stderr, "sageicp: a wait inside the chained ICP launches timed out: this frame is registered again with "
+                                     "k_fin between the launches\n");
+            g_no_chain = true;
+            const int rc2 = run_icp(m, d_frame, n, init, max_dist, kernel, sem_th, comm, out, stats, us_upload, t_begin);
+            g_no_chain = false;
+            return rc2;
+        }
         if (prof)
             for (int k = 0; k < sc.h_state->iter && k < enq; ++k)      // the rest were no-ops
                 if (sampled(k)) harvest(k);

@@ -21,6 +21,7 @@ constexpr int kRowWords = 32;
 constexpr int kRowCq = 27, kRowKey = 28, kRowOcc = 31;
 constexpr int kRowLdsStride = 36;          // words; 16-B pieces of 8 consecutive rows hit distinct banks
 
+struct LoopShared;
 struct IcpParams {
     const Point4 *frame;      // pristine (sorted) frame, or ready-made queries (apply_pose == 0)
     int n;
@@ -76,6 +77,15 @@ struct IcpParams {
     // instead: c4 -3 % against -7 %, profiles/r06/lpt_max_ab.txt; stripes of 4, 2, 1 workgroups: within 1.5 %, lpt_stripe_ab.txt).
     uint32_t *stripe_work;    // optional, out: [stripes] max over the stripe's waves of the most points one of a wave's queries was handed
     const uint32_t *stripe_order;  // optional: [stripes] the stripe dispatched at each position (null: the order of the frame)
+    // k_icp, chained (frames beyond the LDS, one GPU): the launches of the iterations follow each other without a k_fin in
+    // between — the solving wave of the one-launch loop (k_loop_solve, resident beside them on its own stream) collects the
+    // sums as the last workgroup of a launch sends them, solves while the next launch starts, and the first wave of every
+    // workgroup of that launch waits for the pose it publishes: one kernel boundary per iteration instead of two, and the
+    // solve under it.  Same sums, same solve: the same bits.
+    LoopShared *chain;        // non-null: this launch is iteration `chain_iter` of a chained loop
+    int chain_iter;
+    unsigned long long chain_timeout;   // 100-MHz ticks a workgroup waits for its pose
+    unsigned long long chain_epoch;     // launch 0 tells the solving wave to start (LoopShared::go)
     unsigned long long *counters;  // optional: [2 x waves] running sums of {C_q, pairs evaluated}
     unsigned nwaves;          // waves that own queries: ceil(n / (64 >> lw))
 #ifdef SAGE_ICP_DELAY_PROBE
@@ -157,7 +167,9 @@ void launch_fin(const FinParams &p, hipStream_t s);
 // other); the block is zeroed before every launch; every wait is bounded.
 constexpr int kLoopReplicas = 8;           // accumulator copies (workgroup b adds into copy b & 7)
 constexpr int kLoopPoseGranules = 25;      // R[9], t[3] as 24 x {tag, 32 bits} + {tag, done}
+constexpr int kChainReplicas = 32;         // accumulator copies of the chained launches (k_icp: thousands of workgroups, <= 255 per copy)
 struct LoopShared {
+    long long acc32[2][kChainReplicas][kAccWords];      // the chained launches' accumulators (as acc below, 32 copies)
     long long acc[2][kLoopReplicas][kAccWords];         // as FinParams::acc, one set per iteration parity, every word
                                                         // (digit << 8) | workgroups in it; word 51: (workgroups whose sums overflowed << 8) | workgroups
     unsigned long long pose[32];                        // granules (tag << 32) | payload, tag = iteration + 1
@@ -182,6 +194,9 @@ struct LoopParams {
                                    // grid fills the machine) and waits for LoopShared::go to carry this number
     double T0[7];                  // the initial pose (the solving wave starts before the loop state is uploaded)
     double acc_unscale;            // 1 / IcpParams::acc_scale
+    int copies;                    // accumulator copies the workgroups add into: kLoopReplicas (k_loop: LoopShared::acc) or
+                                   // kChainReplicas (chained k_icp launches: LoopShared::acc32)
+    IcpProgress *progress;         // optional (chained launches): the host-mapped word the host steers its look-ahead by
     int shared_loop;               // 1: under a communicator — an overflowing sum or a bad frame point does not end
                                    // this rank's loop on its own (the ranks must keep exchanging in step)
     int prio;                      // wave priorities by the work of a wave's unit (kernels.hip, k_loop): 0 off | 1..3: on, the

@@ -177,6 +177,15 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
+// (what the workgroups of a launch share with each other and with the solving wave: agent-scope atomics only —
+// the eight L2s are not coherent with each other)
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 
 // One map point through the buffer path: `off` is the point's byte offset, the resource carries the
 // 64-bit base, so a load costs no 64-bit address arithmetic.  (The point array stays under 4 GiB:
@@ -334,8 +343,9 @@ __global__ __launch_bounds__(256) void k_rows(IcpParams P) {
 // per-workgroup LDS header of k_icp (words): arrival counter | the workgroup's fixed-point accumulators
 // (kWgAccWords 64-bit words)
 constexpr unsigned kWgAccWords = 52;         // (16 sums + pair count) x 3 digits = 51 | [51] overflow flag
-constexpr unsigned kWgArrive = 0, kWgAcc = 2;
-constexpr unsigned kWgHeaderWords = (kWgAcc + 2u * kWgAccWords + 15u) & ~15u;
+constexpr unsigned kWgArrive = 0, kWgGo = 1, kWgAcc = 2;      // kWgGo: chained launches: 0 go on, else leave
+constexpr unsigned kWgPose = kWgAcc + 2u * kWgAccWords;       // chained launches: R[9], t[3] of this iteration (16-B aligned)
+constexpr unsigned kWgHeaderWords = (kWgPose + 24u + 15u) & ~15u;
 __host__ __device__ constexpr unsigned icp_wave_words(int lw) {
     // the rows of the wave's queries (kRowLdsStride words each); reused by the epilogue's
     // transposed reduction, 16 components x (queries + 2) fp64
@@ -549,11 +559,60 @@ struct PairFullFlat {
     bool ha, hb;
 };
 
+// Chained launches (IcpParams::chain): wave 0 of a workgroup of the launch of iteration `it` waits for the pose the solving
+// wave publishes after iteration it - 1 (25 self-tagged granules, tag = it; kernels.h, LoopShared) and hands it to the
+// workgroup through LDS.  smem[kWgGo] != 0: the workgroup leaves — the loop ended before this iteration (the done granule
+// carries an older tag, or this tag with its done word set), or a wait timed out somewhere.
+__device__ __forceinline__ void chain_wait_pose(const IcpParams &P, uint32_t *smem, int lane) {
+    LoopShared *sh = P.chain;
+    const unsigned long long tag = static_cast<unsigned long long>(P.chain_iter);
+    const unsigned long long *src = lane < kLoopPoseGranules ? &sh->pose[lane] : &sh->abort_word[0];
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned go = 0u;
+    unsigned long long g;
+    for (;;) {
+        g = ld_agent(src);
+        const unsigned long long g24 = static_cast<unsigned long long>(static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(g), 24))) |
+                                       (static_cast<unsigned long long>(static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(g >> 32), 24))) << 32);
+        const bool ok = lane >= kLoopPoseGranules || (g >> 32) == tag;
+        if (__all(ok)) {
+            if (static_cast<uint32_t>(g24) != 0u) go = 1u;             // the pose after the LAST iteration: nothing left to do
+            break;
+        }
+        if ((g24 >> 32) < tag && static_cast<uint32_t>(g24) != 0u) {   // the loop ended before this iteration
+            go = 1u;
+            break;
+        }
+        const bool late = __builtin_amdgcn_s_memrealtime() - t0 > P.chain_timeout;
+        if (__any(lane == kLoopPoseGranules && g != 0ull) || late) {
+            if (lane == 0 && late) {
+                st_agent(&sh->abort_word[0], 1ull);
+                const_cast<IcpState *>(P.st)->loop_aborted = 1;
+            }
+            go = 2u;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (!go && lane < 24) smem[kWgPose + static_cast<unsigned>(lane)] = static_cast<uint32_t>(g);
+    if (lane == 0) smem[kWgGo] = go;
+}
+
 template <int LW, bool FUSED, bool FILT, bool FLATQ>
 __global__ __launch_bounds__(64 * kIcpWavesPerBlock) __attribute__((amdgpu_waves_per_eu(SAGE_ICP_OCC, 8)))
 void k_icp(IcpParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    if (P.check_done && P.st->done) return;
+    if (P.chain) {
+        // chained launches: whether the loop has ended travels with the pose (chain_wait_pose); launch 0 tells the solving
+        // wave that the shared block has been zeroed and the loop starts — or that it never will (a non-finite frame point)
+        if (P.chain_iter == 0) {
+            const bool bad = P.st->done != 0;
+            if (blockIdx.x == 0 && threadIdx.x == 0) st_agent(&P.chain->go[0], P.chain_epoch | (bad ? 0x8000000000000000ull : 0ull));
+            if (bad) return;
+        }
+    } else if (P.check_done && P.st->done) {
+        return;
+    }
     icp_body<LW, FUSED, FILT, false, FLATQ>(P, smem);
     PROBE_DELAY_REPEAT((icp_body<LW, FUSED, FILT, false, FLATQ>(P, smem)));
 }
@@ -578,8 +637,14 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
     }
     const int wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     if (FUSED && !PERSIST) {
-        if (threadIdx.x == 0) smem[kWgArrive] = 0u;
+        if (threadIdx.x == 0) {
+            smem[kWgArrive] = 0u;
+            smem[kWgGo] = 0u;
+        }
         if (threadIdx.x < 2u * kWgAccWords) smem[kWgAcc + threadIdx.x] = 0u;
+        // the pose of this iteration, for the workgroup (a chained launch after the first gets it from the solving wave, below)
+        if (threadIdx.x < 12u && !(P.chain && P.chain_iter > 0))
+            reinterpret_cast<double *>(smem + kWgPose)[threadIdx.x] = threadIdx.x < 9u ? P.st->R[threadIdx.x] : P.st->T[4u + threadIdx.x - 9u];
         __syncthreads();
     }
     uint32_t *wl;
@@ -684,7 +749,17 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
         if (NP > 6) pc6 = row_piece(6);
     }
     PROBE_DELAY_WAIT(P);
+    if constexpr (FUSED && !PERSIST) {
+        if (P.chain && P.chain_iter > 0) {
+            // (the loads above are in flight while wave 0 waits for the pose: the launch started under the solve)
+            if (wv == 0) chain_wait_pose(P, smem, lane);
+            __syncthreads();
+            if (smem[kWgGo]) return;
+        }
+    }
+    const double *lpose = reinterpret_cast<const double *>(smem + kWgPose);       // (FUSED && !PERSIST: the workgroup's copy)
     const Query s = PERSIST ? make_query<(W >= 4)>(f, pose, pose + 9, 1, P.voxel_size, P.inv_voxel_size)
+                   : FUSED  ? make_query<(W >= 4)>(f, lpose, lpose + 9, P.apply_pose, P.voxel_size, P.inv_voxel_size)
                             : make_query<(W >= 4)>(f, P.st->R, P.st->T + 4, P.apply_pose, P.voxel_size, P.inv_voxel_size);
     const bool stale = valid && (static_cast<uint32_t>(s.kx) != rk.x || static_cast<uint32_t>(s.ky) != rk.y ||
                                  static_cast<uint32_t>(s.kz) != rk.z);
@@ -1335,9 +1410,13 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
                 prior = __hip_atomic_fetch_add(&smem[kWgArrive], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
             prior = __builtin_amdgcn_readfirstlane(prior);
-            if (prior == kIcpWavesPerBlock - 1u)
-                wgacc_flush(wgacc, P.acc + static_cast<size_t>(blockIdx.x & (kAccReplicas - 1)) * kAccWords,
-                            P.acc + kAccWords - 1);
+            if (prior == kIcpWavesPerBlock - 1u) {
+                if (P.chain)
+                    wgacc_flush<true>(wgacc, &P.chain->acc32[P.chain_iter & 1][blockIdx.x & (kChainReplicas - 1)][0], nullptr);
+                else
+                    wgacc_flush(wgacc, P.acc + static_cast<size_t>(blockIdx.x & (kAccReplicas - 1)) * kAccWords,
+                                P.acc + kAccWords - 1);
+            }
         }
     }
     PROBE_NN_END(P, valid, ci, npairs, lane, wave_id);
@@ -1738,12 +1817,6 @@ extern "C" void sageicp_debug_loop_times(unsigned long long *wg, unsigned long l
 #define LOOP_STAMP_WG(it, k) do { } while (0)
 #endif
 
-__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // exchange_sums for ONE wave (the solving wave of k_loop_solve): S (LDS) holds this rank's sums on entry
 // and the sums over all ranks, added in rank order, on exit; `g` is the exchange counter (the same on
@@ -1814,6 +1887,7 @@ struct SolveLds {
     double pub[12];
     long long digits[kAccWords];
 };
+template <int COPIES>
 __device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, const P2pParams &X, SolveLds &m, int it,
                                                           unsigned long long &xg) {
     LoopShared *sh = L.sh;
@@ -1829,18 +1903,18 @@ __device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, c
     // iteration after the next (the clears are complete long before that pose is published: the waits
     // of the next iteration's passes cover them).
     {
-        const long long per = static_cast<long long>(L.wgs >> 3);      // workgroups adding into each copy
-        long long (*acc)[kAccWords] = sh->acc[it & 1];
-        long long v[kLoopReplicas];
+        const long long per = static_cast<long long>(L.wgs / COPIES);      // workgroups adding into each copy
+        long long (*acc)[kAccWords] = COPIES == kLoopReplicas ? sh->acc[it & 1] : sh->acc32[it & 1];
+        long long v[COPIES];
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         for (;;) {
 #pragma unroll
-            for (int r = 0; r < kLoopReplicas; ++r)
+            for (int r = 0; r < COPIES; ++r)
                 v[r] = __hip_atomic_load(&acc[r][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             bool ok = true;
             if (lane <= 3 * kAccValues) {          // (word 3 kAccValues: the overflow count, counted like the sums)
 #pragma unroll
-                for (int r = 0; r < kLoopReplicas; ++r) ok &= (v[r] & 255ll) == per;
+                for (int r = 0; r < COPIES; ++r) ok &= (v[r] & 255ll) == per;
             }
             if (__all(ok)) break;
             unsigned long long ab = 0ull;
@@ -1853,6 +1927,9 @@ __device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, c
                     st_agent(&sh->abort_word[0], 1ull);
                     st->loop_aborted = 1;
                     st_agent(&sh->pose[24], (tag << 32) | 2ull);
+                    if (L.progress)        // (chained launches: the host stops enqueuing)
+                        __hip_atomic_store(&L.progress->word, (1ull << 32) | static_cast<unsigned long long>(it), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_SYSTEM);
                 }
                 if (X.nranks > 1) {
                     // the peers are inside (or on their way to) this very exchange: they leave it with us, and every
@@ -1869,10 +1946,10 @@ __device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, c
         long long d = 0;
         if (lane <= 3 * kAccValues) {
 #pragma unroll
-            for (int r = 0; r < kLoopReplicas; ++r) d += (v[r] - per) >> 8;       // (exact: the low byte is the count)
+            for (int r = 0; r < COPIES; ++r) d += (v[r] - per) >> 8;       // (exact: the low byte is the count)
         }
 #pragma unroll
-        for (int r = 0; r < kLoopReplicas; ++r)
+        for (int r = 0; r < COPIES; ++r)
             __hip_atomic_store(&acc[r][lane], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         digits[lane] = d;
         __builtin_amdgcn_wave_barrier();
@@ -1972,6 +2049,9 @@ __device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, c
 #pragma unroll
         for (int i = 0; i < 7; ++i) st->T_icp[i] = Tn[i];
     }
+    if (L.progress && lane == 0)       // (chained launches: the host keeps a few launches enqueued ahead and stops at `done`)
+        __hip_atomic_store(&L.progress->word, (static_cast<unsigned long long>(done ? 1u : 0u) << 32) | static_cast<unsigned long long>(it + 1),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (done && lane < kNumSums) st->sums[lane] = S[lane];
     __builtin_amdgcn_wave_barrier();
     LOOP_STAMP_SOLVER(it, 2);
@@ -1989,6 +2069,7 @@ struct SolveArgs {
     LoopParams L;
     P2pParams X;
 };
+template <int COPIES>      // (two kernels: the one beside k_loop keeps its registers — 157, the grid's residency margin was measured with it)
 __global__ __launch_bounds__(64) void k_loop_solve(SolveArgs A) {
     __shared__ SolveLds m;
     __builtin_amdgcn_s_setprio(3);             // (the grid waits for this wave: its SIMD's other waves can)
@@ -2021,7 +2102,7 @@ __global__ __launch_bounds__(64) void k_loop_solve(SolveArgs A) {
         auto ka = __builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(ka));
         const SolveArgs &K = *(const SolveArgs *)(ka);
-        if (loop_finish_iteration(K.L, K.X, m, it, xg)) return;
+        if (loop_finish_iteration<COPIES>(K.L, K.X, m, it, xg)) return;
     }
 }
 
@@ -2068,7 +2149,7 @@ void k_loop(LoopArgs A) {
         X.nranks = 1;
         unsigned long long xg = 0ull;
         for (int it = 0;; ++it)
-            if (loop_finish_iteration(L, X, m, it, xg)) return;
+            if (loop_finish_iteration<kLoopReplicas>(L, X, m, it, xg)) return;
     }
 #endif
 
@@ -2643,7 +2724,8 @@ void launch_loop_solve(const LoopParams &l, const P2pParams &x, hipStream_t s) {
     SolveArgs a;
     a.L = l;
     a.X = x;
-    hipLaunchKernelGGL(k_loop_solve, dim3(1), dim3(64), 0, s, a);
+    if (l.copies == kChainReplicas) hipLaunchKernelGGL(k_loop_solve<kChainReplicas>, dim3(1), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(k_loop_solve<kLoopReplicas>, dim3(1), dim3(64), 0, s, a);
 }
 
 int launch_gn(const GnParams &p, hipStream_t s) {
