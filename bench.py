@@ -556,6 +556,7 @@ def main():
                          ("launch per iteration" if not any(st.single_launch for st in stats) else "mixed"),
             "lanes_per_query": int(stats[-1].lanes_per_query), "queries": int(hi - lo),
             "calls_single_launch": int(ls.calls_single_launch), "calls_per_iteration": int(ls.calls_per_iteration),
+            "calls_chained": int(ls.calls_chained),
             "loop_timeouts": int(ls.timeouts), "last_fallback": int(ls.last_fallback)}
     per_rank = [mine]
     if use_dist:
@@ -638,7 +639,9 @@ def main():
                                  else "full 32-B fp64 records",
                     "loop_form": "one launch for the whole loop (k_loop + its solving wave): avg_launch_us is the "
                                  "launch / its iterations, solve and hand-offs included"
-                                 if one_launch else "k_icp + k_fin per iteration",
+                                 if one_launch else ("k_icp launches chained (no k_fin between them: the solving wave of the one-launch loop "
+                                                     "resident beside them); avg_launch_us is k_icp alone, ms_per_step the whole iteration"
+                                                     if mine["calls_chained"] else "k_icp + k_fin per iteration"),
                     "candidates_per_query": round(cand_per_launch / max(n_local, 1), 1),
                     "pairs_evaluated_frac": round(pairs / max(cands, 1), 4),
                     "pair_counts": "the library's per-wave counters (C_q, pairs evaluated) are off in the timed region — "

@@ -226,6 +226,8 @@ int sageicp_register_frame_resident(const sageicp_map *map, const sageicp_frame 
 typedef struct sageicp_loop_status {
     uint64_t calls_single_launch;       /* registrations of this handle that ran in one launch */
     uint64_t calls_per_iteration;       /* ... through the launch-per-iteration form */
+    uint64_t calls_chained;             /* ... of those, with the launches chained: no k_fin between them, the solving wave of the
+                                         * one-launch form resident beside them (frames beyond the LDS on one GPU) */
     uint32_t timeouts;                  /* launches that gave up (each cost its time-out, 50 ms by default, before the fall-back) */
     uint32_t cooldown_calls;            /* calls that will still stay away from the one-launch form */
     uint32_t derate_workgroups;         /* workgroups taken off every later plan of this handle (32 per time-out, at most 512) */

@@ -226,7 +226,7 @@ if not getattr(_Environ, "_sageicp_hooked", False):
 
 
 class LoopStatus(C.Structure):
-    _fields_ = [("calls_single_launch", C.c_uint64), ("calls_per_iteration", C.c_uint64), ("timeouts", C.c_uint32),
+    _fields_ = [("calls_single_launch", C.c_uint64), ("calls_per_iteration", C.c_uint64), ("calls_chained", C.c_uint64), ("timeouts", C.c_uint32),
                 ("cooldown_calls", C.c_uint32), ("derate_workgroups", C.c_uint32), ("last_fallback", C.c_int32)]
 
 

@@ -668,6 +668,7 @@ int sageicp_map_loop_status(const sageicp_map *m, sageicp_loop_status *out) {
     const Scratch &sc = m->sc;
     out->calls_single_launch = sc.calls_single_launch;
     out->calls_per_iteration = sc.calls_per_iteration;
+    out->calls_chained = sc.calls_chained;
     out->timeouts = sc.loop_timeouts;
     out->cooldown_calls = static_cast<uint32_t>(std::max(0, sc.loop_cooldown));
     out->derate_workgroups = 32u * static_cast<uint32_t>(std::max(0, sc.loop_derate));

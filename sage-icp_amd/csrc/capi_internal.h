@@ -149,7 +149,7 @@ struct Scratch {
     int loop_cooldown = 0;         // calls that stay away from k_loop after one of its launches timed out
     int loop_derate = 0;           // x 32 workgroups fewer than the residency rule allows: one more after every time-out
     // what sageicp_map_loop_status reports
-    uint64_t calls_single_launch = 0, calls_per_iteration = 0;
+    uint64_t calls_single_launch = 0, calls_per_iteration = 0, calls_chained = 0;
     uint32_t loop_timeouts = 0;
     int last_fallback = 0;
     unsigned long long *d_cand = nullptr;      // per-wave counters of k_icp [2 x sort_cap]

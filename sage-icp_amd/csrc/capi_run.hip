@@ -740,6 +740,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     }
     for (int i = 0; i < 7; ++i) out[i] = st.T[i];
     if (looped) ++sc.calls_single_launch; else ++sc.calls_per_iteration;
+    if (!looped && chain) ++sc.calls_chained;
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         stats->iterations = st.iter;

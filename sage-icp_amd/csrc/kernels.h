@@ -77,6 +77,12 @@ struct IcpParams {
     // instead: c4 -3 % against -7 %, profiles/r06/lpt_max_ab.txt; stripes of 4, 2, 1 workgroups: within 1.5 %, lpt_stripe_ab.txt).
     uint32_t *stripe_work;    // optional, out: [stripes] max over the stripe's waves of the most points one of a wave's queries was handed
     const uint32_t *stripe_order;  // optional: [stripes] the stripe dispatched at each position (null: the order of the frame)
+    unsigned long long *counters;  // optional: [2 x waves] running sums of {C_q, pairs evaluated}
+    unsigned nwaves;          // waves that own queries: ceil(n / (64 >> lw))
+#ifdef SAGE_ICP_DELAY_PROBE
+    unsigned dbg_delay;       // probe builds: ticks (100 MHz) a wave waits for "the pose" after its start
+    unsigned dbg_repeat;      // probe builds: extra passes of the whole body inside one launch (warm L2s)
+#endif
     // k_icp, chained (frames beyond the LDS, one GPU): the launches of the iterations follow each other without a k_fin in
     // between — the solving wave of the one-launch loop (k_loop_solve, resident beside them on its own stream) collects the
     // sums as the last workgroup of a launch sends them, solves while the next launch starts, and the first wave of every
@@ -86,12 +92,6 @@ struct IcpParams {
     int chain_iter;
     unsigned long long chain_timeout;   // 100-MHz ticks a workgroup waits for its pose
     unsigned long long chain_epoch;     // launch 0 tells the solving wave to start (LoopShared::go)
-    unsigned long long *counters;  // optional: [2 x waves] running sums of {C_q, pairs evaluated}
-    unsigned nwaves;          // waves that own queries: ceil(n / (64 >> lw))
-#ifdef SAGE_ICP_DELAY_PROBE
-    unsigned dbg_delay;       // probe builds: ticks (100 MHz) a wave waits for "the pose" after its start
-    unsigned dbg_repeat;      // probe builds: extra passes of the whole body inside one launch (warm L2s)
-#endif
 };
 
 #ifndef SAGE_ICP_WAVES
@@ -169,13 +169,14 @@ constexpr int kLoopReplicas = 8;           // accumulator copies (workgroup b ad
 constexpr int kLoopPoseGranules = 25;      // R[9], t[3] as 24 x {tag, 32 bits} + {tag, done}
 constexpr int kChainReplicas = 32;         // accumulator copies of the chained launches (k_icp: thousands of workgroups, <= 255 per copy)
 struct LoopShared {
-    long long acc32[2][kChainReplicas][kAccWords];      // the chained launches' accumulators (as acc below, 32 copies)
     long long acc[2][kLoopReplicas][kAccWords];         // as FinParams::acc, one set per iteration parity, every word
                                                         // (digit << 8) | workgroups in it; word 51: (workgroups whose sums overflowed << 8) | workgroups
     unsigned long long pose[32];                        // granules (tag << 32) | payload, tag = iteration + 1
     unsigned long long abort_word[16];                  // [0] != 0: a wait timed out somewhere — everybody leaves
     unsigned long long go[16];                          // [0]: the call's epoch, stored by k_loop's first workgroup when the
                                                         // grid has started (bit 63: the frame holds a non-finite point)
+    long long acc32[2][kChainReplicas][kAccWords];      // the chained launches' accumulators (as acc above, 32 copies; last:
+                                                        // what k_loop touches keeps its small offsets)
 };
 struct LoopParams {
     LoopShared *sh;
@@ -194,15 +195,15 @@ struct LoopParams {
                                    // grid fills the machine) and waits for LoopShared::go to carry this number
     double T0[7];                  // the initial pose (the solving wave starts before the loop state is uploaded)
     double acc_unscale;            // 1 / IcpParams::acc_scale
-    int copies;                    // accumulator copies the workgroups add into: kLoopReplicas (k_loop: LoopShared::acc) or
-                                   // kChainReplicas (chained k_icp launches: LoopShared::acc32)
-    IcpProgress *progress;         // optional (chained launches): the host-mapped word the host steers its look-ahead by
     int shared_loop;               // 1: under a communicator — an overflowing sum or a bad frame point does not end
                                    // this rank's loop on its own (the ranks must keep exchanging in step)
     int prio;                      // wave priorities by the work of a wave's unit (kernels.hip, k_loop): 0 off | 1..3: on, the
                                    // priority of a unit beyond one per wave
     int deal;                      // 1: a wave's FIRST unit of an iteration is fixed by where the wave sits — unit (SIMD +
                                    // the workgroup's slot on the CU) mod waves — instead of first come first served (k_loop)
+    int copies;                    // accumulator copies the workgroups add into: kLoopReplicas (k_loop: LoopShared::acc) or
+                                   // kChainReplicas (chained k_icp launches: LoopShared::acc32)
+    IcpProgress *progress;         // optional (chained launches): the host-mapped word the host steers its look-ahead by
 };
 struct LoopArgs {                  // k_loop's one argument: its passes re-read it from the kernel-argument segment
     IcpParams P;

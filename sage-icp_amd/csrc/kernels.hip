@@ -757,10 +757,16 @@ __device__ __forceinline__ void icp_body(const IcpParams &P, uint32_t *smem, Loo
             if (smem[kWgGo]) return;
         }
     }
-    const double *lpose = reinterpret_cast<const double *>(smem + kWgPose);       // (FUSED && !PERSIST: the workgroup's copy)
-    const Query s = PERSIST ? make_query<(W >= 4)>(f, pose, pose + 9, 1, P.voxel_size, P.inv_voxel_size)
-                   : FUSED  ? make_query<(W >= 4)>(f, lpose, lpose + 9, P.apply_pose, P.voxel_size, P.inv_voxel_size)
-                            : make_query<(W >= 4)>(f, P.st->R, P.st->T + 4, P.apply_pose, P.voxel_size, P.inv_voxel_size);
+    const Query s = [&]() {
+        if constexpr (PERSIST) {
+            return make_query<(W >= 4)>(f, pose, pose + 9, 1, P.voxel_size, P.inv_voxel_size);
+        } else if constexpr (FUSED) {
+            const double *lpose = reinterpret_cast<const double *>(smem + kWgPose);       // the workgroup's copy
+            return make_query<(W >= 4)>(f, lpose, lpose + 9, P.apply_pose, P.voxel_size, P.inv_voxel_size);
+        } else {
+            return make_query<(W >= 4)>(f, P.st->R, P.st->T + 4, P.apply_pose, P.voxel_size, P.inv_voxel_size);
+        }
+    }();
     const bool stale = valid && (static_cast<uint32_t>(s.kx) != rk.x || static_cast<uint32_t>(s.ky) != rk.y ||
                                  static_cast<uint32_t>(s.kz) != rk.z);
     unsigned occ = rk.w;
