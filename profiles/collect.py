@@ -88,6 +88,11 @@ entry = {
                           "--pmc runs one kernel at a time), divided by the launch's %d iterations; the duration is the "
                           "PRODUCT's, from --kernel-trace" % iters if loop else
                           "; no-op launches of a finished loop excluded"),
+    # (the source hash covers the sources, not the -D flags or switches of the counter passes: said here)
+    "counter_build": ("-DSAGE_LOOP_INGRID twin of the library (sage-icp_amd/_probe/libsageicp_ingrid.so): bytes and instruction counts of "
+                      "the twin over the kernel-trace time of the product" if loop else
+                      "the product library with SAGEICP_CHAIN=0 (k_fin between the launches instead of the resident solving wave: "
+                      "the same k_icp)"),
     "avg_launch_us_kernel_trace": round(avg_us, 2),
     "k_fin_avg_us_kernel_trace": round(fin[0][2] / 1e3, 2) if fin and not loop else None,
     "avg_launch_us_fetch_pass": round(fetch_us, 2),

@@ -20,6 +20,9 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o k
 # collection twin of the library (sage-icp_amd/_probe/libsageicp_ingrid.so, -DSAGE_LOOP_INGRID: the solving wave
 # is one more workgroup of the grid; same search code, same bytes and instructions, not the same time).
 if [ -f $R/sage-icp_amd/_probe/libsageicp_ingrid.so ]; then export SAGEICP_VARIANT_LIB=$R/sage-icp_amd/_probe/libsageicp_ingrid.so; fi
+# ... and the chained launches of the frames beyond the LDS (k_icp beside the resident solving wave: two kernels that talk
+# to each other as well) run with k_fin between them (SAGEICP_CHAIN=0): the same k_icp, the same bytes and instructions.
+export SAGEICP_CHAIN=0
 PM="$BENCH --steps 1 --warmup 0 --no-profile-events"
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$K" --output-format csv -d $OUT/pmc_fetch -o pmc -- $PM > /dev/null 2> $OUT/pmc_fetch.err
 timeout 400 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-include-regex "$K" --output-format csv -d $OUT/pmc_tcc -o pmc -- $PM > /dev/null 2> $OUT/pmc_tcc.err
@@ -27,6 +30,7 @@ timeout 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY S
 timeout 400 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_THREAD_CYCLES_VALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD --kernel-include-regex "$K" --output-format csv -d $OUT/pmc_sq2 -o pmc -- $PM > /dev/null 2> $OUT/pmc_sq2.err
 timeout 400 rocprofv3 --pmc TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS --kernel-include-regex "$K" --output-format csv -d $OUT/pmc_mem -o pmc -- $PM > /dev/null 2> $OUT/pmc_mem.err
 unset SAGEICP_VARIANT_LIB
+unset SAGEICP_CHAIN
 cd $R
 # the un-profiled line of the same workload (with the CPU baseline and the parity block)
 timeout 900 python bench.py --workload $WL --params $PRM > $OUT/bench_default.json 2> $OUT/bench_default.err
