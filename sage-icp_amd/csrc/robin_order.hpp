@@ -259,10 +259,21 @@ public:
     // back, and the loop goes on at p + 1 — so exactly one kind of far entry is NOT erased in this sweep: the one that
     // stood at p + 1 and moved into p, behind the loop.  Every other entry that moved is still ahead of it.  Hence: the
     // far entries in bucket order; one that is found behind the position the loop has reached was skipped, every
-    // other one is erased where it stands now.  (An entry cannot pass the loop the other way: bucket 0 is looked at
-    // first, before anything was erased.)  O(far entries), not O(buckets).
+    // other one is erased where it stands now.  O(far entries), not O(buckets).
+    // That argument needs the array not to be a ring: a run of entries that wraps around its end (bucket 0 holding an
+    // entry away from its home) lets a shift carry a skipped entry from bucket 0 to the last bucket — AHEAD of the
+    // loop again, which then erases it after all.  Erasures only move entries towards their homes, so a table without
+    // such a run before the sweep has none during it; one with it (a few in a thousand sweeps of a small table) takes
+    // the sweep as written, with the list as its predicate.
     template <class E>
     void sweep_erase_listed(std::vector<std::pair<uint32_t, uint32_t>> far, E on_erase) {
+        if (!b_.empty() && (b_[0] >> 48) > 1) {
+            std::vector<uint32_t> vals(far.size());
+            for (size_t k = 0; k < far.size(); ++k) vals[k] = far[k].second;
+            std::sort(vals.begin(), vals.end());
+            sweep_erase([&](uint32_t v) { return std::binary_search(vals.begin(), vals.end(), v); }, on_erase);
+            return;
+        }
         std::vector<std::pair<size_t, size_t>> at(far.size());          // (bucket before the sweep, index into far)
         for (size_t k = 0; k < far.size(); ++k) at[k] = {find(far[k].first, far[k].second), k};
         std::sort(at.begin(), at.end());

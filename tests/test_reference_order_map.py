@@ -233,12 +233,15 @@ def test_random_update_sequences_on_the_device_against_the_oracle(gpu_sage, orac
     its bucket array — RobinTable::sweep_erase_listed — and the device evicts what the sweep reached): after every
     update the map is the oracle's in mode 3, Pointcloud() byte for byte and IN ORDER, also across Clear(), jumps back
     into evicted ground, and a switch to host-side updates and back"""
-    from hypothesis import given, settings, HealthCheck, strategies as st
+    from hypothesis import example, given, settings, HealthCheck, strategies as st
 
-    @settings(max_examples=25, deadline=None, suppress_health_check=list(HealthCheck))
+    # (the example: a 64-bucket table whose run wraps around the end of the array — the listed sweep of round 6's first
+    # form left one voxel too many; tests/test_robin_order.py holds the host-side half of it)
+    @settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck))
     @given(seed=st.integers(0, 2**31 - 1), vs=st.sampled_from([0.5, 1.0, 2.0]), rng_m=st.sampled_from([8.0, 20.0, 45.0]),
            basic=st.integers(1, 6), critical=st.integers(0, 6), step=st.sampled_from([0.0, 3.0, 9.0, 25.0]),
            n_pts=st.sampled_from([1, 40, 600, 3000]))
+    @example(seed=1356125, vs=2.0, rng_m=45.0, basic=1, critical=0, step=0.0, n_pts=40)
     def run(seed, vs, rng_m, basic, critical, step, n_pts):
         rng = np.random.default_rng(seed)
         m = gpu_sage.VoxelHashMap(vs, rng_m, basic, critical, [40, 50]).set_reference_order(True)
