@@ -475,7 +475,10 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     // query crosses a voxel face.  (Round 1 re-sorted when the pose had drifted half a voxel; with a
     // lane per query that no longer pays for its ~90 us: 45.3 against 47.2 us per iteration on the
     // c2 cold start, profiles/README.md.)
-    if (n > 0)
+    // ... from kSortFrameFrom points on (kernels.h); SAGEICP_SORT_FROM overrides the size (0: always sorted)
+    if (n > 0 && n < static_cast<uint64_t>(std::max(0, env_int("SAGEICP_SORT_FROM", kSortFrameFrom))))
+        HIPCHK(check_copy_frame(d_frame, sc.d_sorted, static_cast<int>(n), sc.d_state, comm == nullptr, s));
+    else if (n > 0)
         HIPCHK(sort_frame(d_frame, sc.d_sorted, static_cast<int>(n), sc.d_state, true, comm == nullptr,
                           m->host.voxel_size, sc.d_keys, sc.d_vals, sc.d_sort_temp,
                           sc.sort_temp_bytes_, s));

@@ -277,5 +277,12 @@ int icp_stripes_for(int n, int lw);        // stripes of the k_icp launch of n q
 hipError_t sort_frame(const Point4 *d_in, Point4 *d_out, int n, IcpState *st, bool apply_pose, bool stop_on_bad,
                       double voxel_size, uint32_t *keys, uint32_t *vals, void *temp,
                       size_t temp_bytes, hipStream_t s);
+// The order is worth its launches from ~20 k points on (profiles/r06/nosort_ab.txt: 10 k points -4 %, 15 k -1 %, 30 k +3 %,
+// 60 k +11 % without it: a small frame's rows and the map under it are cache-resident in any order, and the twelve launches
+// of the sort are 27 us of a registration that takes 800).  Below, the frame is searched as it came — check_copy_frame: the
+// same refusal of non-finite input, one launch.  (The bits of a pose depend on which four queries form a block of the
+// exact sums, i.e. on the order: the rule looks at the frame's size only, so every form of the loop takes the same.)
+constexpr int kSortFrameFrom = 16384;
+hipError_t check_copy_frame(const Point4 *d_in, Point4 *d_out, int n, IcpState *st, bool stop_on_bad, hipStream_t s);
 
 }  // namespace sageicp

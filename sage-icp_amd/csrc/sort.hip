@@ -73,6 +73,28 @@ __global__ __launch_bounds__(256) void k_gather(const Point4 *in, const uint32_t
     out[i] = in[perm[i]];
 }
 
+// A frame too small for the order to pay (frame_sort_pays): the same refusal of non-finite input, the frame as it came.
+__global__ __launch_bounds__(256) void k_check_copy(const Point4 *pts, int n, IcpState *st, int stop_on_bad, Point4 *out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const Point4 f = pts[i];
+    if (!(fabs(f.x) <= 1.7976931348623157e308 && fabs(f.y) <= 1.7976931348623157e308 &&
+          fabs(f.z) <= 1.7976931348623157e308 && fabs(f.l) <= 1.7976931348623157e308)) {
+        st->bad_input = 1;
+        if (stop_on_bad) {
+            st->done = 1;
+            if (IcpProgress *pg = st->progress)
+                __hip_atomic_store(&pg->word, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    out[i] = f;
+}
+hipError_t check_copy_frame(const Point4 *d_in, Point4 *d_out, int n, IcpState *st, bool stop_on_bad, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_check_copy, dim3((n + 255) / 256), dim3(256), 0, s, d_in, n, st, stop_on_bad ? 1 : 0, d_out);
+    return hipGetLastError();
+}
+
 size_t sort_temp_bytes(int n) {
     size_t bytes = 0;
     uint32_t *k = nullptr;
