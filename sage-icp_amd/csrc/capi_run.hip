@@ -492,7 +492,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         IcpParams lp = ip;
         lp.filter = plan.filter ? ip.filter : 0;
         lp.nwaves = loop_waves;
-        HIPCHK(hipMemsetAsync(sc.d_loop, 0, sizeof(LoopShared), s));
+        HIPCHK(hipMemsetAsync(sc.d_loop, 0, offsetof(LoopShared, acc32), s));      // (the chained launches' copies are not this loop's)
         if (prof) HIPCHK(hipEventRecord(sc.events[1], s));
         launch_loop(lp, L, plan.lw, s);
         if (hipPeekAtLastError() == hipSuccess) solver_guard.sc = nullptr;      // the grid is on its way: it will say go
