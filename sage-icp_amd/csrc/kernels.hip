@@ -2036,6 +2036,15 @@ __device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, c
 #pragma unroll
         for (int i = 0; i < 9; ++i) pub[i] = Rn[i];
         pub[9] = Tn[4]; pub[10] = Tn[5]; pub[11] = Tn[6];
+    }
+    __builtin_amdgcn_wave_barrier();
+    LOOP_STAMP_SOLVER(it, 2);
+    // 4. publish: 24 halves of R, t and the done word, each with its tag — before the bookkeeping below: the grid waits
+    // for these words, nobody for the history (and the wait that follows would otherwise sit out those stores' round trip)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the clears of step 1, issued microseconds ago)
+    if (lane < 24) st_agent(&sh->pose[lane], (tag << 32) | reinterpret_cast<const uint32_t *>(pub)[lane]);
+    if (lane == 24) st_agent(&sh->pose[24], (tag << 32) | done);
+    if (lane == 0) {
         if (it < kHistory) st->n_corr[it] = static_cast<uint32_t>(S[kCount]);
         if (overflow) st->acc_overflow = 1;
         if (exchange_failed) st->exchange_failed = 1;
@@ -2059,12 +2068,6 @@ __device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, c
         __hip_atomic_store(&L.progress->word, (static_cast<unsigned long long>(done ? 1u : 0u) << 32) | static_cast<unsigned long long>(it + 1),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (done && lane < kNumSums) st->sums[lane] = S[lane];
-    __builtin_amdgcn_wave_barrier();
-    LOOP_STAMP_SOLVER(it, 2);
-    // 4. publish: 24 halves of R, t and the done word, each with its tag
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the clears of step 1, issued microseconds ago)
-    if (lane < 24) st_agent(&sh->pose[lane], (tag << 32) | reinterpret_cast<const uint32_t *>(pub)[lane]);
-    if (lane == 24) st_agent(&sh->pose[24], (tag << 32) | done);
     LOOP_STAMP_SOLVER(it, 3);
     return done;
 }
