@@ -1091,3 +1091,35 @@ def test_counters_can_be_switched_off(gpu_sage, oracle):
         assert sa.sum_candidates > 0 and sa.pairs_evaluated > 0
         assert sb.sum_candidates == 0 and sb.pairs_evaluated == 0
         assert (sa.iterations, sa.converged, sa.n_corr_first, sa.n_corr_last) == (sb.iterations, sb.converged, sb.n_corr_first, sb.n_corr_last)
+
+
+@pytest.mark.parametrize("n", [16383, 16384])
+def test_small_frames_are_searched_as_they_came(gpu_sage, oracle, monkeypatch, n):
+    """kSortFrameFrom (kernels.h): below 16,384 points the frame is not sorted (its launches cost more than the order
+    buys), from there on it is.  Either side of the limit: the oracle's registration (Registration.cpp:113-141) within
+    1e-7, its iteration and correspondence counts; the one-launch loop and the launch-per-iteration loop bit for bit;
+    and the other order of the same frame (SAGEICP_SORT_FROM) within 1e-9 with the same iterations — the order moves
+    which four queries share a block of the exact sums, i.e. ulps, never the search"""
+    from sage_icp_amd import synthetic as syn
+    w, om = _workload(gpu_sage, oracle, "c2", 0.15)
+    p = syn.PARAMS["cold"]
+    scan = np.ascontiguousarray(w["scan"][:n])
+    assert len(scan) == n
+    pose, st = gpu_sage.register_frame(scan, w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"], return_stats=True)
+    opose, ost = om.register_frame(scan, oracle.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"])
+    assert st.single_launch == 1 and st.converged == 1
+    assert np.abs(pose - opose).max() < 1e-7 and st.iterations == ost.iterations
+    assert st.n_corr_first == ost.n_corr_first and st.n_corr_last == ost.n_corr_last
+    monkeypatch.setenv("SAGEICP_LOOP", "0")
+    per_it, sp = gpu_sage.register_frame(scan, w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"], return_stats=True)
+    assert sp.single_launch == 0 and np.array_equal(per_it, pose) and sp.iterations == st.iterations
+    monkeypatch.delenv("SAGEICP_LOOP")
+    monkeypatch.setenv("SAGEICP_SORT_FROM", "0" if n < 16384 else "1000000")
+    other, so = gpu_sage.register_frame(scan, w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"], return_stats=True)
+    assert np.abs(other - pose).max() < 1e-9 and so.iterations == st.iterations and so.n_corr_last == st.n_corr_last
+    # a non-finite point in a frame that is not sorted is refused by the launch that stands in for the sort
+    bad = scan.copy()
+    bad[n // 2, 1] = np.nan
+    monkeypatch.delenv("SAGEICP_SORT_FROM")
+    with pytest.raises(gpu_sage.SageIcpError):
+        gpu_sage.register_frame(bad, w["map"], gpu_sage.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"])
