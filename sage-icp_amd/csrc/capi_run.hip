@@ -200,6 +200,15 @@ static bool plan_loop(const sageicp_map *m, uint64_t n, double sem_th, LoopPlan 
     const int env_nw = std::min(kLoopMaxWavesHost, std::max(0, env_int("SAGEICP_LOOP_WAVES", 0)));
     const int env_gpw = std::max(0, env_int("SAGEICP_LOOP_GPW", 0));
     auto groups_at = [n](int l) { return (n + (64u >> l) - 1) / (64u >> l); };
+    // the workgroup slots a launch may count on: k per CU less a sixteenth (below) — and behind a CU mask (SAGEICP_CU_SHARE:
+    // ranks sharing one GPU) one per CU fewer for every halving of the device: on half of the CUs six of seven workgroups per
+    // CU are resident (832 of 896 time out, 768 hold), on a quarter five (384 time out, 320 hold): profiles/r06/run48.sh, run50.sh
+    auto slots = [&](int k) {
+        const uint64_t a = static_cast<uint64_t>(k) * cus * 15 / 16;
+        int less = 0;
+        for (int sh = 1; sh < sc.cu_share_k; sh *= 2) ++less;
+        return (less > 0 && k > less) ? std::min(a, static_cast<uint64_t>(k - less) * cus) : a;
+    };
     auto round32 = [](uint64_t w) { return std::max<uint64_t>(32, (w + 31) / 32 * 32); };   // (XCD stripes: 8 x kLoopStripe)
     // the accumulator words count their workgroups in 8 bits, and (digit << 8) summed over the blocks of four
     // queries of a copy's workgroups must stay inside 63 bits: |digit| < 2^40 per block (kernels.hip, to_digits)
@@ -211,7 +220,7 @@ static bool plan_loop(const sageicp_map *m, uint64_t n, double sem_th, LoopPlan 
         const uint64_t wgs = round32((groups_at(lw) + nw - 1) / nw);
         const size_t lds = loop_lds_bytes(lw, nw, nw);
         const int k = loop_wgs_per_cu(sc, lw, filter, nw, lds);
-        if (k < 1 || wgs + 32ull * static_cast<uint64_t>(sc.loop_derate) > static_cast<uint64_t>(k) * cus * 15 / 16 || !countable(wgs, nw, lw)) return false;
+        if (k < 1 || wgs + 32ull * static_cast<uint64_t>(sc.loop_derate) > slots(k) || !countable(wgs, nw, lw)) return false;
         *pl = LoopPlan{lw, nw, nw, static_cast<int>(wgs), filter};
         return true;
     };
@@ -229,7 +238,7 @@ static bool plan_loop(const sageicp_map *m, uint64_t n, double sem_th, LoopPlan 
                 // (measured, profiles/r05/resident_probe: of the 7 x 256 = 1,792 slots for workgroups of four waves
                 // 1,696 are resident together beside the solving wave, 1,728 are not; a sixteenth stays free, and
                 // a launch that still times out takes another 32 workgroups off every later plan of this handle)
-                uint64_t cap = static_cast<uint64_t>(k) * cus * 15 / 16 / 32 * 32;
+                uint64_t cap = slots(k) / 32 * 32;
                 cap = cap > 32ull * static_cast<uint64_t>(sc.loop_derate) ? cap - 32ull * static_cast<uint64_t>(sc.loop_derate) : 0;
                 if (cap < 32) continue;
                 if (const int e = env_int("SAGEICP_LOOP_MAX_WGS", 0)) cap = std::min<uint64_t>(cap, static_cast<uint64_t>(e) / 32 * 32);   // (probes)
