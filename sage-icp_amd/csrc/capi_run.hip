@@ -213,7 +213,7 @@ static bool plan_loop(const sageicp_map *m, uint64_t n, double sem_th, LoopPlan 
     // the accumulator words count their workgroups in 8 bits, and (digit << 8) summed over the blocks of four
     // queries of a copy's workgroups must stay inside 63 bits: |digit| < 2^40 per block (kernels.hip, to_digits)
     auto countable = [](uint64_t wgs, uint64_t gpw, int lw) {
-        return wgs / 8 <= 255 && (wgs / 8) * gpw * ((64u >> lw) / 4u) <= 8192;
+        return wgs / kLoopReplicas <= 255 && (wgs / kLoopReplicas) * gpw * ((64u >> lw) / 4u) <= 8192;
     };
     // one wave per group: nw groups per workgroup of nw waves
     auto one_pass = [&](int lw, int nw, LoopPlan *pl) {

@@ -165,7 +165,14 @@ void launch_fin(const FinParams &p, hipStream_t s);
 // wave per workgroup waiting for it: no kernel boundary, no k_fin.  Everything the workgroups share
 // inside the launch is accessed with agent-scope atomics only (per-XCD L2s are not coherent with each
 // other); the block is zeroed before every launch; every wait is bounded.
-constexpr int kLoopReplicas = 8;           // accumulator copies (workgroup b adds into copy b & 7)
+#ifndef SAGE_LOOP_REPLICAS
+#define SAGE_LOOP_REPLICAS 8
+#endif
+constexpr int kLoopReplicas = SAGE_LOOP_REPLICAS;      // accumulator copies (workgroup b adds into copy b & 7: one copy per XCD)
+// (One copy per XCD is what matters, not their number: workgroup b runs on XCD b % 8, so a copy's words are only ever
+// touched by one XCD's atomics.  Four copies — two XCDs per copy — cost a 15 k-query grid 12 % and a 30 k one 7 %, sixteen are
+// no different from eight: profiles/r06/replicas_ab.txt, copies_ab.txt.  The chained launches' 32 and k_fin's 32 keep the
+// same property: b % 32 determines b % 8.)
 constexpr int kLoopPoseGranules = 25;      // R[9], t[3] as 24 x {tag, 32 bits} + {tag, done}
 constexpr int kChainReplicas = 32;         // accumulator copies of the chained launches (k_icp: thousands of workgroups, <= 255 per copy)
 struct LoopShared {
