@@ -281,6 +281,10 @@ public:
         for (const auto &pk : at) {
             const auto &f = far[pk.second];
             const size_t pos = find(f.first, f.second);
+            if (pos >= b_.size()) {                                       // not in the table: the caller's list and this array have
+                max_field_ = 0xFFFFu;                                     // parted ways — the order is no longer claimed (valid())
+                continue;
+            }
             if (pos < next) continue;                                     // moved into the bucket just erased: not looked at
             on_erase(f.second);
             erase_at(pos);
