@@ -24,7 +24,7 @@ for _ in range(3):
     pose, st = sage.register_frame(f, w["map"], sage.IDENTITY, p["max_dist"], p["kernel"], p["sem_th"], return_stats=True)
 assert st.single_launch == 1
 IT, WG = 32, 2048
-wg = np.zeros((IT, WG, 2), dtype=np.uint64)
+wg = np.zeros((IT, WG, 4), dtype=np.uint64)      # (round 6: four stamps per workgroup; this script reads the first two — loop_tail.py the rest)
 sv = np.zeros((IT, 4), dtype=np.uint64)
 sage.lib().sageicp_debug_loop_times(wg.ctypes.data_as(C.c_void_p), sv.ctypes.data_as(C.c_void_p))
 wg = wg.astype(np.float64) / 100.0
