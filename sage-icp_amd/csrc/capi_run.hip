@@ -405,8 +405,14 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
     // call or its cool-down: a GPU that did not hold that grid is not asked to hold a resident solving wave either.)
     const int chain_grid = n > 0 ? icp_blocks_for(static_cast<int>(n), lw) : 0;
     // (profiling level 2 asks for the time of every kernel of every iteration, k_fin's too: the form with k_fin)
-    const bool chain = !loop_shape && !comm && polled && n > 0 && chain_grid / kChainReplicas <= 255 && !g_no_chain && !prof2 &&
-                       env_int("SAGEICP_CHAIN", 1) != 0;
+    // (Under a communicator with the direct exchange the form exists too — the exchange is the solving wave's, as in the
+    // one-launch loop; parity-green and in step when a rank loses it, tests/test_gpu_parity.py — but it is OFF unless
+    // SAGEICP_CHAIN_COMM=1: the only place it could be measured, two processes sharing one GPU, runs c4 twice as slowly
+    // with it (42.7 against 21.0 ms per frame: the waiting launches of two processes on one device's queues,
+    // profiles/r06/run63.sh); on a GPU per rank it has never run.  Never for several ranks of one process on one device.)
+    const bool chain_comm = comm && p2p && !comm->device_shared && env_int("SAGEICP_CHAIN_COMM", 0) != 0;
+    const bool chain = !loop_shape && (!comm || chain_comm) && polled && n > 0 &&
+                       chain_grid / kChainReplicas <= 255 && !g_no_chain && !prof2 && env_int("SAGEICP_CHAIN", 1) != 0;
     if ((use_loop || chain) && (rc = sc.loop_streams())) return rc;
     if (chain) {
         L.sh = sc.d_loop;
@@ -419,6 +425,16 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         // (the solving wave waits for a whole LAUNCH here, not for resident workgroups: the first launch of a process
         // loads code objects, a big frame's launch takes its hundred microseconds)
         L.count_timeout_ticks = std::max<unsigned long long>(L.timeout_ticks, 20ull * 100000ull) * 10ull;
+        if (comm) {
+            // (as for the one-launch loop: a launch waits for a pose that waits for the peers' sums — its patience has to
+            // outlast the exchange's; the solving wave's wait for its OWN launch stays local)
+            L.shared_loop = 1;
+            if (env_int("SAGEICP_LOOP_TIMEOUT_TICKS", 0) == 0)
+                L.timeout_ticks = std::max(L.timeout_ticks, xp.timeout_ticks + 100000000ull);
+            // (tests: ONE rank of a communicator loses its launches — the others must follow it out of the exchange)
+            if (env_int("SAGEICP_LOOP_COUNT_TIMEOUT_RANK", -1) == comm->rank)
+                L.count_timeout_ticks = static_cast<unsigned long long>(std::max(1, env_int("SAGEICP_LOOP_COUNT_TIMEOUT_TICKS", 1)));
+        }
         L.max_iterations = max_it;
         L.epoch = ++sc.loop_epoch;
         for (int i = 0; i < 7; ++i) L.T0[i] = init[i];
@@ -646,6 +662,7 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
         volatile unsigned long long *word = &sc.h_prog->word;
         int enq = 0;
         unsigned spins = 0;
+        unsigned long long idle_word = ~0ull;       // (chained: the progress word at the last look that found the stream idle)
         for (;;) {
             const unsigned long long w = *word;
             const int comp = static_cast<int>(w & 0xFFFFFFFFull);
@@ -663,6 +680,15 @@ int run_icp(const sageicp_map *m, const Point4 *d_frame, uint64_t n, const doubl
                     return fail(SAGEICP_ERR_HIP, std::string("ICP loop: ") + hipGetErrorString(q));
                 if (q == hipSuccess && (*word >> 32) == 0 && enq >= max_it)
                     break;     // everything ran and nothing flagged the end: read the state below
+                if (chain && q == hipSuccess) {
+                    // chained: every launch enqueued has run, and the solving wave has said nothing new for a whole
+                    // interval (~1 ms; a solve takes microseconds) — it is gone (an exit that did not reach the progress
+                    // word): the state below says why, and the frame is registered again with k_fin
+                    if (idle_word == *word) break;
+                    idle_word = *word;
+                } else {
+                    idle_word = ~0ull;
+                }
             }
         }
         if (chain && solver_guard.sc) {

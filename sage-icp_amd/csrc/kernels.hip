@@ -1989,6 +1989,9 @@ __device__ __forceinline__ unsigned loop_finish_iteration(const LoopParams &L, c
                 st->loop_aborted = 1;
                 st->peer_aborted = 1;
                 st_agent(&sh->pose[24], (tag << 32) | 2ull);
+                if (L.progress)        // (chained launches: the host stops enqueuing)
+                    __hip_atomic_store(&L.progress->word, (1ull << 32) | static_cast<unsigned long long>(it), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
             }
             return 2u;
         }

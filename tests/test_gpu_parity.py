@@ -864,6 +864,44 @@ def test_one_rank_loses_its_one_launch_loop_and_all_ranks_follow_in_step(gpu_sag
     assert hurt["config"]["correspondences_first_last"] == good["config"]["correspondences_first_last"]
 
 
+def test_chained_launches_under_a_communicator(gpu_sage):
+    """frames beyond the one-launch loop under a communicator with the direct exchange (SAGEICP_CHAIN_COMM=1: off by default,
+    capi_run.hip says why): the launches of the iterations chained beside each rank's resident solving wave, which makes
+    the exchange (as in the one-launch loop) — no k_fin.
+    Two processes on the one GPU, the one-launch loop switched off: the chained run registers the frame exactly as the
+    run with k_fin between the launches; and a rank whose solving wave loses its launches (10 ns of patience) takes its
+    peer out of the exchange with it, both register the frame again with k_fin, in step, and the run ends normally"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SAGEICP_BENCH_DEVICE="0", SAGEICP_BENCH_BACKEND="gloo", SAGEICP_P2P_TIMEOUT_S="5",
+               MASTER_ADDR="127.0.0.1", SAGEICP_LOOP="0", SAGEICP_CHAIN_COMM="1")
+    common = ["--steps", "2", "--warmup", "1", "--scale", "0.1", "--no-cpu-baseline"]
+
+    def two_ranks(extra, port):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                            "--gpus", "2", "--exchange", "direct"] + common,
+                           capture_output=True, text=True, env=dict(env, **extra), timeout=240)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads(r.stdout.strip().splitlines()[-1]), r.stderr
+
+    chained, _ = two_ranks({}, 29551)
+    with_fin, _ = two_ranks({"SAGEICP_CHAIN": "0"}, 29553)
+    hurt, err = two_ranks({"SAGEICP_LOOP_COUNT_TIMEOUT_RANK": "1", "SAGEICP_LOOP_COUNT_TIMEOUT_TICKS": "1"}, 29555)
+    for r in chained["config"]["per_rank"]:
+        assert r["loop_form"] == "launch per iteration" and r["calls_chained"] >= 3 and r["loop_timeouts"] == 0
+    for r in with_fin["config"]["per_rank"]:
+        assert r["calls_chained"] == 0
+    assert chained["config"]["exchange"] == with_fin["config"]["exchange"] == hurt["config"]["exchange"] == "direct"
+    for other in (with_fin, hurt):
+        assert other["config"]["iterations_per_frame"] == chained["config"]["iterations_per_frame"]
+        assert other["config"]["converged"] and other["config"]["pose_error_vs_planted"] == chained["config"]["pose_error_vs_planted"]
+        assert other["config"]["correspondences_first_last"] == chained["config"]["correspondences_first_last"]
+    assert "chained ICP launches timed out" in err
+
+
 def test_bench_independent_frames_mode(gpu_sage):
     """bench.py --independent (the throughput curve of BASELINE config 5): two ranks on the one GPU
     of the box, each registering the whole frame against its own map, no exchange: weak scaling,
