@@ -9,6 +9,11 @@ import os
 
 import numpy as np
 import pytest
+
+
+def _examples(n):
+    """SAGE_TEST_EXAMPLES=k runs k times the usual number of random examples (campaigns; profiles/README.md)"""
+    return n * max(1, int(os.environ.get("SAGE_TEST_EXAMPLES", "1")))
 from hypothesis import HealthCheck, given, settings, strategies as st
 
 pytestmark = pytest.mark.gpu
@@ -57,7 +62,7 @@ def test_correspondences_index_exact(gpu_sage, oracle, seed, vs, basic, critical
     assert np.array_equal(tgt, otgt) and np.array_equal(src, osrc)
 
 
-@settings(max_examples=150, deadline=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=_examples(150), deadline=None, suppress_health_check=list(HealthCheck))
 @given(seed=st.integers(0, 2**31 - 1), vs=st.sampled_from([0.1, 0.3, 0.8, 1.0, 2.5]),
        th=st.sampled_from([0.05, 0.4, 1.0, 1.7]), md=st.sampled_from([0.2, 0.9, 2.0, 6.0]),
        basic=st.integers(0, 24), critical=st.integers(1, 24), span=st.sampled_from([1.5, 6.0, 20.0]),
@@ -567,7 +572,7 @@ def test_register_frame_with_initial_guess_and_edge_inputs(gpu_sage, oracle, sca
     assert st.iterations == 1 and st.n_corr_first == 0
 
 
-@settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=_examples(60), deadline=None, suppress_health_check=list(HealthCheck))
 @given(seed=st.integers(0, 2**31 - 1), vs=st.sampled_from([0.3, 0.8, 1.0, 2.0]),
        sigma=st.sampled_from([0.3, 1.0, 2.0]), th=st.sampled_from([0.05, 0.4, 1.0]),
        lw=st.integers(0, 4), compact=st.booleans(), n_q=st.sampled_from([200, 3000, 12000]),

@@ -2,7 +2,13 @@
 product (bit-identical block contents and order expected) and against the CPU oracle (same set
 of points per voxel, same search results).  Needs the MI355X."""
 import numpy as np
+import os
 import pytest
+
+
+def _examples(n):
+    """SAGE_TEST_EXAMPLES=k runs k times the usual number of random examples (campaigns; profiles/README.md)"""
+    return n * max(1, int(os.environ.get("SAGE_TEST_EXAMPLES", "1")))
 from hypothesis import given, settings, strategies as st
 
 pytestmark = pytest.mark.gpu
@@ -134,7 +140,7 @@ def test_device_update_rejects_far_voxel_indices(gpu_sage):
     assert m.size() == 0
 
 
-@settings(max_examples=12, deadline=None)
+@settings(max_examples=_examples(12), deadline=None)
 @given(seed=st.integers(0, 2**31 - 1), vs=st.sampled_from([0.3, 1.0, 2.5]),
        basic=st.integers(0, 6), critical=st.integers(1, 5), md=st.sampled_from([6.0, 15.0, 400.0]),
        n_pts=st.sampled_from([1, 37, 900, 4000]), frames=st.integers(1, 6))

@@ -8,6 +8,11 @@ import os
 import numpy as np
 import pytest
 
+
+def _examples(n):
+    """SAGE_TEST_EXAMPLES=k runs k times the usual number of random examples (campaigns; profiles/README.md)"""
+    return n * max(1, int(os.environ.get("SAGE_TEST_EXAMPLES", "1")))
+
 from test_robin_order import PyRobin
 
 
@@ -202,7 +207,7 @@ def test_random_update_sequences_against_the_oracle(sage, oracle_ref):
     is the oracle's in mode 3, byte for byte and in order"""
     from hypothesis import given, settings, HealthCheck, strategies as st
 
-    @settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck))
+    @settings(max_examples=_examples(40), deadline=None, suppress_health_check=list(HealthCheck))
     @given(seed=st.integers(0, 2**31 - 1), vs=st.sampled_from([0.5, 1.0, 2.0]), rng_m=st.sampled_from([8.0, 20.0, 45.0]),
            basic=st.integers(1, 6), critical=st.integers(0, 6), step=st.sampled_from([0.0, 3.0, 9.0, 25.0]),
            n_pts=st.sampled_from([1, 40, 600, 3000]))
@@ -237,7 +242,7 @@ def test_random_update_sequences_on_the_device_against_the_oracle(gpu_sage, orac
 
     # (the example: a 64-bucket table whose run wraps around the end of the array — the listed sweep of round 6's first
     # form left one voxel too many; tests/test_robin_order.py holds the host-side half of it)
-    @settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck))
+    @settings(max_examples=_examples(40), deadline=None, suppress_health_check=list(HealthCheck))
     @given(seed=st.integers(0, 2**31 - 1), vs=st.sampled_from([0.5, 1.0, 2.0]), rng_m=st.sampled_from([8.0, 20.0, 45.0]),
            basic=st.integers(1, 6), critical=st.integers(0, 6), step=st.sampled_from([0.0, 3.0, 9.0, 25.0]),
            n_pts=st.sampled_from([1, 40, 600, 3000]))
