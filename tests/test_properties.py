@@ -1,6 +1,8 @@
 """Property tests (hypothesis) of the oracle against the independent pure-Python restatement:
 random clouds, voxel sizes, thresholds and map capacities for the semantic NN (KAT-4) and shard
 additivity of the Gauss-Newton sums (KAT-7)."""
+import os
+
 import numpy as np
 from hypothesis import given, settings, strategies as st
 
@@ -9,7 +11,12 @@ import pyref
 LABELS = [0, 0, 10, 40, 44, 50, 70, 71, 80]
 
 
-@settings(max_examples=25, deadline=None)
+def _examples(n):
+    """SAGE_TEST_EXAMPLES=k runs k times the usual number of random examples (campaigns; profiles/README.md)"""
+    return n * max(1, int(os.environ.get("SAGE_TEST_EXAMPLES", "1")))
+
+
+@settings(max_examples=_examples(25), deadline=None)
 @given(seed=st.integers(0, 2**31 - 1), vs=st.sampled_from([0.3, 0.8, 1.0, 2.5]),
        th=st.sampled_from([0.05, 0.4, 1.0, 1.7]), md=st.sampled_from([0.2, 0.9, 6.0]),
        basic=st.integers(0, 5), critical=st.integers(1, 4), span=st.sampled_from([1.5, 4.0, 9.0]))
@@ -34,7 +41,7 @@ def test_get_correspondences_matches_python(oracle, seed, vs, th, md, basic, cri
     assert m.last_sum_candidates == pm.last_candidates
 
 
-@settings(max_examples=20, deadline=None)
+@settings(max_examples=_examples(20), deadline=None)
 @given(seed=st.integers(0, 2**31 - 1), n=st.integers(1, 300), shards=st.sampled_from([2, 3, 4, 8]),
        kernel=st.sampled_from([0.1, 0.6667, 3.0]))
 def test_gauss_newton_sums_are_shard_additive(oracle, seed, n, shards, kernel):
